@@ -1,0 +1,249 @@
+"""Deterministic synthetic weights / inputs (no pretrained checkpoints exist offline).
+
+Every value is a pure function of (seed, tensor name, flat index): a splitmix64 hash of
+the index, top 24 bits -> uniform in [-1, 1) -> scaled.  Only integer ops and exact
+float64 multiplies are used, so the generated tensors are bit-identical on every
+machine / numpy / torch build (``torch.manual_seed`` gives no such guarantee).  The
+golden-vector script, the CPU oracle, the parity tests and ``bench.py`` all draw their
+weights from here, so "same inputs" is true by construction on both sides of a
+comparison.
+
+The state-dict *key names and shapes* are the reference's checkpoint schema
+(``eva_clip_psz14.pt``: /root/reference/EVA_clip/eva_model.py:177-315,
+vit_model.py:248-310; OpenAI CLIP: EVA_clip/model.py:216-331), so the same dict loads
+into the reference modules via ``load_state_dict`` and into this package's towers.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+_M64 = (1 << 64) - 1
+
+
+def _fnv1a64(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in s.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & _M64
+    return h
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform_pm1(name: str, n: int, seed: int) -> np.ndarray:
+    """n float64 values, uniform on the 2^-23 grid in [-1, 1)."""
+    base = np.uint64((_fnv1a64(name) ^ ((seed * 0x9E3779B97F4A7C15) & _M64)) & _M64)
+    out = np.empty(n, dtype=np.float64)
+    step = 1 << 22
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        with np.errstate(over="ignore"):
+            idx = np.arange(s, e, dtype=np.uint64) + base
+        z = _splitmix64(idx)
+        out[s:e] = (z >> np.uint64(40)).astype(np.float64) * (2.0 / (1 << 24)) - 1.0
+    return out
+
+
+def tensor(name: str, shape, std: float, seed: int, mean: float = 0.0) -> torch.Tensor:
+    """fp32 tensor with the given std (uniform distribution of matching variance)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = uniform_pm1(name, n, seed)
+    v = (u * (std * math.sqrt(3.0)) + mean).astype(np.float32)
+    return torch.from_numpy(v.reshape(tuple(shape)))
+
+
+def frames(name: str, shape, seed: int) -> torch.Tensor:
+    """Synthetic already-normalised frames: unit-variance values (N(0,1)-like)."""
+    return tensor(name, shape, 1.0, seed)
+
+
+def tokens(name: str, batch: int, seed: int, context_length: int = 77,
+           vocab_size: int = 49408) -> torch.Tensor:
+    """Synthetic CLIP token rows: [SOT] ids... [EOT] 0-padding (clip.py:196-232 layout).
+
+    EOT (vocab-1) is the largest id in each row, which is what ``text.argmax(-1)``
+    (eva_model.py:243) relies on.
+    """
+    sot, eot = vocab_size - 2, vocab_size - 1
+    u = uniform_pm1(name, batch * context_length, seed).reshape(batch, context_length)
+    lens = 3 + ((uniform_pm1(name + ".len", batch, seed) + 1.0) * 0.5 * 20).astype(np.int64)
+    ids = ((u + 1.0) * 0.5 * (vocab_size - 1000)).astype(np.int64) + 300
+    out = np.zeros((batch, context_length), dtype=np.int64)
+    for b in range(batch):
+        n = int(lens[b])
+        out[b, 0] = sot
+        out[b, 1:1 + n] = ids[b, :n]
+        out[b, 1 + n] = eot
+    return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------------
+# EVA-CLIP (vision: BEiT-style ViT; text: open_clip-style transformer)
+# ----------------------------------------------------------------------------------
+
+EVA_CLIP_G_14 = {  # /root/reference/EVA_clip/model_configs/EVA_CLIP_g_14.json
+    "embed_dim": 1024,
+    "vision_cfg": {"image_size": 224, "layers": 40, "width": 1408, "head_width": 88,
+                   "mlp_ratio": 4.3637, "patch_size": 14, "drop_path_rate": 0.4},
+    "text_cfg": {"context_length": 77, "vocab_size": 49408, "width": 768, "heads": 12,
+                 "layers": 12},
+}
+
+# A small config with the awkward dimensions of the real one (head_dim 88, 257 tokens,
+# mlp_ratio that truncates) for fast CPU parity checks.
+EVA_CLIP_TINY = {
+    "embed_dim": 64,
+    "vision_cfg": {"image_size": 224, "layers": 2, "width": 176, "head_width": 88,
+                   "mlp_ratio": 4.3637, "patch_size": 14, "drop_path_rate": 0.0},
+    "text_cfg": {"context_length": 77, "vocab_size": 49408, "width": 128, "heads": 2,
+                 "layers": 2},
+}
+
+
+def eva_vision_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
+    v = cfg["vision_cfg"]
+    D, P, L = v["width"], v["patch_size"], v["layers"]
+    N = (v["image_size"] // P) ** 2 + 1
+    Dm = int(D * v["mlp_ratio"])  # vit_model.py:166
+    E = cfg["embed_dim"]
+    s = {"visual.cls_token": (1, 1, D), "visual.pos_embed": (1, N, D),
+         "visual.patch_embed.proj.weight": (D, 3, P, P), "visual.patch_embed.proj.bias": (D,)}
+    for i in range(L):
+        p = f"visual.blocks.{i}."
+        s.update({p + "norm1.weight": (D,), p + "norm1.bias": (D,),
+                  p + "attn.q_bias": (D,), p + "attn.v_bias": (D,),
+                  p + "attn.qkv.weight": (3 * D, D),
+                  p + "attn.proj.weight": (D, D), p + "attn.proj.bias": (D,),
+                  p + "norm2.weight": (D,), p + "norm2.bias": (D,),
+                  p + "mlp.fc1.weight": (Dm, D), p + "mlp.fc1.bias": (Dm,),
+                  p + "mlp.fc2.weight": (D, Dm), p + "mlp.fc2.bias": (D,)})
+    s.update({"visual.norm.weight": (D,), "visual.norm.bias": (D,),
+              "visual.head.weight": (E, D), "visual.head.bias": (E,)})
+    return s
+
+
+def eva_text_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
+    t = cfg["text_cfg"]
+    D, L, E = t["width"], t["layers"], cfg["embed_dim"]
+    s = {"text.token_embedding.weight": (t["vocab_size"], D),
+         "text.positional_embedding": (t["context_length"], D)}
+    for i in range(L):
+        p = f"text.transformer.resblocks.{i}."
+        s.update({p + "ln_1.weight": (D,), p + "ln_1.bias": (D,),
+                  p + "attn.in_proj_weight": (3 * D, D), p + "attn.in_proj_bias": (3 * D,),
+                  p + "attn.out_proj.weight": (D, D), p + "attn.out_proj.bias": (D,),
+                  p + "ln_2.weight": (D,), p + "ln_2.bias": (D,),
+                  p + "mlp.c_fc.weight": (4 * D, D), p + "mlp.c_fc.bias": (4 * D,),
+                  p + "mlp.c_proj.weight": (D, 4 * D), p + "mlp.c_proj.bias": (D,)})
+    s.update({"text.ln_final.weight": (D,), "text.ln_final.bias": (D,),
+              "text.text_projection": (D, E), "text.logit_scale": ()})
+    return s
+
+
+def _layer_index(name: str) -> int:
+    parts = name.split(".")
+    for a, b in zip(parts, parts[1:]):
+        if a in ("blocks", "resblocks", "layer") and b.isdigit():
+            return int(b)
+    return 0
+
+
+def _init_rule(name: str, shape) -> Tuple[float, float]:
+    """(std, mean) per tensor.  Scales follow the reference's own initialisers
+    (vit_model.py:291-318 trunc_normal .02 with proj/fc2 / sqrt(2*layer);
+    eva_model.py:206-222) but biases and LayerNorm affines are made non-trivial so
+    that every bias / affine code path is exercised by the parity tests."""
+    leaf = name.split(".")[-1]
+    if name.endswith("logit_scale"):
+        return 0.0, math.log(1 / 0.07)
+    if "norm" in name or ".ln_" in name or "ln_final" in name or "ln_pre" in name or "ln_post" in name \
+            or "LayerNorm" in name:
+        return (0.1, 1.0) if leaf == "weight" else (0.05, 0.0)
+    if leaf in ("bias", "q_bias", "v_bias", "in_proj_bias"):
+        return 0.02, 0.0
+    if name.endswith("token_embedding.weight"):
+        return 0.02, 0.0
+    if name.endswith("positional_embedding") or name.endswith("pos_embed") or name.endswith("cls_token") \
+            or name.endswith("class_embedding"):
+        return 0.02, 0.0
+    if name.endswith("qkv.weight") or name.endswith("in_proj_weight"):
+        return 0.04, 0.0
+    if name.endswith("attn.proj.weight") or name.endswith("fc2.weight") \
+            or name.endswith("out_proj.weight") or name.endswith("c_proj.weight"):
+        return 0.02 / math.sqrt(2.0 * (_layer_index(name) + 1)), 0.0
+    if name.endswith("text_projection") or name.endswith("visual.proj"):
+        return shape[0] ** -0.5, 0.0
+    return 0.02, 0.0
+
+
+def state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str, torch.Tensor]:
+    out = {}
+    for name, shape in shapes.items():
+        std, mean = _init_rule(name, shape)
+        out[name] = tensor(name, shape, std, seed, mean)
+    return out
+
+
+def eva_clip_state_dict(cfg: dict, seed: int, towers=("visual", "text")) -> Dict[str, torch.Tensor]:
+    shapes = {}
+    if "visual" in towers:
+        shapes.update(eva_vision_shapes(cfg))
+    if "text" in towers:
+        shapes.update(eva_text_shapes(cfg))
+    return state_dict(shapes, seed)
+
+
+# ----------------------------------------------------------------------------------
+# OpenAI CLIP ViT-B/32 as vendored in the reference (EVA_clip/model.py)
+# ----------------------------------------------------------------------------------
+
+OPENAI_VIT_B32 = {"embed_dim": 512, "image_resolution": 224, "vision_layers": 12, "vision_width": 768,
+                  "vision_patch_size": 32, "context_length": 77, "vocab_size": 49408,
+                  "transformer_width": 512, "transformer_heads": 8, "transformer_layers": 12}
+
+OPENAI_VIT_TINY = {"embed_dim": 64, "image_resolution": 224, "vision_layers": 2, "vision_width": 128,
+                   "vision_patch_size": 32, "context_length": 77, "vocab_size": 49408,
+                   "transformer_width": 128, "transformer_heads": 2, "transformer_layers": 2}
+
+
+def openai_clip_shapes(c: dict) -> Dict[str, Tuple[int, ...]]:
+    W, P, E = c["vision_width"], c["vision_patch_size"], c["embed_dim"]
+    G = c["image_resolution"] // P
+    s = {"visual.conv1.weight": (W, 3, P, P), "visual.class_embedding": (W,),
+         "visual.positional_embedding": (G * G + 1, W),
+         "visual.ln_pre.weight": (W,), "visual.ln_pre.bias": (W,)}
+
+    def blocks(prefix, D, L):
+        for i in range(L):
+            p = f"{prefix}.resblocks.{i}."
+            s.update({p + "attn.in_proj_weight": (3 * D, D), p + "attn.in_proj_bias": (3 * D,),
+                      p + "attn.out_proj.weight": (D, D), p + "attn.out_proj.bias": (D,),
+                      p + "ln_1.weight": (D,), p + "ln_1.bias": (D,),
+                      p + "mlp.c_fc.weight": (4 * D, D), p + "mlp.c_fc.bias": (4 * D,),
+                      p + "mlp.c_proj.weight": (D, 4 * D), p + "mlp.c_proj.bias": (D,),
+                      p + "ln_2.weight": (D,), p + "ln_2.bias": (D,)})
+
+    blocks("visual.transformer", W, c["vision_layers"])
+    s.update({"visual.ln_post.weight": (W,), "visual.ln_post.bias": (W,), "visual.proj": (W, E)})
+    T = c["transformer_width"]
+    blocks("transformer", T, c["transformer_layers"])
+    s.update({"token_embedding.weight": (c["vocab_size"], T),
+              "positional_embedding": (c["context_length"], T),
+              "ln_final.weight": (T,), "ln_final.bias": (T,),
+              "text_projection": (T, E), "logit_scale": ()})
+    return s
+
+
+def openai_clip_state_dict(c: dict, seed: int) -> Dict[str, torch.Tensor]:
+    return state_dict(openai_clip_shapes(c), seed)

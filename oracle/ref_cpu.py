@@ -1,0 +1,282 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+A from-scratch, functional fp32 restatement (plain ``torch`` CPU ops on explicit state
+dicts) of the reference's frame/text encoding + cross-modal scoring path.  Only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this file; ``hirest_amd`` never does (it fails loudly when its HIP library is
+missing instead of falling back to anything here).
+
+PARITY PIN: every function below is checked in ``tests/test_oracle_golden.py`` against
+golden vectors in ``tests/golden/*.npz`` that were produced by importing the real
+reference modules from /root/reference in the build container
+(``tests/golden/make_golden.py``, which is committed; the reference itself never
+travels).  Observed agreement oracle-vs-reference: <= 3e-6 relative (fp32 rounding /
+summation order only).
+
+Each function cites the reference file:line it restates.  Paths are relative to
+/root/reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+# ----------------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------------
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    """nn.LayerNorm over the last dim, biased variance (vit_model.py:159,165,285 eps 1e-6;
+    eva_model.py:19-25 eps 1e-5)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def gelu_erf(x: torch.Tensor) -> torch.Tensor:
+    """nn.GELU() default = exact erf form (vit_model.py:47,53; eva_model.py:289)."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def quick_gelu(x: torch.Tensor) -> torch.Tensor:
+    """EVA_clip/model.py:175-177."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+# ----------------------------------------------------------------------------------
+# EVA-CLIP vision tower (EVA_clip/vit_model.py)
+# ----------------------------------------------------------------------------------
+
+def eva_patch_embed(sd: SD, img: torch.Tensor, patch: int) -> torch.Tensor:
+    """PatchEmbed.forward (vit_model.py:185-206): Conv2d(k=s=P)+bias, flatten(2).transpose(1,2);
+    then cls/pos prologue of forward_features (vit_model.py:326-334)."""
+    B, C, H, W = img.shape
+    g = H // patch
+    w = sd["visual.patch_embed.proj.weight"]
+    D = w.shape[0]
+    x = img.reshape(B, C, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * patch * patch)
+    x = x @ w.reshape(D, -1).t() + sd["visual.patch_embed.proj.bias"]
+    x = torch.cat([sd["visual.cls_token"].expand(B, 1, D), x], dim=1)
+    return x + sd["visual.pos_embed"]
+
+
+def eva_attention(sd: SD, p: str, h: torch.Tensor, heads: int) -> torch.Tensor:
+    """Attention.forward (vit_model.py:120-150).  K has no bias; the bias is added
+    BEFORE q is scaled (:124-130); no rel-pos bias (use_rel_pos_bias=False, :254)."""
+    B, N, D = h.shape
+    dh = D // heads
+    bias = torch.cat([sd[p + "attn.q_bias"], torch.zeros(D), sd[p + "attn.v_bias"]])
+    qkv = h @ sd[p + "attn.qkv.weight"].t() + bias
+    qkv = qkv.reshape(B, N, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * dh ** -0.5, qkv[1], qkv[2]
+    a = torch.softmax(q @ k.transpose(-2, -1), dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, N, D)
+    return a @ sd[p + "attn.proj.weight"].t() + sd[p + "attn.proj.bias"]
+
+
+def eva_mlp(sd: SD, p: str, h: torch.Tensor) -> torch.Tensor:
+    """Mlp.forward (vit_model.py:56-62)."""
+    y = gelu_erf(h @ sd[p + "mlp.fc1.weight"].t() + sd[p + "mlp.fc1.bias"])
+    return y @ sd[p + "mlp.fc2.weight"].t() + sd[p + "mlp.fc2.bias"]
+
+
+def eva_block(sd: SD, i: int, x: torch.Tensor, heads: int, eps: float = 1e-6) -> torch.Tensor:
+    """Block.forward, gamma_1 is None branch (vit_model.py:175-178); DropPath = identity in eval."""
+    p = f"visual.blocks.{i}."
+    x = x + eva_attention(sd, p, layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps), heads)
+    x = x + eva_mlp(sd, p, layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps))
+    return x
+
+
+def eva_encode_image(sd: SD, img: torch.Tensor, cfg: dict, n_layers: Optional[int] = None) -> torch.Tensor:
+    """EVA_CLIP.encode_image (eva_model.py:317) -> VisionTransformer.forward (vit_model.py:326-351):
+    patch-embed, cls/pos, L blocks, LayerNorm(eps 1e-6), take token 0, head Linear."""
+    v = cfg["vision_cfg"]
+    assert img.shape[-1] == v["image_size"] and img.shape[-2] == v["image_size"]  # vit_model.py:203
+    heads = v["width"] // v["head_width"]  # eva_model.py:291
+    L = v["layers"] if n_layers is None else n_layers
+    x = eva_patch_embed(sd, img.float(), v["patch_size"])
+    for i in range(L):
+        x = eva_block(sd, i, x, heads)
+    x = layer_norm(x[:, 0], sd["visual.norm.weight"], sd["visual.norm.bias"], 1e-6)
+    return x @ sd["visual.head.weight"].t() + sd["visual.head.bias"]
+
+
+# ----------------------------------------------------------------------------------
+# CLIP-style text towers (eva_model.py:177-250 and EVA_clip/model.py:343-356)
+# ----------------------------------------------------------------------------------
+
+def _mha_block(sd: SD, p: str, x: torch.Tensor, heads: int, mask: Optional[torch.Tensor], act, eps: float = 1e-5):
+    """ResidualAttentionBlock (eva_model.py:110-159 / model.py:180-202) around
+    nn.MultiheadAttention: in_proj rows [q;k;v], each (head, dh); scores/sqrt(dh) + additive mask."""
+    B, L, D = x.shape
+    dh = D // heads
+    h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps)
+    qkv = h @ sd[p + "attn.in_proj_weight"].t() + sd[p + "attn.in_proj_bias"]
+    q, k, v = [t.reshape(B, L, heads, dh).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    s = (q * dh ** -0.5) @ k.transpose(-2, -1)
+    if mask is not None:
+        s = s + mask
+    a = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, D)
+    x = x + a @ sd[p + "attn.out_proj.weight"].t() + sd[p + "attn.out_proj.bias"]
+    h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps)
+    y = act(h @ sd[p + "mlp.c_fc.weight"].t() + sd[p + "mlp.c_fc.bias"])
+    return x + y @ sd[p + "mlp.c_proj.weight"].t() + sd[p + "mlp.c_proj.bias"]
+
+
+def causal_mask(L: int) -> torch.Tensor:
+    """build_attention_mask (eva_model.py:224-230): -inf strictly above the diagonal."""
+    return torch.full((L, L), float("-inf")).triu_(1)
+
+
+def eva_encode_text(sd: SD, tok: torch.Tensor, cfg: dict, n_layers: Optional[int] = None) -> torch.Tensor:
+    """EVA_CLIP.encode_text (eva_model.py:320) -> TextTransformer.forward (:232-250)."""
+    t = cfg["text_cfg"]
+    L = t["layers"] if n_layers is None else n_layers
+    x = sd["text.token_embedding.weight"][tok] + sd["text.positional_embedding"]
+    mask = causal_mask(tok.shape[1])
+    for i in range(L):
+        x = _mha_block(sd, f"text.transformer.resblocks.{i}.", x, t["heads"], mask, gelu_erf)
+    x = layer_norm(x, sd["text.ln_final.weight"], sd["text.ln_final.bias"], 1e-5)
+    x = x[torch.arange(x.shape[0]), tok.argmax(dim=-1)]  # EOT = largest id (:243)
+    return x @ sd["text.text_projection"]
+
+
+def eva_forward(sd: SD, img, tok, cfg: dict):
+    """EVA_CLIP.forward (eva_model.py:323-334)."""
+    if img is None:
+        return eva_encode_text(sd, tok, cfg)
+    if tok is None:
+        return eva_encode_image(sd, img, cfg)
+    return (F.normalize(eva_encode_image(sd, img, cfg), dim=-1),
+            F.normalize(eva_encode_text(sd, tok, cfg), dim=-1),
+            sd["text.logit_scale"].exp())
+
+
+# ----------------------------------------------------------------------------------
+# OpenAI CLIP ViT as vendored by the reference (EVA_clip/model.py) — BASELINE config 1
+# ----------------------------------------------------------------------------------
+
+def openai_encode_image(sd: SD, img: torch.Tensor, c: dict) -> torch.Tensor:
+    """VisionTransformer.forward (model.py:254-273).  NOTE the vendored copy drops the CLS
+    token and returns ln_post(patch tokens) @ proj -> [B, grid^2, E] (SURVEY hazard H4)."""
+    P, W = c["vision_patch_size"], c["vision_width"]
+    B, C, H, _ = img.shape
+    g = H // P
+    x = img.float().reshape(B, C, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * P * P)
+    x = x @ sd["visual.conv1.weight"].reshape(W, -1).t()  # conv1 has no bias (model.py:220)
+    x = torch.cat([sd["visual.class_embedding"].expand(B, 1, W), x], dim=1) + sd["visual.positional_embedding"]
+    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], 1e-5)
+    heads = W // 64  # model.py:299
+    for i in range(c["vision_layers"]):
+        x = _mha_block(sd, f"visual.transformer.resblocks.{i}.", x, heads, None, quick_gelu)
+    x = layer_norm(x[:, 1:], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5)
+    return x @ sd["visual.proj"]
+
+
+def openai_encode_text(sd: SD, tok: torch.Tensor, c: dict) -> torch.Tensor:
+    """CLIP.encode_text (model.py:343-356)."""
+    x = sd["token_embedding.weight"][tok] + sd["positional_embedding"]
+    mask = causal_mask(tok.shape[1])
+    for i in range(c["transformer_layers"]):
+        x = _mha_block(sd, f"transformer.resblocks.{i}.", x, c["transformer_heads"], mask, quick_gelu)
+    x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
+    return x[torch.arange(x.shape[0]), tok.argmax(dim=-1)] @ sd["text_projection"]
+
+
+# ----------------------------------------------------------------------------------
+# pooling, scoring, ranking (inference_video_retrieval.py:283-334, evaluate.py:33-81)
+# ----------------------------------------------------------------------------------
+
+def subsample_ids(n_frames: int, n_model_frames: int) -> np.ndarray:
+    """np.linspace(0, n-1, F).astype(int) (inference_video_retrieval.py:39,315)."""
+    return np.linspace(0, n_frames - 1, n_model_frames).astype(int)
+
+
+def pool_video(frame_embeds: torch.Tensor, normalize_frames_first: bool = False) -> torch.Tensor:
+    """[V,F,E] -> [V,E]: mean over frames then L2 (inference_video_retrieval.py:283-285, 323-327).
+    ``normalize_frames_first`` reproduces extract_features.py:64 features (hazard H2)."""
+    x = frame_embeds.float()
+    if normalize_frames_first:
+        x = x / x.norm(dim=-1, keepdim=True)
+    x = x.mean(dim=1)
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """text_embeds /= text_embeds.norm(dim=-1, keepdim=True) (inference_video_retrieval.py:212)."""
+    x = x.float()
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def similarity(text_n: torch.Tensor, video_n: torch.Tensor) -> torch.Tensor:
+    """torch.matmul(T, V.T) (inference_video_retrieval.py:334)."""
+    return text_n @ video_n.t()
+
+
+def rank_videos(scores_row: Sequence[float], names: Sequence[str]) -> List[str]:
+    """evaluate.py:58-60: sorted(zip(scores, videos)) reversed -> descending score, ties broken
+    by video NAME descending (hazard H5)."""
+    pairs = sorted(zip(scores_row, names))
+    return [n for _, n in pairs[::-1]]
+
+
+def topk_with_ties(scores: torch.Tensor, tie_rank: torch.Tensor, k: int) -> torch.Tensor:
+    """Index form of ``rank_videos``: order by (score desc, tie_rank desc).  tie_rank[v] is the
+    rank of video v's name in ascending name order."""
+    s = scores.double().numpy()
+    t = tie_rank.numpy()
+    out = np.empty((s.shape[0], k), dtype=np.int64)
+    for q in range(s.shape[0]):
+        order = np.lexsort((-t, -s[q]))  # last key is primary
+        out[q] = order[:k]
+    return torch.from_numpy(out)
+
+
+def recall_at_k(scores: torch.Tensor, names: Sequence[str], gt: Sequence[Sequence[str]],
+                ks=(1, 5, 10, 50)) -> Dict[str, float]:
+    """evaluate_video_retrieval, 'all' category (evaluate.py:33-81)."""
+    count = {k: 0 for k in ks}
+    rows = scores.tolist()
+    for q, row in enumerate(rows):
+        ranked = rank_videos(row, names)
+        g = set(gt[q])
+        for k in ks:
+            if any(v in g for v in ranked[:k]):
+                count[k] += 1
+    return {f"R@{k}": count[k] / len(rows) * 100 for k in ks}
+
+
+# ----------------------------------------------------------------------------------
+# timestamp <-> frame index and IoU (hirest_dataset.py:12-68, evaluate.py:25-31)
+# ----------------------------------------------------------------------------------
+
+def frame_index_to_timestamp(frame_index: int, v_duration: float, n_frames: int) -> int:
+    """hirest_dataset.py:42-68 (n_frames < 0 means one frame per second)."""
+    d = int(v_duration)
+    n = d if n_frames < 0 else n_frames
+    bins = np.linspace(0, d - 1, n)
+    return int(bins[frame_index])
+
+
+def timestamp_to_frame_index(t: float, v_duration: float, n_frames: int) -> int:
+    """hirest_dataset.py:12-40: digitize(right=True), clamped to n-1."""
+    d = int(v_duration)
+    n = d if n_frames < 0 else n_frames
+    bins = np.linspace(0, d - 1, n)
+    idx = int(np.digitize(t, bins, right=True))
+    return min(idx, n - 1)
+
+
+def compute_iou(a, b) -> float:
+    """evaluate.py:25-31."""
+    inter = max(0, min(b[1], a[1]) - max(b[0], a[0]))
+    union = min(max(b[1], a[1]) - min(b[0], a[0]), b[1] - b[0] + a[1] - a[0])
+    return float(inter) / (union + 1e-8)

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by running the REAL reference code.
+
+Runs only in the build container (needs /root/reference, read-only).  It imports the
+reference's own modules (EVA_clip/{eva_clip,eva_model,vit_model,model,clip,
+simple_tokenizer}.py, evaluate.py, hirest_dataset.py functions) with a handful of stub
+modules for packages that are not installed offline (timm helpers, torchvision
+transforms, ftfy, tkinter, ...; recipe from SURVEY.md 8c), loads the deterministic
+synthetic weights of ``hirest_amd.synth`` into them with ``load_state_dict(strict=True)``
+and stores inputs-by-seed + reference outputs as small ``.npz``/``.json`` fixtures.
+
+Nothing from the reference is copied: the fixtures hold only numbers.  The GPU box never
+sees /root/reference; tests there compare against these files.
+
+    python tests/golden/make_golden.py [--only NAME ...]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from hirest_amd import synth  # noqa: E402
+
+
+def install_stubs():
+    d = tempfile.mkdtemp(prefix="hirest_stubs_")
+    os.makedirs(f"{d}/timm/models")
+    open(f"{d}/timm/__init__.py", "w").close()
+    open(f"{d}/timm/models/__init__.py", "w").close()
+    with open(f"{d}/timm/models/layers.py", "w") as f:
+        f.write("import torch\n"
+                "def to_2tuple(x):\n    return x if isinstance(x, (tuple, list)) else (x, x)\n"
+                "def drop_path(x, p=0., training=False):\n"
+                "    assert not training, 'golden vectors are eval-mode only'\n    return x\n"
+                "def trunc_normal_(t, mean=0., std=1., a=-2., b=2.):\n    return t\n")
+    with open(f"{d}/timm/models/registry.py", "w") as f:
+        f.write("def register_model(f):\n    return f\n")
+    os.makedirs(f"{d}/tkinter")
+    with open(f"{d}/tkinter/__init__.py", "w") as f:
+        f.write("E = 'e'\n")
+    os.makedirs(f"{d}/torchvision")
+    open(f"{d}/torchvision/__init__.py", "w").close()
+    with open(f"{d}/torchvision/transforms.py", "w") as f:
+        f.write("class _T:\n    def __init__(self, *a, **k):\n        pass\n"
+                "Normalize = Compose = ToTensor = Resize = CenterCrop = _T\n"
+                "class InterpolationMode:\n    BICUBIC = 'bicubic'\n")
+    with open(f"{d}/ftfy.py", "w") as f:
+        f.write("def fix_text(t):\n    return t\n")
+    with open(f"{d}/language_evaluation.py", "w") as f:
+        f.write("")
+    with open(f"{d}/srt.py", "w") as f:
+        f.write("")
+    sys.path.insert(0, d)
+    sys.path.append(f"{REF}/EVA_clip")
+    # the reference's `import clip` (hirest_dataset.py:9) is the pip package; the vendored
+    # EVA_clip/clip.py has the byte-identical tokenizer and is what we import.
+    return d
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def np32(t):
+    return t.detach().float().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------
+
+def gen_eva(cfg_name, cfg, seed, n_img, n_txt, token_rows=(0, 1, 128, 256)):
+    import eva_model  # reference
+    torch.manual_seed(0)
+    model = eva_model.EVA_CLIP(**cfg)
+    sd = synth.eva_clip_state_dict(cfg, seed)
+    print(model.load_state_dict(sd, strict=True))
+    model.eval()
+    img = synth.frames(f"{cfg_name}.img", (n_img, 3, 224, 224), seed + 1)
+    tok = synth.tokens(f"{cfg_name}.tok", n_txt, seed + 2)
+    inter = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            inter[name] = np32(out[:, list(token_rows)])
+        return fn
+    L = cfg["vision_cfg"]["layers"]
+    hs = [model.visual.blocks[0].register_forward_hook(hook("vis_block0")),
+          model.visual.blocks[L - 1].register_forward_hook(hook(f"vis_block_last")),
+          model.visual.blocks[0].attn.register_forward_hook(hook("vis_attn0")),
+          model.visual.blocks[0].mlp.register_forward_hook(hook("vis_mlp0"))]
+    pre = {}
+    hs.append(model.visual.blocks[0].register_forward_pre_hook(
+        lambda m, a: pre.__setitem__("vis_embed", np32(a[0][:, list(token_rows)]))))
+    with torch.no_grad():
+        img_e = model.encode_image(img)
+        txt_e = model.encode_text(tok)
+        fi, ft, ls = model(img, tok)
+        only_t = model(None, tok)
+        only_i = model(img, None)
+    for h in hs:
+        h.remove()
+    assert torch.equal(only_t, txt_e) and torch.equal(only_i, img_e)
+    save(f"{cfg_name}.npz", seed=seed, n_img=n_img, n_txt=n_txt, token_rows=np.array(token_rows),
+         tokens=tok.numpy(), image_embed=np32(img_e), text_embed=np32(txt_e),
+         fwd_image=np32(fi), fwd_text=np32(ft), logit_scale_exp=np32(ls), **inter, **pre)
+
+
+def gen_openai(cfg_name, c, seed, n_img, n_txt, prompts=None):
+    import model as ref_model  # reference EVA_clip/model.py
+    import clip as ref_clip
+    torch.manual_seed(0)
+    m = ref_model.CLIP(c["embed_dim"], c["image_resolution"], c["vision_layers"], c["vision_width"],
+                       c["vision_patch_size"], c["context_length"], c["vocab_size"],
+                       c["transformer_width"], c["transformer_heads"], c["transformer_layers"])
+    sd = synth.openai_clip_state_dict(c, seed)
+    print(m.load_state_dict(sd, strict=True))
+    m.eval().float()
+    img = synth.frames(f"{cfg_name}.img", (n_img, 3, 224, 224), seed + 1)
+    if prompts is not None:
+        tok = ref_clip.tokenize(prompts[:n_txt])
+    else:
+        tok = synth.tokens(f"{cfg_name}.tok", n_txt, seed + 2)
+    with torch.no_grad():
+        pt = m.encode_image(img)          # [B, 49, E]  (vendored ViT drops CLS: hazard H4)
+        te = m.encode_text(tok)
+    fe = pt.mean(dim=1)                   # frame embedding = mean of projected patch tokens (our stated reduction)
+    fn = fe / fe.norm(dim=-1, keepdim=True)
+    tn = te / te.norm(dim=-1, keepdim=True)
+    cos = tn @ fn.t()
+    top5 = cos.topk(min(5, cos.shape[1]), dim=-1).indices
+    save(f"{cfg_name}.npz", seed=seed, n_img=n_img, n_txt=n_txt, tokens=tok.numpy(),
+         patch_tokens_sample=np32(pt[:4]), frame_embed=np32(fe), text_embed=np32(te),
+         cosine=np32(cos), top5=top5.numpy())
+
+
+def gen_tokenizer(prompts):
+    import clip as ref_clip
+    extra = ["a diagram", "A photo of a cat!!", "  multiple   spaces\tand\ttabs  ", "it's John's 3rd try: 42%",
+             "naïve café — “quoted” text", "&amp; html &lt;entities&gt;", "", "UPPER lower MiXeD 12345",
+             "emoji \U0001F600 test", "hyphen-ated words_and_underscores"]
+    texts = list(prompts) + extra
+    ids = ref_clip.tokenize(texts).numpy()
+    long_text = " ".join(["word"] * 100)
+    try:
+        ref_clip.tokenize(long_text)
+        raised = False
+    except RuntimeError:
+        raised = True
+    trunc = ref_clip.tokenize(long_text, truncate=True).numpy()
+    with open(os.path.join(HERE, "tokenizer_texts.json"), "w") as f:
+        json.dump({"texts": texts, "long_text": long_text, "raises_without_truncate": raised}, f, ensure_ascii=False)
+    save("tokenizer.npz", ids=ids.astype(np.int32), truncated=trunc.astype(np.int32))
+
+
+def gen_eval():
+    """evaluate.py:33-81 on a synthetic score matrix with deliberate exact ties (hazard H5),
+    plus compute_iou and the timestamp<->frame-index tables (hirest_dataset.py:12-68)."""
+    sys.path.insert(0, REF)
+    import evaluate as ref_eval
+    # hirest_dataset imports the pip `clip` and `srt`; we only need two pure functions,
+    # so load them through the stubbed import environment.
+    import hirest_dataset as ref_ds
+    gt = json.load(open(f"{REF}/data/splits/all_data_test.json"))
+    neg = json.load(open(f"{REF}/data/splits/all_data_test_negative_samples.json"))
+    prompts = list(gt.keys())[:40]
+    vids = []
+    for p in prompts:
+        vids += list(gt[p].keys())
+    for p in list(neg.keys())[:20]:
+        vids += list(neg[p].keys())
+    seen, names = set(), []
+    for v in vids:
+        if v not in seen:
+            seen.add(v)
+            names.append(v)
+    u = synth.uniform_pm1("eval.scores", len(prompts) * len(names), 5).reshape(len(prompts), len(names))
+    scores = np.round(u * 8).astype(np.float32) / 8.0   # coarse grid => many exact ties
+    ref_eval.PROMPT_CATEGORIES = ["all", "synthetic"]
+    ref_eval.PROMPT_TO_CAT = {p: "synthetic" for p in prompts}
+    sub_gt = {p: gt[p] for p in prompts}
+    pred = {p: {"videos": names, "scores": scores[i].tolist()} for i, p in enumerate(prompts)}
+    res = ref_eval.evaluate_video_retrieval(sub_gt, pred)
+    ranked_top10 = []
+    for i, p in enumerate(prompts):
+        s, v = zip(*sorted(zip(pred[p]["scores"], names)))
+        ranked_top10.append(list(v[::-1][:10]))
+    ious = []
+    pairs = [((0, 10), (5, 15)), ((0, 10), (10, 20)), ((3, 7), (0, 100)), ((0, 1), (0, 1)), ((5, 9), (1, 2)),
+             ((12, 40), (30, 35))]
+    for a, b in pairs:
+        ious.append(ref_eval.compute_iou(list(a), list(b)))
+    ts = []
+    for dur, n in [(200.0, 32), (367.8, -1), (59.9, 20), (1855.2, -1), (12.0, 32)]:
+        nn = int(dur) if n < 0 else n
+        f2t = [ref_ds.frame_index_to_timestamp(i, dur, n) for i in range(nn)]
+        t2f = [ref_ds.timestamp_to_frame_index(t, dur, n) for t in np.arange(0, dur, 1.7)]
+        ts.append({"duration": dur, "n_frames": n, "frame_to_ts": f2t, "ts_to_frame": t2f})
+    with open(os.path.join(HERE, "retrieval_eval.json"), "w") as f:
+        json.dump({"prompts": prompts, "names": names, "gt": {p: list(gt[p].keys()) for p in prompts},
+                   "scores_seed": 5, "recall": res["all"], "ranked_top10": ranked_top10,
+                   "iou_pairs": pairs, "ious": ious, "timestamps": ts}, f)
+    print("wrote retrieval_eval.json", res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    install_stubs()
+    os.chdir(REF)
+    torch.set_num_threads(os.cpu_count())
+    prompts = list(json.load(open(f"{REF}/data/splits/all_data_test.json")).keys())
+    with open(os.path.join(HERE, "test_prompts.json"), "w") as f:
+        json.dump(prompts, f)
+    jobs = {
+        "eva_tiny": lambda: gen_eva("eva_tiny", synth.EVA_CLIP_TINY, 11, 3, 4),
+        "openai_tiny": lambda: gen_openai("openai_tiny", synth.OPENAI_VIT_TINY, 21, 3, 4),
+        "tokenizer": lambda: gen_tokenizer(prompts),
+        "eval": gen_eval,
+        "openai_b32": lambda: gen_openai("openai_b32", synth.OPENAI_VIT_B32, 1, 64, 16, prompts=prompts),
+        "eva_g14": lambda: gen_eva("eva_g14", synth.EVA_CLIP_G_14, 3, 2, 8),
+    }
+    for name, fn in jobs.items():
+        if args.only and name not in args.only:
+            continue
+        print("==", name)
+        fn()
+
+
+if __name__ == "__main__":
+    main()
