@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encoded frames/sec of the EVA-CLIP-g/14 frame encoder (224^2, bf16 MFMA)
+on N MI355X, BASELINE.json configs[1]: a 1024-frame synthetic batch per GPU per step.
+
+One step = the hot path over one batch: 32 videos x 32 frames -> encode_image (40-layer ViT-g)
+-> mean-pool + L2 -> all-gather of the [V,1024] rows over RCCL (identity at N=1) -> 546-query
+cosine matrix -> top-10.  Inputs (bf16 NCHW frames, token ids) are resident in HBM before the
+timed region; weights are random-init of the real architecture (no checkpoints offline).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      live per-launch timing (hipEvent pairs recorded by the library on the launch
+                stream during the timed steps) of the dominant kernel vs the dense bf16 MFMA peak
+  cpu_baseline  the fp32 CPU oracle (oracle/ref_cpu.py, kind "port") timed on this host on a
+                bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FRAMES_PER_STEP = 1024          # configs[1]
+FRAMES_PER_VIDEO = 32
+N_QUERIES = 546                 # size of the real HiREST test prompt set
+TOPK = 10
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
+GFLOP_PER_FRAME = 534.06        # algorithmic work of the vision tower
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=256, help="frames per tower call (micro-batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    import hirest_amd
+    from hirest_amd import _lib, retrieval, synth
+    lib = _lib.load()
+
+    cfg = synth.EVA_CLIP_G_14
+    model = hirest_amd.EVA_CLIP(**cfg).to(dev).eval()
+    model.init_random_(seed=1234)
+    model.visual.max_frames_per_call = args.chunk
+
+    V_local = args.frames // FRAMES_PER_VIDEO
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
+    frames = torch.randn((V_local, FRAMES_PER_VIDEO, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+    tokens = synth.tokens("bench.queries", N_QUERIES, 5).to(dev)
+    text_n = retrieval.encode_texts(model, tokens)            # queries encoded once, outside the frame metric
+    V_total = V_local * world
+
+    def step():
+        pooled = retrieval.encode_videos(model, frames)                     # [V_local, 1024]
+        allv = retrieval.gather_rows(pooled, V_total)                       # RCCL all-gather (no-op at N=1)
+        _, val, idx = retrieval.retrieve(text_n, allv, min(TOPK, V_total))
+        return idx
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.hirest_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    # per-launch records of the timed steps (this rank)
+    recs = (_lib.ProfRecord * 200000)()
+    nrec = lib.hirest_profile_collect(recs, len(recs))
+    lib.hirest_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    out = None
+    if rank == 0:
+        frames_total = args.frames * world * args.steps
+        value = frames_total / elapsed
+        # ---- roofline of the dominant kernel, from the live records
+        groups = {}
+        kinds = {0: "gemm", 1: "attention", 2: "layernorm"}
+        for i in range(max(nrec, 0)):
+            r = recs[i]
+            key = (r.kind, r.tag, r.d0, r.d1, r.d2)
+            g = groups.setdefault(key, [0, 0.0])
+            g[0] += 1
+            g[1] += r.ms
+        total_ms = sum(g[1] for g in groups.values()) or 1.0
+        breakdown = []
+        for (kind, tag, d0, d1, d2), (cnt, ms) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+            ent = {"kernel": kinds.get(kind, str(kind)), "tag": tag, "dims": [d0, d1, d2], "launches": cnt,
+                   "avg_ms": ms / cnt, "share": ms / total_ms}
+            if kind == 0:
+                ent["tflops"] = 2.0 * d0 * d1 * d2 / (ms / cnt * 1e-3) / 1e12
+            elif kind == 1:
+                ent["tflops"] = 4.0 * d0 * d1 * d1 * d2 / (ms / cnt * 1e-3) / 1e12   # QK^T + PV, algorithmic
+            breakdown.append(ent)
+        dom = next((e for e in breakdown if e["kernel"] == "gemm"), None)
+        roofline = None
+        if dom:
+            epi = {0: "bias", 1: "bias+gelu", 2: "bias+quickgelu", 3: "bias+residual", 4: "bias->f32", 5: "patch+pos"}
+            roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                        "kernel": f"gemm_t128<{epi.get(dom['tag'], dom['tag'])}> M={dom['dims'][0]} N={dom['dims'][1]} K={dom['dims'][2]}",
+                        "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                        "algorithmic_flops_per_launch": 2.0 * dom["dims"][0] * dom["dims"][1] * dom["dims"][2],
+                        "whole_tower_tflops": value / world * GFLOP_PER_FRAME / 1e3,
+                        "whole_tower_frac": value / world * GFLOP_PER_FRAME / 1e3 / MFMA_BF16_PEAK_TFLOPS,
+                        "breakdown": breakdown[:12]}
+        out = {"metric": "encoded frames/sec (EVA-CLIP-g/14 224^2)", "value": value, "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "EVA-CLIP-g/14 frame encoder, 1024-frame synthetic batch bf16 per GPU per step "
+                                      "(BASELINE configs[1]) as 32 videos x 32 frames -> mean-pool+L2 -> all-gather "
+                                      "[V,1024] rows -> 546-query cosine top-10; random-init weights",
+                          "frames_per_gpu_per_step": args.frames, "global_batch": args.frames * world,
+                          "micro_batch": args.chunk, "parallelism": f"dp{world}"},
+               "roofline": roofline}
+
+    # ---- CPU baseline: the fp32 oracle on this host's cores, bounded sample (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_cpu
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("visual.")}
+        n = args.cpu_frames
+        sample = frames.reshape(-1, 3, 224, 224)[:n].float().cpu()
+        with torch.no_grad():
+            ref_cpu.eva_encode_image(sd, sample[:1], cfg)       # warm-up
+            t0 = time.perf_counter()
+            cpu_out = ref_cpu.eva_encode_image(sd, sample, cfg)
+            dt = time.perf_counter() - t0
+        gpu_out = model.encode_image(frames.reshape(-1, 3, 224, 224)[:n]).float().cpu()
+        cos = torch.nn.functional.cosine_similarity(cpu_out, gpu_out, dim=-1).min().item()
+        out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{n} frames of the same synthetic batch, full 40-layer EVA-CLIP-g/14 fp32 "
+                                         f"(oracle/ref_cpu.py, torch CPU), 1 warm-up frame + 1 timed pass = {dt:.1f} s",
+                               "min_cosine_gpu_vs_cpu_on_sample": cos}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""ctypes binding of libhirest_hip.so (include/hirest_hip.h).  No torch types cross the boundary:
+device pointers are ``tensor.data_ptr()`` integers, the stream is the raw hipStream_t handle.
+
+There is NO fallback: if the library is missing or fails to load, every op raises.  (The CPU
+oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
+
+EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_POS_F32 = range(6)
+
+ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
+                ("bias", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
+                ("pos", C.c_void_p), ("patches_per_frame", C.c_int32)]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                                          "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VisionTower(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "heads", "head_dim", "mlp_dim",
+                                         "layers", "embed_dim", "kpad", "act")] + \
+               [("ln_eps", C.c_float)] + \
+               [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
+                ("blocks", C.POINTER(BlockWeights)),
+                ("norm_g", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
+                ("image_mean", C.c_void_p), ("image_std", C.c_void_p)]
+
+
+class TextTower(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("context", "vocab", "width", "heads", "layers", "embed_dim", "act")] + \
+               [("ln_eps", C.c_float)] + \
+               [("tok_emb", C.c_void_p), ("pos", C.c_void_p), ("blocks", C.POINTER(BlockWeights)),
+                ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p), ("proj_w", C.c_void_p)]
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("tag", C.c_int32), ("d0", C.c_int64), ("d1", C.c_int64), ("d2", C.c_int64),
+                ("ms", C.c_float)]
+
+
+_SIGNATURES = {
+    "hirest_profile_enable": (C.c_int, [C.c_int32]),
+    "hirest_profile_collect": (C.c_int, [C.POINTER(ProfRecord), C.c_int32]),
+    "hirest_abi_version": (C.c_int, []),
+    "hirest_build_info": (C.c_char_p, []),
+    "hirest_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "hirest_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                   C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_attention_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_float, C.c_int32, C.c_void_p]),
+    "hirest_patchify": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_void_p]),
+    "hirest_write_cls_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_void_p]),
+    "hirest_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hirest_pool_l2norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_similarity_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_topk_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "hirest_vision_workspace_bytes": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),
+    "hirest_vision_forward": (C.c_int, [C.POINTER(VisionTower), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hirest_text_workspace_bytes": (C.c_size_t, [C.POINTER(TextTower), C.c_int32]),
+    "hirest_text_forward": (C.c_int, [C.POINTER(TextTower), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m hirest_amd.build` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.hirest_abi_version() != 1:
+        raise RuntimeError("libhirest_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code == 0:
+        return
+    if code < 0:
+        raise RuntimeError(f"{what}: {ERRORS.get(code, code)}")
+    raise RuntimeError(f"{what}: HIP error {code}")

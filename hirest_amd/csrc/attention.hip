@@ -1,0 +1,178 @@
+// Multi-head self-attention core for short sequences (N <= 272: the ViT's 257 tokens, CLIP's 77).
+// Replaces q@k^T -> softmax -> @v (vit_model.py:131-147; nn.MultiheadAttention core with the
+// additive causal mask of eva_model.py:224-230).
+//
+// One workgroup (4 waves) per (frame, head).  K [N x dh] and V^T [dh x N] of that head live in LDS
+// for the whole block; each wave walks 16-query tiles:
+//   S^T = K . Q^T      v_mfma_f32_16x16x32_bf16(a = K rows from LDS, b = Q rows straight from HBM)
+//   softmax over keys  fully in registers: the C layout of S^T puts query (lane&15) in the lane and
+//                      keys in (lane>>4, reg), so row max / sum are a local reduce + 2 shuffles
+//   O^T = V^T . P^T    the same registers, converted to bf16, ARE the B operand (k-slots permuted
+//                      consistently on the V^T side: slot j<4 -> key 32s+4g+j, j>=4 -> 32s+16+4g+j-4)
+// so P never leaves registers and O^T leaves each lane with 4 consecutive head-dim values (8-B stores).
+// Head dim 88 is zero-padded to 96 for the QK^T contraction; padded keys are masked to -inf.
+#include "common.h"
+#include "profile.h"
+
+namespace {
+
+template <int DH, int DP, int NT>
+struct AttnCfg {
+    static constexpr int NPAD = 16 * NT;
+    static constexpr int KS = (NT + 1) / 2;        // 32-key steps for P.V
+    static constexpr int KP = 32 * KS;
+    static constexpr int KRS = DP * 2 + 16;        // K row stride (bytes), padded
+    static constexpr int VRS = KP * 2 + 16;        // V^T row stride (bytes), padded
+    static constexpr int LDS_BYTES = NPAD * KRS + DP * VRS;
+};
+
+template <int DH, int DP, int NT>
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       int N, int H, float scale_log2e, int causal) {
+    using C = AttnCfg<DH, DP, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + C::NPAD * C::KRS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * DH;
+
+    // ---- stage K (row-major, zero padded) ----
+    constexpr int KCH = DP / 8;
+    for (int idx = tid; idx < C::NPAD * KCH; idx += 256) {
+        const int key = idx / KCH, ch = idx - key * KCH;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < N && ch * 8 < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + D + ch * 8);
+        *reinterpret_cast<bf16x8*>(Ks + key * C::KRS + ch * 16) = v;
+    }
+    // ---- stage V transposed: Vt[d][key] ----
+    constexpr int VCH = DH / 8;
+    for (int idx = tid; idx < C::KP * VCH; idx += 256) {
+        const int ch = idx / C::KP, key = idx - ch * C::KP;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < N) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + 2 * D + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16_t*>(Vt + (ch * 8 + e) * C::VRS + key * 2) = v[e];
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, c16 = lane & 15;
+    const int nqt = (N + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + c16;
+        const bool qvalid = q < N;
+        bf16x8 qf[DP / 32];
+#pragma unroll
+        for (int kk = 0; kk < DP / 32; ++kk) {
+            const int d = (kk * 4 + g) * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qvalid && d < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * ld + d);
+            qf[kk] = v;
+        }
+        // ---- S^T tiles ----
+        f32x4 st[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < DP / 32; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::KRS + (kk * 4 + g) * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+            }
+            st[t] = acc;
+        }
+        // ---- mask + softmax (fp32) ----
+        const int klimit = causal ? (q < N - 1 ? q : N - 1) : N - 1;   // last visible key
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = t * 16 + 4 * g + i;
+                const float s = key <= klimit ? st[t][i] : -3.0e38f;
+                st[t][i] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pz = exp2f((st[t][i] - mx) * scale_log2e);
+                st[t][i] = pz;
+                sum += pz;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        // ---- P^T as bf16 B fragments ----
+        bf16x8 pf[C::KS];
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf[s][i] = (bf16_t)st[2 * s][i];
+                if (2 * s + 1 < NT) pf[s][4 + i] = (bf16_t)st[2 * s + 1][i];
+                else pf[s][4 + i] = (bf16_t)0.f;
+            }
+        }
+        // ---- O^T = V^T . P^T ----
+#pragma unroll 1
+        for (int dt = 0; dt < DP / 16; ++dt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const char* vrow = Vt + (dt * 16 + c16) * C::VRS + 8 * g;
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + s * 64);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + s * 64 + 32);
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s], acc, 0, 0, 0);
+            }
+            const int d = dt * 16 + 4 * g;
+            if (qvalid && d < DH) {
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(acc[i] * inv);
+                *reinterpret_cast<bf16x4*>(out + ((int64_t)b * N + q) * D + h * DH + d) = o;
+            }
+        }
+    }
+}
+
+template <int DH, int DP, int NT>
+int launch(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
+    using C = AttnCfg<DH, DP, NT>;
+    static bool configured = false;
+    auto kern = attention_kernel<DH, DP, NT>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), C::LDS_BYTES, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
+    return hirest_launch_status();
+}
+
+}  // namespace
+
+extern "C" int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out, int32_t B, int32_t N, int32_t H,
+                                     int32_t dh, float scale, int32_t causal, void* stream) {
+    if (!qkv || !out || B <= 0 || N <= 0 || H <= 0) return HIREST_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
+    bf16_t* o = reinterpret_cast<bf16_t*>(out);
+    HirestProfScope prof(HIREST_PROF_ATTENTION, causal, (int64_t)B * H, N, dh, s);
+    if (dh == 88) {
+        if (N <= 80) return launch<88, 96, 5>(q, o, B, N, H, scale, causal, s);
+        if (N <= 272) return launch<88, 96, 17>(q, o, B, N, H, scale, causal, s);
+    } else if (dh == 64) {
+        if (N <= 80) return launch<64, 64, 5>(q, o, B, N, H, scale, causal, s);
+        if (N <= 272) return launch<64, 64, 17>(q, o, B, N, H, scale, causal, s);
+    }
+    return HIREST_E_SHAPE;
+}

@@ -1,0 +1,242 @@
+// HBM-bound row kernels around the GEMMs: LayerNorm, patch extraction, CLS/pos prologue,
+// token embedding + EOT index, dtype casts.  One wave per row, 16-B vector accesses.
+#include "common.h"
+#include "profile.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (float4 per lane per step), two-pass
+// statistics in fp32 (mean, then E[(x-mean)^2]) exactly like nn.LayerNorm's definition.
+// ---------------------------------------------------------------------------------------------
+template <int NV, bool OUT_F32>   // NV = ceil(D/4/64) float4 per lane
+__global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, int64_t ldx,
+                                                     const int32_t* __restrict__ row_index,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, void* __restrict__ out, int64_t ldo, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t src = row_index ? (int64_t)row_index[row] : (int64_t)row;
+    const float* xr = x + src * ldx;
+    const int nv = D >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if constexpr (OUT_F32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)row * ldo + 4 * c) = y;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)y[e];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + (int64_t)row * ldo + 4 * c) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch extraction.  One thread produces 8 consecutive k-columns (16 B of bf16) of one patch row.
+// Column k = c*P*P + ph*P + pw (conv weight flatten order, vit_model.py:198).
+// ---------------------------------------------------------------------------------------------
+template <int IN_DTYPE>
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ frames, int B, int S, int P,
+                                                      const float* __restrict__ mean3, const float* __restrict__ std3,
+                                                      bf16_t* __restrict__ patches, int Kpad) {
+    const int G = S / P, PP = P * P, K = 3 * PP;
+    const int chunks = Kpad >> 3;
+    const int64_t total = (int64_t)B * G * G * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % chunks);
+        const int64_t prow = idx / chunks;
+        const int pw_i = (int)(prow % G);
+        const int ph_i = (int)((prow / G) % G);
+        const int b = (int)(prow / ((int64_t)G * G));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            float val = 0.f;
+            if (k < K) {
+                const int c = k / PP, rr = k - c * PP;
+                const int dy = rr / P, dx = rr - dy * P;
+                const int y = ph_i * P + dy, xx = pw_i * P + dx;
+                if constexpr (IN_DTYPE == 0) {
+                    val = reinterpret_cast<const float*>(frames)[(((int64_t)b * 3 + c) * S + y) * S + xx];
+                } else if constexpr (IN_DTYPE == 1) {
+                    val = (float)reinterpret_cast<const bf16_t*>(frames)[(((int64_t)b * 3 + c) * S + y) * S + xx];
+                } else {
+                    const float u = (float)reinterpret_cast<const uint8_t*>(frames)[(((int64_t)b * S + y) * S + xx) * 3 + c];
+                    val = (u / 255.0f - mean3[c]) / std3[c];
+                }
+            }
+            o[e] = (bf16_t)val;
+        }
+        *reinterpret_cast<bf16x8*>(patches + prow * Kpad + ch * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, int64_t ldx, const float* __restrict__ cls,
+                                                      const float* __restrict__ pos0, int B, int T, int D) {
+    const int nv = D >> 2;
+    const int64_t total = (int64_t)B * nv;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % nv);
+        const int b = (int)(idx / nv);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(cls + 4 * c);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pos0 + 4 * c);
+        *reinterpret_cast<f32x4*>(x + (int64_t)b * T * ldx + 4 * c) = a + p;
+    }
+}
+
+// one wave per (b,t) row; wave 0 of each batch row's first block also computes the EOT index
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                                          const float* __restrict__ pos, float* __restrict__ x,
+                                                          int32_t* __restrict__ eot_row, int B, int L, int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L, t = row - b * L;
+    int64_t id = tokens[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* e = tok_emb + id * D;
+    const float* p = pos + (int64_t)t * D;
+    float* o = x + (int64_t)row * D;
+    for (int c = lane; c < (D >> 2); c += 64)
+        *reinterpret_cast<f32x4*>(o + 4 * c) = *reinterpret_cast<const f32x4*>(e + 4 * c) + *reinterpret_cast<const f32x4*>(p + 4 * c);
+    if (t == 0 && eot_row) {
+        // argmax over the L token ids, first maximum (torch.argmax semantics on distinct maxima)
+        int64_t best = -1; int bi = 0;
+        for (int i = lane; i < L; i += 64) {
+            const int64_t v = tokens[(int64_t)b * L + i];
+            if (v > best) { best = v; bi = i; }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            const int64_t ov = __shfl_xor(best, o2, 64);
+            const int oi = __shfl_xor(bi, o2, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) eot_row[b] = b * L + bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + 4 * i);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x4*>(out + 4 * i) = o;
+    }
+}
+
+inline int grid_for(int64_t total, int block = 256, int cap = 256 * 8) {
+    int64_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <bool OUT_F32>
+int launch_ln(const float* x, int64_t ldx, const int32_t* ri, const float* g, const float* b, float eps, void* out,
+              int64_t ldo, int rows, int D, hipStream_t s) {
+    int nv = (D / 4 + 63) / 64;
+    if (nv > 8) nv = nv <= 12 ? 12 : (nv <= 16 ? 16 : (nv <= 24 ? 24 : 32));  // round up to an instantiated size
+    dim3 grid((rows + 3) / 4), block(256);
+#define LN_CASE(NVV) \
+    case NVV: hipLaunchKernelGGL((layernorm_rows<NVV, OUT_F32>), grid, block, 0, s, x, ldx, ri, g, b, eps, out, ldo, rows, D); break;
+    switch (nv) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+        LN_CASE(12) LN_CASE(16) LN_CASE(24) LN_CASE(32)
+        default: return HIREST_E_SHAPE;
+    }
+#undef LN_CASE
+    return hirest_launch_status();
+}
+
+}  // namespace
+
+extern "C" int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_index, const float* gamma,
+                                const float* beta, float eps, void* out, int64_t ldo, int32_t out_is_f32,
+                                int32_t rows, int32_t D, void* stream) {
+    if (!x || !gamma || !beta || !out || rows <= 0) return HIREST_E_BADARG;
+    if (D <= 0 || D % 4 != 0 || D > 8192 || ldx % 4 != 0 || ldo % 4 != 0) return HIREST_E_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HirestProfScope prof(HIREST_PROF_LAYERNORM, 0, rows, D, 0, s);
+    if (out_is_f32) return launch_ln<true>(x, ldx, row_index, gamma, beta, eps, out, ldo, rows, D, s);
+    return launch_ln<false>(x, ldx, row_index, gamma, beta, eps, out, ldo, rows, D, s);
+}
+
+extern "C" int hirest_patchify(const void* frames, int32_t in_dtype, int32_t B, int32_t S, int32_t P,
+                               const float* mean3, const float* std3, hirest_bf16* patches, int32_t Kpad, void* stream) {
+    if (!frames || !patches || B <= 0 || S <= 0 || P <= 0) return HIREST_E_BADARG;
+    if (S % P != 0 || Kpad % 8 != 0 || Kpad < 3 * P * P) return HIREST_E_SHAPE;
+    if (in_dtype == 2 && (!mean3 || !std3)) return HIREST_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int G = S / P;
+    const int64_t total = (int64_t)B * G * G * (Kpad / 8);
+    dim3 grid(grid_for(total, 256, 256 * 16)), block(256);
+    bf16_t* o = reinterpret_cast<bf16_t*>(patches);
+    switch (in_dtype) {
+        case 0: hipLaunchKernelGGL(patchify_kernel<0>, grid, block, 0, s, frames, B, S, P, mean3, std3, o, Kpad); break;
+        case 1: hipLaunchKernelGGL(patchify_kernel<1>, grid, block, 0, s, frames, B, S, P, mean3, std3, o, Kpad); break;
+        case 2: hipLaunchKernelGGL(patchify_kernel<2>, grid, block, 0, s, frames, B, S, P, mean3, std3, o, Kpad); break;
+        default: return HIREST_E_BADARG;
+    }
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_write_cls_rows(float* x, int64_t ldx, const float* cls, const float* pos0, int32_t B,
+                                     int32_t tokens_per_frame, int32_t D, void* stream) {
+    if (!x || !cls || !pos0 || B <= 0) return HIREST_E_BADARG;
+    if (D % 4 != 0 || ldx % 4 != 0) return HIREST_E_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for((int64_t)B * (D / 4))), dim3(256), 0, s, x, ldx, cls, pos0, B,
+                       tokens_per_frame, D);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_embed_tokens(const int64_t* tokens, const float* tok_emb, const float* pos, float* x,
+                                   int32_t* eot_row, int32_t B, int32_t L, int32_t D, int32_t vocab, void* stream) {
+    if (!tokens || !tok_emb || !pos || !x || B <= 0 || L <= 0) return HIREST_E_BADARG;
+    if (D % 4 != 0) return HIREST_E_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((B * L + 3) / 4), dim3(256), 0, s, tokens, tok_emb, pos, x, eot_row, B, L, D, vocab);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_f32_to_bf16(const float* in, hirest_bf16* out, int64_t n, void* stream) {
+    if (!in || !out || n <= 0) return HIREST_E_BADARG;
+    if (n % 4 != 0) return HIREST_E_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, in, reinterpret_cast<bf16_t*>(out), n / 4);
+    return hirest_launch_status();
+}

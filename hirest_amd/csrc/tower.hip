@@ -1,0 +1,130 @@
+// Tower runners: enqueue one full forward of a pre-LN transformer tower on a stream.
+//   vision: EVA ViT  (vit_model.py:326-351)   frames -> [B, embed_dim]
+//   text:   CLIP text transformer (eva_model.py:232-250)   token ids -> [B, embed_dim]
+// Pure orchestration of the kernels in gemm/attention/elementwise; no allocation, no sync.
+//
+// Workspace (B frames, M = B*T tokens), every region 256-B aligned:
+//   x    f32  [M, D]                     residual stream (fp32: 40 residual adds stay exact-ish)
+//   h    bf16 [M, D]                     LN output / attention output (never live together)
+//   big  bf16 [M, max(3D, Dm, kpad*)]    qkv / MLP hidden / patches (never live together)
+//   eot  i32  [B]                        text only
+#include "common.h"
+
+namespace {
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Regions {
+    size_t x, h, big, eot, total;
+};
+
+Regions plan(int64_t M, int D, int wide, int B) {
+    Regions r;
+    size_t off = 0;
+    r.x = off; off += align256((size_t)M * D * 4);
+    r.h = off; off += align256((size_t)M * D * 2);
+    r.big = off; off += align256((size_t)M * wide * 2);
+    r.eot = off; off += align256((size_t)B * 4);
+    r.total = off;
+    return r;
+}
+
+inline int vision_wide(const hirest_vision_tower* t) {
+    int w = 3 * t->width;
+    if (t->mlp_dim > w) w = t->mlp_dim;
+    if (t->kpad > w) w = t->kpad;
+    return w;
+}
+
+#define CHECK(expr) do { int _e = (expr); if (_e != 0) return _e; } while (0)
+
+int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int M, int N,
+         int K, int epi, void* stream, const float* pos = nullptr, int P = 0) {
+    hirest_gemm_args a;
+    a.A = reinterpret_cast<const hirest_bf16*>(A); a.lda = lda;
+    a.W = reinterpret_cast<const hirest_bf16*>(W); a.ldw = ldw;
+    a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
+    a.pos = pos; a.patches_per_frame = P;
+    return hirest_gemm_bf16(&a, stream);
+}
+
+// one pre-LN block: x += proj(attn(LN1 x)); x += fc2(act(fc1(LN2 x)))
+int run_block(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf16* big, int B, int T, int D, int heads,
+              int dh, int Dm, float eps, int act, int causal, void* stream) {
+    const int M = B * T;
+    CHECK(hirest_layernorm(x, D, nullptr, w.ln1_g, w.ln1_b, eps, h, D, 0, M, D, stream));
+    CHECK(gemm(h, D, w.qkv_w, D, w.qkv_b, big, 3 * D, M, 3 * D, D, HIREST_EPI_BIAS_BF16, stream));
+    CHECK(hirest_attention_bf16(big, h, B, T, heads, dh, 1.0f / sqrtf((float)dh), causal, stream));
+    CHECK(gemm(h, D, w.proj_w, D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_F32, stream));
+    CHECK(hirest_layernorm(x, D, nullptr, w.ln2_g, w.ln2_b, eps, h, D, 0, M, D, stream));
+    CHECK(gemm(h, D, w.fc1_w, D, w.fc1_b, big, Dm, M, Dm, D,
+               act == 1 ? HIREST_EPI_BIAS_QGELU_BF16 : HIREST_EPI_BIAS_GELU_BF16, stream));
+    CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_F32, stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int hirest_abi_version(void) { return HIREST_ABI_VERSION; }
+
+extern "C" const char* hirest_build_info(void) {
+    return "hirest_hip gfx950 (CDNA4) | gemm t128 32x32x16 bf16 MFMA + LDS-DMA | attention 16x16x32 bf16 MFMA | " __VERSION__;
+}
+
+extern "C" size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B) {
+    if (!t || B <= 0) return 0;
+    const int T = (t->image_size / t->patch) * (t->image_size / t->patch) + 1;
+    return plan((int64_t)B * T, t->width, vision_wide(t), B).total;
+}
+
+extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* frames, int32_t in_dtype, int32_t B,
+                                     float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!t || !frames || !out || !workspace || B <= 0 || !t->blocks) return HIREST_E_BADARG;
+    if (t->width != t->heads * t->head_dim || t->image_size % t->patch != 0) return HIREST_E_SHAPE;
+    const int G = t->image_size / t->patch, P = G * G, T = P + 1, D = t->width;
+    const Regions r = plan((int64_t)B * T, D, vision_wide(t), B);
+    if (workspace_bytes < r.total) return HIREST_E_WORKSPACE;
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* x = reinterpret_cast<float*>(ws + r.x);
+    hirest_bf16* h = reinterpret_cast<hirest_bf16*>(ws + r.h);
+    hirest_bf16* big = reinterpret_cast<hirest_bf16*>(ws + r.big);
+
+    // patch-embed: im2col -> GEMM whose epilogue adds bias + pos and scatters to rows b*T+1+p; CLS rows
+    CHECK(hirest_patchify(frames, in_dtype, B, t->image_size, t->patch, t->image_mean, t->image_std, big, t->kpad, stream));
+    CHECK(gemm(big, t->kpad, t->patch_w, t->kpad, t->patch_b, x, D, B * P, D, t->kpad, HIREST_EPI_PATCH_POS_F32, stream,
+               t->pos, P));
+    CHECK(hirest_write_cls_rows(x, D, t->cls, t->pos, B, T, D, stream));
+    for (int l = 0; l < t->layers; ++l)
+        CHECK(run_block(t->blocks[l], x, h, big, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps, t->act, 0, stream));
+    // norm on the CLS rows only (LayerNorm is per-row, so norm(x)[:,0] == norm(x[:,0])), then head
+    CHECK(hirest_layernorm(x, (int64_t)T * D, nullptr, t->norm_g, t->norm_b, t->ln_eps, h, D, 0, B, D, stream));
+    CHECK(gemm(h, D, t->head_w, D, t->head_b, out, t->embed_dim, B, t->embed_dim, D, HIREST_EPI_BIAS_F32, stream));
+    return 0;
+}
+
+extern "C" size_t hirest_text_workspace_bytes(const hirest_text_tower* t, int32_t B) {
+    if (!t || B <= 0) return 0;
+    return plan((int64_t)B * t->context, t->width, 4 * t->width, B).total;
+}
+
+extern "C" int hirest_text_forward(const hirest_text_tower* t, const int64_t* tokens, int32_t B, float* out,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!t || !tokens || !out || !workspace || B <= 0 || !t->blocks) return HIREST_E_BADARG;
+    if (t->width % t->heads != 0) return HIREST_E_SHAPE;
+    const int L = t->context, D = t->width, dh = D / t->heads;
+    const Regions r = plan((int64_t)B * L, D, 4 * D, B);
+    if (workspace_bytes < r.total) return HIREST_E_WORKSPACE;
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* x = reinterpret_cast<float*>(ws + r.x);
+    hirest_bf16* h = reinterpret_cast<hirest_bf16*>(ws + r.h);
+    hirest_bf16* big = reinterpret_cast<hirest_bf16*>(ws + r.big);
+    int32_t* eot = reinterpret_cast<int32_t*>(ws + r.eot);
+
+    CHECK(hirest_embed_tokens(tokens, t->tok_emb, t->pos, x, eot, B, L, D, t->vocab, stream));
+    for (int l = 0; l < t->layers; ++l)
+        CHECK(run_block(t->blocks[l], x, h, big, B, L, D, t->heads, dh, 4 * D, t->ln_eps, t->act, 1, stream));
+    // ln_final on the EOT rows only, then @ text_projection
+    CHECK(hirest_layernorm(x, D, eot, t->lnf_g, t->lnf_b, t->ln_eps, h, D, 0, B, D, stream));
+    CHECK(gemm(h, D, t->proj_w, D, nullptr, out, t->embed_dim, B, t->embed_dim, D, HIREST_EPI_BIAS_F32, stream));
+    return 0;
+}

@@ -1,0 +1,152 @@
+"""Tensor-level wrappers over the C ABI (one function per kernel entry point).
+
+torch is used for device memory and the current stream only; every computation below is a
+hand-written gfx950 kernel inside libhirest_hip.so.  All wrappers validate device / dtype /
+contiguity and raise RuntimeError on violations (the reference's ATen ops raise likewise).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS_BF16, EPI_BIAS_F32, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32,
+                   EPI_PATCH_POS_F32)
+
+__all__ = ["gemm", "layernorm", "attention", "patchify", "write_cls_rows", "embed_tokens", "to_bf16",
+           "pool_l2norm", "similarity", "topk", "stream_ptr"]
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype, name: str) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
+    return None if t is None else _dev(t, dtype, name)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epilogue: int,
+         pos: Optional[torch.Tensor] = None, patches_per_frame: int = 0) -> torch.Tensor:
+    """out <- epilogue(a @ w.T + bias); a [M,K] bf16, w [N,K] bf16, bias [N] f32."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
+    out_dtype = torch.bfloat16 if epilogue in (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16) else torch.float32
+    args = _lib.GemmArgs(_dev(a, torch.bfloat16, "gemm.a"), K, _dev(w, torch.bfloat16, "gemm.w"), K,
+                         _opt(bias, torch.float32, "gemm.bias"), _dev(out, out_dtype, "gemm.out"), out.shape[-1],
+                         M, N, K, epilogue, _opt(pos, torch.float32, "gemm.pos"), patches_per_frame)
+    _lib.check(lib.hirest_gemm_bf16(C.byref(args), stream_ptr()), "hirest_gemm_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor,
+              row_index: Optional[torch.Tensor] = None, ldx: Optional[int] = None, rows: Optional[int] = None):
+    lib = _lib.load()
+    D = gamma.numel()
+    rows = rows if rows is not None else (row_index.numel() if row_index is not None else x.numel() // D)
+    ldx = ldx if ldx is not None else D
+    out_f32 = 1 if out.dtype == torch.float32 else 0
+    _lib.check(lib.hirest_layernorm(_dev(x, torch.float32, "ln.x"), ldx, _opt(row_index, torch.int32, "ln.row_index"),
+                                    _dev(gamma, torch.float32, "ln.gamma"), _dev(beta, torch.float32, "ln.beta"),
+                                    float(eps), _dev(out, out.dtype, "ln.out"), D, out_f32, rows, D, stream_ptr()),
+               "hirest_layernorm")
+    return out
+
+
+def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, N: int, H: int, dh: int, causal: bool,
+              scale: Optional[float] = None):
+    lib = _lib.load()
+    scale = dh ** -0.5 if scale is None else scale
+    _lib.check(lib.hirest_attention_bf16(_dev(qkv, torch.bfloat16, "attn.qkv"), _dev(out, torch.bfloat16, "attn.out"),
+                                         B, N, H, dh, float(scale), int(bool(causal)), stream_ptr()),
+               "hirest_attention_bf16")
+    return out
+
+
+_IN_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.uint8: 2}
+
+
+def patchify(frames: torch.Tensor, patch: int, kpad: int, out: torch.Tensor, mean=None, std=None):
+    lib = _lib.load()
+    if frames.dtype not in _IN_DTYPES:
+        raise RuntimeError(f"patchify: unsupported frame dtype {frames.dtype}")
+    code = _IN_DTYPES[frames.dtype]
+    B = frames.shape[0]
+    S = frames.shape[-1] if code != 2 else frames.shape[1]
+    _lib.check(lib.hirest_patchify(_dev(frames, frames.dtype, "patchify.frames"), code, B, S, patch,
+                                   _opt(mean, torch.float32, "mean"), _opt(std, torch.float32, "std"),
+                                   _dev(out, torch.bfloat16, "patchify.out"), kpad, stream_ptr()), "hirest_patchify")
+    return out
+
+
+def write_cls_rows(x: torch.Tensor, cls: torch.Tensor, pos0: torch.Tensor, B: int, T: int, D: int):
+    lib = _lib.load()
+    _lib.check(lib.hirest_write_cls_rows(_dev(x, torch.float32, "x"), D, _dev(cls, torch.float32, "cls"),
+                                         _dev(pos0, torch.float32, "pos"), B, T, D, stream_ptr()), "hirest_write_cls_rows")
+    return x
+
+
+def embed_tokens(tokens: torch.Tensor, tok_emb: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, eot_row: torch.Tensor):
+    lib = _lib.load()
+    B, L = tokens.shape
+    V, D = tok_emb.shape
+    _lib.check(lib.hirest_embed_tokens(_dev(tokens, torch.int64, "tokens"), _dev(tok_emb, torch.float32, "tok_emb"),
+                                       _dev(pos, torch.float32, "pos"), _dev(x, torch.float32, "x"),
+                                       _dev(eot_row, torch.int32, "eot_row"), B, L, D, V, stream_ptr()), "hirest_embed_tokens")
+    return x
+
+
+def to_bf16(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 (RNE) on device through the library's cast kernel."""
+    lib = _lib.load()
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    n = t.numel()
+    if n % 4 != 0:
+        raise RuntimeError("to_bf16: element count must be a multiple of 4")
+    _lib.check(lib.hirest_f32_to_bf16(_dev(t, torch.float32, "to_bf16.in"), out.data_ptr(), n, stream_ptr()), "hirest_f32_to_bf16")
+    return out
+
+
+def pool_l2norm(frame_embeds: torch.Tensor, normalize_frames_first: bool = False) -> torch.Tensor:
+    """[V,F,E] f32 -> [V,E]: mean over frames then L2 (inference_video_retrieval.py:283-285)."""
+    lib = _lib.load()
+    V, F, E = frame_embeds.shape
+    out = torch.empty((V, E), dtype=torch.float32, device=frame_embeds.device)
+    _lib.check(lib.hirest_pool_l2norm(_dev(frame_embeds, torch.float32, "pool.in"), out.data_ptr(), V, F, E,
+                                      int(bool(normalize_frames_first)), stream_ptr()), "hirest_pool_l2norm")
+    return out
+
+
+def similarity(text_n: torch.Tensor, video_n: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    Q, E = text_n.shape
+    V = video_n.shape[0]
+    out = torch.empty((Q, V), dtype=torch.float32, device=text_n.device)
+    _lib.check(lib.hirest_similarity_f32(_dev(text_n, torch.float32, "sim.text"), _dev(video_n, torch.float32, "sim.video"),
+                                         out.data_ptr(), Q, V, E, stream_ptr()), "hirest_similarity_f32")
+    return out
+
+
+def topk(scores: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
+    lib = _lib.load()
+    Q, V = scores.shape
+    idx = torch.empty((Q, k), dtype=torch.int32, device=scores.device)
+    val = torch.empty((Q, k), dtype=torch.float32, device=scores.device)
+    _lib.check(lib.hirest_topk_f32(_dev(scores, torch.float32, "topk.scores"), _opt(tie_rank, torch.int32, "topk.tie_rank"),
+                                   Q, V, k, idx.data_ptr(), val.data_ptr(), stream_ptr()), "hirest_topk_f32")
+    return val, idx

@@ -101,10 +101,11 @@ EVA_CLIP_G_14 = {  # /root/reference/EVA_clip/model_configs/EVA_CLIP_g_14.json
 }
 
 # A small config with the awkward dimensions of the real one (head_dim 88, 257 tokens,
-# mlp_ratio that truncates) for fast CPU parity checks.
+# mlp_ratio that truncates) for fast CPU parity checks.  Widths are multiples of 64 (the
+# GEMM's K granule): 704 = 8 heads x 88.
 EVA_CLIP_TINY = {
     "embed_dim": 64,
-    "vision_cfg": {"image_size": 224, "layers": 2, "width": 176, "head_width": 88,
+    "vision_cfg": {"image_size": 224, "layers": 2, "width": 704, "head_width": 88,
                    "mlp_ratio": 4.3637, "patch_size": 14, "drop_path_rate": 0.0},
     "text_cfg": {"context_length": 77, "vocab_size": 49408, "width": 128, "heads": 2,
                  "layers": 2},

@@ -1,0 +1,207 @@
+/*
+ * hirest_hip.h — C ABI of libhirest_hip.so, the MI355X (gfx950) implementation of HiREST's
+ * frame/text encoding + cross-modal scoring hot path.
+ *
+ * The reference has no FFI of its own: its boundary is the duck-typed Python surface
+ *   EVA_CLIP.encode_image / encode_text / forward      (EVA_clip/eva_model.py:317-334)
+ *   build_eva_model_and_transforms                      (EVA_clip/eva_clip.py:155-172)
+ *   mean-pool + L2 + text @ video.T                     (inference_video_retrieval.py:283-285,323-334)
+ *   sort-by-score ranking, R@k                          (evaluate.py:58-69)
+ * and every "kernel" underneath is a stock ATen op.  This header is the seam a
+ * maintainer binds instead (ctypes stub in INTEGRATION.md): plain device pointers and
+ * sizes, no torch types.  Conventions for every entry point:
+ *   - all pointers are DEVICE pointers unless the name says host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing
+ *     synchronises, nothing allocates device memory, there is no hidden global state;
+ *   - return value: 0 on success, a negative HIREST_E_* for argument errors, or a
+ *     positive hipError_t from the launch;
+ *   - bf16 tensors are raw uint16 bit patterns (round-to-nearest-even from fp32);
+ *   - matrices are row-major; "ld*" are leading dimensions in ELEMENTS.
+ */
+#ifndef HIREST_HIP_H
+#define HIREST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIREST_ABI_VERSION 1
+
+#define HIREST_E_BADARG   (-1)
+#define HIREST_E_SHAPE    (-2)   /* unsupported shape (see each function) */
+#define HIREST_E_WORKSPACE (-3)  /* workspace too small */
+
+typedef uint16_t hirest_bf16;
+
+int hirest_abi_version(void);
+/* human-readable build string: arch, compiler, kernel variants */
+const char* hirest_build_info(void);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM with fused epilogues:  acc[m][n] = sum_k A[m][k] * W[n][k]   (bf16 in, fp32 accumulate
+ * on MFMA).  W is a torch nn.Linear weight as stored ([out_features, in_features]).
+ * Replaces F.linear / nn.Linear / `x @ proj` on the path (vit_model.py:56-62,124-127,148;
+ * eva_model.py:137-142,249; nn.MultiheadAttention in/out projections).
+ * Requirements: K % 64 == 0, N % 4 == 0, lda/ldw multiples of 8, pointers 16-B aligned.
+ * ------------------------------------------------------------------------------------ */
+enum hirest_epilogue {
+    HIREST_EPI_BIAS_BF16 = 0,        /* out bf16 [M,ldo]  = acc + bias                        */
+    HIREST_EPI_BIAS_GELU_BF16 = 1,   /* out bf16          = gelu_erf(acc + bias)  (nn.GELU()) */
+    HIREST_EPI_BIAS_QGELU_BF16 = 2,  /* out bf16          = quick_gelu(acc + bias) (model.py:175) */
+    HIREST_EPI_BIAS_RESID_F32 = 3,   /* out f32 (in/out)  = out + acc + bias     (x += f(x)) */
+    HIREST_EPI_BIAS_F32 = 4,         /* out f32           = acc + bias                        */
+    HIREST_EPI_PATCH_POS_F32 = 5     /* patch-embed: row m=b*P+p -> out row b*(P+1)+1+p;
+                                        out f32 = acc + bias + pos[(1+p)*ldo' ...]; see below */
+};
+
+typedef struct hirest_gemm_args {
+    const hirest_bf16* A;  int64_t lda;   /* [M,K] */
+    const hirest_bf16* W;  int64_t ldw;   /* [N,K] */
+    const float* bias;                    /* [N] or NULL */
+    void* out;             int64_t ldo;   /* [M,N] bf16 or f32 by epilogue */
+    int32_t M, N, K;
+    int32_t epilogue;                     /* enum hirest_epilogue */
+    /* HIREST_EPI_PATCH_POS_F32 only: */
+    const float* pos;                     /* [(P+1), N] position embedding (row 0 = cls slot) */
+    int32_t patches_per_frame;            /* P (256 for 224^2 / 14) */
+} hirest_gemm_args;
+
+int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (biased variance, fp32 statistics), fp32 in -> bf16 or f32 out.
+ * Replaces nn.LayerNorm / LayerNorm subclasses (vit_model.py:159,165,285; eva_model.py:19-25;
+ * model.py:166-172).  Row i of the input is x + row_index[i]*ldx (row_index NULL -> i).
+ * D % 4 == 0, D <= 8192.
+ * ------------------------------------------------------------------------------------ */
+int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_index,
+                     const float* gamma, const float* beta, float eps,
+                     void* out, int64_t ldo, int32_t out_is_f32,
+                     int32_t rows, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-head self-attention core on a packed QKV activation (the output of the QKV GEMM):
+ *   qkv bf16 [B*N, 3*H*dh] with columns ordered (which in {q,k,v}, head, dh)
+ *   out bf16 [B*N, H*dh]   = softmax(scale * q k^T [+ causal mask]) v,  heads concatenated
+ * Replaces vit_model.py:127-147 (no mask) and nn.MultiheadAttention's core with the additive
+ * -inf causal mask of eva_model.py:224-230.  fp32 softmax, bf16 P.V on MFMA.
+ * Supported: N <= 272, dh in {64, 88} (dh 88 is zero-padded to 96 on chip).
+ * ------------------------------------------------------------------------------------ */
+int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out,
+                          int32_t B, int32_t N, int32_t H, int32_t dh,
+                          float scale, int32_t causal, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Patch extraction (im2col for Conv2d with kernel == stride == P, vit_model.py:198,205):
+ * frames [B,3,S,S] -> patches bf16 [B*(S/P)^2, Kpad], column order (c, ph, pw) = the conv
+ * weight's flatten order; columns >= 3*P*P are zero.  in_dtype: 0 = f32 NCHW (already
+ * normalised), 1 = bf16 NCHW, 2 = uint8 NHWC raw RGB with fused (x/255-mean)/std
+ * (eva_clip.py:16-17,125-153 ToTensor+Normalize).
+ * ------------------------------------------------------------------------------------ */
+int hirest_patchify(const void* frames, int32_t in_dtype, int32_t B, int32_t S, int32_t P,
+                    const float* mean3, const float* std3,
+                    hirest_bf16* patches, int32_t Kpad, void* stream);
+
+/* x[b*(P+1)] = cls + pos[0]  for every frame (vit_model.py:330-333, the CLS row). */
+int hirest_write_cls_rows(float* x, int64_t ldx, const float* cls, const float* pos0,
+                          int32_t B, int32_t tokens_per_frame, int32_t D, void* stream);
+
+/* Text prologue: x[b,t,:] = tok_emb[tok[b,t]] + pos[t]  (eva_model.py:233-235); also writes
+ * eot_row[b] = b*L + argmax_t tok[b,t] (first maximum) for the EOT gather (eva_model.py:243). */
+int hirest_embed_tokens(const int64_t* tokens, const float* tok_emb, const float* pos,
+                        float* x, int32_t* eot_row, int32_t B, int32_t L, int32_t D,
+                        int32_t vocab, void* stream);
+
+/* fp32 -> bf16 conversion of a dense buffer (weights upload, feature casts). n % 4 == 0. */
+int hirest_f32_to_bf16(const float* in, hirest_bf16* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pooling + scoring (inference_video_retrieval.py:283-285, 323-334; evaluate.py:58-60)
+ * ------------------------------------------------------------------------------------ */
+/* [V,F,E] f32 -> [V,E] f32: (optional per-frame L2) -> mean over F -> L2.  F==1 is plain L2. */
+int hirest_pool_l2norm(const float* frame_embeds, float* out, int32_t V, int32_t F, int32_t E,
+                       int32_t normalize_frames_first, void* stream);
+
+/* scores[q][v] = <T[q], Vn[v]> in fp32 FMA arithmetic. */
+int hirest_similarity_f32(const float* text_n, const float* video_n, float* scores,
+                          int32_t Q, int32_t V, int32_t E, void* stream);
+
+/* Per-query top-k by (score desc, tie_rank desc); tie_rank NULL -> ties by higher index first
+ * = the reference's sorted(zip(scores, names))[::-1] when tie_rank[v] = rank of names[v]. */
+int hirest_topk_f32(const float* scores, const int32_t* tie_rank, int32_t Q, int32_t V, int32_t k,
+                    int32_t* out_index, float* out_score, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole-tower runners: one call = one forward of a transformer tower over a batch, all
+ * kernels enqueued on `stream`.  Weights are referenced, never copied.
+ * ------------------------------------------------------------------------------------ */
+typedef struct hirest_block_weights {      /* pre-LN transformer block */
+    const float* ln1_g; const float* ln1_b;
+    const hirest_bf16* qkv_w; const float* qkv_b;     /* [3D,D], [3D] (EVA: q_bias,0,v_bias) */
+    const hirest_bf16* proj_w; const float* proj_b;   /* [D,D] */
+    const float* ln2_g; const float* ln2_b;
+    const hirest_bf16* fc1_w; const float* fc1_b;     /* [Dm,D] */
+    const hirest_bf16* fc2_w; const float* fc2_b;     /* [D,Dm] */
+} hirest_block_weights;
+
+typedef struct hirest_vision_tower {       /* EVA ViT (vit_model.py:248-351) */
+    int32_t image_size, patch, width, heads, head_dim, mlp_dim, layers, embed_dim;
+    int32_t kpad;                          /* padded 3*P*P (multiple of 64) */
+    int32_t act;                           /* 0 gelu_erf, 1 quick_gelu */
+    float ln_eps;
+    const hirest_bf16* patch_w;            /* [width, kpad] */
+    const float* patch_b;                  /* [width] */
+    const float* cls;                      /* [width] */
+    const float* pos;                      /* [tokens, width] */
+    const hirest_block_weights* blocks;    /* HOST array [layers] */
+    const float* norm_g; const float* norm_b;
+    const hirest_bf16* head_w;             /* [embed_dim, width] */
+    const float* head_b;                   /* [embed_dim] or NULL */
+    const float* image_mean; const float* image_std; /* device [3], used when in_dtype==2 */
+} hirest_vision_tower;
+
+size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B);
+/* frames: see hirest_patchify in_dtype; out: f32 [B, embed_dim] (not normalised), like
+ * EVA_CLIP.encode_image (eva_model.py:317). */
+int hirest_vision_forward(const hirest_vision_tower* t, const void* frames, int32_t in_dtype,
+                          int32_t B, float* out, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+typedef struct hirest_text_tower {         /* CLIP text transformer (eva_model.py:177-250) */
+    int32_t context, vocab, width, heads, layers, embed_dim;
+    int32_t act;
+    float ln_eps;
+    const float* tok_emb;                  /* [vocab, width] f32 */
+    const float* pos;                      /* [context, width] */
+    const hirest_block_weights* blocks;    /* HOST array [layers] */
+    const float* lnf_g; const float* lnf_b;
+    const hirest_bf16* proj_w;             /* text_projection transposed: [embed_dim, width] */
+} hirest_text_tower;
+
+size_t hirest_text_workspace_bytes(const hirest_text_tower* t, int32_t B);
+int hirest_text_forward(const hirest_text_tower* t, const int64_t* tokens, int32_t B, float* out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optional per-launch timing (bench.py's live roofline measurement).  When enabled, every
+ * GEMM / attention / LayerNorm launch is bracketed by hipEventRecord on ITS launch stream;
+ * hirest_profile_collect synchronises those events and returns one record per launch.
+ * Off by default; costs two event records per launch when on.  Not thread-safe.
+ * ------------------------------------------------------------------------------------ */
+enum hirest_prof_kind { HIREST_PROF_GEMM = 0, HIREST_PROF_ATTENTION = 1, HIREST_PROF_LAYERNORM = 2 };
+typedef struct hirest_prof_record {
+    int32_t kind;        /* enum hirest_prof_kind */
+    int32_t tag;         /* GEMM: epilogue id; attention: causal flag; LN: 0 */
+    int64_t d0, d1, d2;  /* GEMM: M,N,K; attention: B*H, N, dh; LN: rows, D, 0 */
+    float ms;            /* elapsed device time of this launch */
+} hirest_prof_record;
+int hirest_profile_enable(int32_t on);                 /* also discards pending records */
+int hirest_profile_collect(hirest_prof_record* out, int32_t max_records); /* returns count (<0 on error) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIREST_HIP_H */

@@ -1,0 +1,107 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol the header declares
+(no compute calls without a GPU), and the host layer mirrors the reference interface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hirest_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    from hirest_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "hirest_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(hirest_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/hirest_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.hirest_abi_version() == 1
+    assert b"gfx950" in lib.hirest_build_info()
+
+
+def test_argument_errors_without_gpu(lib):
+    from hirest_amd import _lib
+    a = _lib.GemmArgs()  # all-NULL
+    assert lib.hirest_gemm_bf16(ctypes.byref(a), None) == -1
+    assert lib.hirest_layernorm(None, 0, None, None, None, 0.0, None, 0, 0, 0, 0, None) == -1
+    assert lib.hirest_attention_bf16(None, None, 1, 1, 1, 64, 1.0, 0, None) == -1
+    assert lib.hirest_vision_workspace_bytes(None, 4) == 0
+
+
+def test_workspace_size_formula(lib):
+    from hirest_amd import _lib
+    t = _lib.VisionTower()
+    t.image_size, t.patch, t.width, t.heads, t.head_dim, t.mlp_dim, t.layers, t.embed_dim, t.kpad = 224, 14, 1408, 16, 88, 6144, 40, 1024, 640
+    M = 256 * 257
+    al = lambda v: (v + 255) // 256 * 256
+    assert lib.hirest_vision_workspace_bytes(ctypes.byref(t), 256) == al(M * 1408 * 4) + al(M * 1408 * 2) + al(M * 6144 * 2) + al(256 * 4)
+
+
+def test_model_schema_and_errors():
+    import hirest_amd
+    from hirest_amd import synth
+    with pytest.raises(RuntimeError):
+        hirest_amd.build_eva_model_and_transforms("no-such-model", pretrained="synth:0")
+    with pytest.raises(Exception):
+        hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained="/nonexistent.pt")
+    model, pre = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained="synth:11")
+    assert model.training  # the reference returns a train-mode module (eva_clip.py:155-172)
+    sd = synth.eva_clip_state_dict(synth.EVA_CLIP_TINY, 11)
+    got = model.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert model.visual.image_size == 224 and model.visual.image_mean == hirest_amd.eva_clip.OPENAI_DATASET_MEAN
+    for p in model.parameters():
+        p.requires_grad = False           # modeling.py:126-129 freeze loop works
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for v in sd.values())
+    with pytest.raises(AssertionError):   # vit_model.py:203
+        model.encode_image(torch.zeros(1, 3, 200, 224))
+    with pytest.raises(RuntimeError):     # no silent CPU fallback
+        model.encode_image(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(RuntimeError):
+        model.encode_text(torch.zeros(1, 77, dtype=torch.long))
+    # checkpoint round trip incl. the 'module.' prefix + wrapper keys (eva_clip.py:68-79)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ck.pt")
+        torch.save({"model": {"module." + k: v for k, v in sd.items()}}, path)
+        m2, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=path)
+        assert all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
+
+
+def test_eva_g14_param_count():
+    """1 012 588 928 vision + 123 846 913 text params, without allocating them."""
+    from hirest_amd import synth
+    nv = sum(int(np.prod(s)) for s in synth.eva_vision_shapes(synth.EVA_CLIP_G_14).values())
+    nt = sum(int(np.prod(s)) if len(s) else 1 for s in synth.eva_text_shapes(synth.EVA_CLIP_G_14).values())
+    assert nv == 1012588928 and nt == 123846913
+
+
+def test_image_transform_geometry():
+    from PIL import Image
+    import hirest_amd
+    tf = hirest_amd.image_transform(224)
+    rng = np.random.RandomState(0)
+    for (h, w) in [(300, 400), (400, 300), (224, 224), (225, 1000)]:
+        img = Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8))
+        t = tf(img)
+        assert t.shape == (3, 224, 224) and t.dtype == torch.float32
+    # a 224x224 image is only converted + normalised: exact formula check
+    arr = rng.randint(0, 255, (224, 224, 3), dtype=np.uint8)
+    t = tf(Image.fromarray(arr))
+    mean = np.array(hirest_amd.eva_clip.OPENAI_DATASET_MEAN, dtype=np.float32).reshape(3, 1, 1)
+    std = np.array(hirest_amd.eva_clip.OPENAI_DATASET_STD, dtype=np.float32).reshape(3, 1, 1)
+    want = (arr.astype(np.float32).transpose(2, 0, 1) / 255.0 - mean) / std
+    assert np.allclose(t.numpy(), want, atol=1e-6)

@@ -40,8 +40,8 @@ def test_eva_tiny_matches_reference(golden_dir):
     assert rel_err(x[:, rows].numpy(), g["vis_embed"]) < RTOL
     p = "visual.blocks.0."
     h = O.layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
-    assert rel_err(O.eva_attention(sd, p, h, 2)[:, rows].numpy(), g["vis_attn0"]) < RTOL
-    x1 = O.eva_block(sd, 0, x, 2)
+    assert rel_err(O.eva_attention(sd, p, h, 8)[:, rows].numpy(), g["vis_attn0"]) < RTOL
+    x1 = O.eva_block(sd, 0, x, 8)
     assert rel_err(x1[:, rows].numpy(), g["vis_block0"]) < RTOL
     assert rel_err(O.eva_encode_image(sd, img, cfg).numpy(), g["image_embed"]) < RTOL
     assert rel_err(O.eva_encode_text(sd, tok, cfg).numpy(), g["text_embed"]) < RTOL
