@@ -2,7 +2,7 @@
 // Replaces q@k^T -> softmax -> @v (vit_model.py:131-147; nn.MultiheadAttention core with the
 // additive causal mask of eva_model.py:224-230).
 //
-// One workgroup (4 waves) per (frame, head).  K [N x dh] and V^T [dh x N] of that head live in LDS
+// One workgroup (8 waves) per (frame, head).  K [N x dh] and V^T [dh x N] of that head live in LDS
 // for the whole block; each wave walks 16-query tiles:
 //   S^T = K . Q^T      v_mfma_f32_16x16x32_bf16(a = K rows from LDS, b = Q rows straight from HBM)
 //   softmax over keys  fully in registers: the C layout of S^T puts query (lane&15) in the lane and
@@ -27,7 +27,7 @@ struct AttnCfg {
 };
 
 template <int DH, int DP, int NT>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        int N, int H, float scale_log2e, int causal) {
     using C = AttnCfg<DH, DP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 
     // ---- stage K (row-major, zero padded) ----
     constexpr int KCH = DP / 8;
-    for (int idx = tid; idx < C::NPAD * KCH; idx += 256) {
+    for (int idx = tid; idx < C::NPAD * KCH; idx += 512) {
         const int key = idx / KCH, ch = idx - key * KCH;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (key < N && ch * 8 < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + D + ch * 8);
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     }
     // ---- stage V transposed: Vt[d][key] ----
     constexpr int VCH = DH / 8;
-    for (int idx = tid; idx < C::KP * VCH; idx += 256) {
+    for (int idx = tid; idx < C::KP * VCH; idx += 512) {
         const int ch = idx / C::KP, key = idx - ch * C::KP;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (key < N) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + 2 * D + ch * 8);
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 
     const int g = lane >> 4, c16 = lane & 15;
     const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += 8) {
         const int q = qt * 16 + c16;
         const bool qvalid = q < N;
         bf16x8 qf[DP / 32];
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
             }
             st[t] = acc;
+            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound how many K fragments are hoisted (VGPR budget: 2 waves/SIMD)
         }
         // ---- mask + softmax (fp32) ----
         const int klimit = causal ? (q < N - 1 ? q : N - 1) : N - 1;   // last visible key
@@ -154,7 +155,7 @@ int launch(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), C::LDS_BYTES, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), C::LDS_BYTES, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
     return hirest_launch_status();
 }
 

@@ -166,8 +166,192 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) {
     }
 }
 
+
+// =================================================================================================
+// Kernel "t256": 256x256 block tile, 8 waves (2 along M x 4 along N, 128x64 each = 4x2 MFMA tiles),
+// K walked in 32-deep slabs through a 4-slot LDS ring (4 x 32 KiB).  Two wave groups (the two M
+// halves) run the same program ONE BARRIER APART: in every barrier interval one group issues its
+// 8 MFMAs (256 matrix-pipe cycles) at priority 1 while the other group issues its ds_read_b128
+// fragment reads and 2 LDS-DMA pieces of the slab two ahead.  Loads are never drained: one counted
+// s_waitcnt vmcnt(4) per slab retires the slab needed next while the newest slab stays in flight.
+//
+// Slab image: [256 A rows + 256 W rows][4 x 16-B chunks], chunk' = chunk ^ ((row>>2)&3) (applied on
+// the LDS-DMA source address and on the fragment read) -> conflict-free ds_read_b128.
+//
+// Hazards (G = global barrier index; group 0 phase j: mid barrier 2j, end 2j+1; group 1: 2j+1, 2j+2):
+//  RAW  slab s+1 is first read by group 0 after G = 4s+3; every wave waits vmcnt(4) for its slab-(s+1)
+//       pieces before its phase-b mid barrier of slab s (G = 4s+2 / 4s+3).
+//  WAR  slot (s+2)&3 last held slab s-2, whose last reads complete right after G = 4s-5; the first
+//       DMA into it is issued after G = 4s-1.
+// =================================================================================================
+constexpr int T_BM = 256, T_BN = 256, T_BK = 32, T_NST = 4;
+constexpr int T_SLAB = (T_BM + T_BN) * T_BK * 2;   // 32 KiB
+constexpr int T_WOFF = T_BM * T_BK * 2;            // W rows start here inside a slab
+
+#define HX_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define HX_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int p_lo = xcd * p.ppx;
+    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    if (np <= 0 || j >= np * p.nbn) return;
+    const int grp = j / (GROUP_M * p.nbn);
+    const int r = j - grp * GROUP_M * p.nbn;
+    int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
+    const int nt_i = r / gcount, mt_i = p_lo + grp * GROUP_M + (r - nt_i * gcount);
+    const int M0 = mt_i * T_BM, N0 = nt_i * T_BN;
+
+    // LDS-DMA pieces: 1 KiB = 16 rows x 64 B; this wave owns A pieces 2w,2w+1 and W pieces 2w,2w+1
+    const bf16_t* a_src[2];
+    const bf16_t* w_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1;
+        int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1;
+        a_src[q] = p.A + (int64_t)gm * p.lda + chunk * 8;
+        w_src[q] = p.W + (int64_t)gn * p.ldw + chunk * 8;
+    }
+    const int piece_off = wave * 2048;
+    auto stage_a = [&](int s) {
+        char* buf = smem + (s & (T_NST - 1)) * T_SLAB + piece_off;
+        glds16(a_src[0] + (int64_t)s * T_BK, buf);
+        glds16(a_src[1] + (int64_t)s * T_BK, buf + 1024);
+    };
+    auto stage_w = [&](int s) {
+        char* buf = smem + (s & (T_NST - 1)) * T_SLAB + T_WOFF + piece_off;
+        glds16(w_src[0] + (int64_t)s * T_BK, buf);
+        glds16(w_src[1] + (int64_t)s * T_BK, buf + 1024);
+    };
+
+    // fragment read offsets (bytes inside a slab)
+    const int frow = lane & 31, fsw = (frow >> 2) & 3, khalf = lane >> 5;
+    const int koff0 = ((0 + khalf) ^ fsw) << 4, koff1 = ((2 + khalf) ^ fsw) << 4;
+    const int a_base = (wr * 128 + frow) * (T_BK * 2);
+    const int w_base = T_WOFF + (wc * 64 + frow) * (T_BK * 2);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    const int ns = p.K / T_BK;
+    // ---- prologue: slabs 0 and 1 in flight, slab 0 landed everywhere
+    stage_a(0); stage_w(0);
+    if (ns > 1) { stage_a(1); stage_w(1); HX_WAIT_VM(4); } else { HX_WAIT_VM(0); }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+    for (int s = 0; s < ns; ++s) {
+        const char* buf = smem + (s & (T_NST - 1)) * T_SLAB;
+        const bool pre = s + 2 < ns;
+        // ================= phase a: rows [0,64) of this wave's 128 =================
+        bf16x8 wf[2][2], af[2][2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            wf[n][0] = *reinterpret_cast<const bf16x8*>(buf + w_base + n * 32 * 64 + koff0);
+            wf[n][1] = *reinterpret_cast<const bf16x8*>(buf + w_base + n * 32 * 64 + koff1);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            af[m][0] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 64 + koff0);
+            af[m][1] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 64 + koff1);
+        }
+        if (pre) stage_a(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        HX_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[m][ks], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase b: rows [64,128) =================
+        bf16x8 ag[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ag[m][0] = *reinterpret_cast<const bf16x8*>(buf + a_base + (2 + m) * 32 * 64 + koff0);
+            ag[m][1] = *reinterpret_cast<const bf16x8*>(buf + a_base + (2 + m) * 32 * 64 + koff1);
+        }
+        if (pre) { stage_w(s + 2); HX_WAIT_VM(4); } else { HX_WAIT_VM(0); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        HX_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[2 + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], ag[m][ks], acc[2 + m][n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+
+    // ---- epilogue
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = M0 + wr * 128 + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = N0 + wc * 64 + jn * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= p.N) continue;
+                f32x4 v = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                epilogue_store<EPI>(p, m, n, v);
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch256(GemmP p, hipStream_t s) {
+    static bool configured = false;
+    auto kern = gemm_t256<EPI>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           T_NST * T_SLAB);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
+    p.ppx = (p.nbm + 7) / 8;
+    const int grid = 8 * p.ppx * p.nbn;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T_NST * T_SLAB, s, p);
+    return hirest_launch_status();
+}
+
+int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 (tests / A-B benchmarking)
+
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
+    const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
+    if (g_force_kernel == 2 || (g_force_kernel == 0 && big)) return launch256<EPI>(p, s);
     const int grid = 8 * p.ppx * p.nbn;
     hipLaunchKernelGGL(gemm_t128<EPI>, dim3(grid), dim3(256), 2 * STAGE_BYTES, s, p);
     return hirest_launch_status();
@@ -175,10 +359,16 @@ int launch(const GemmP& p, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int hirest_gemm_select_kernel(int32_t which) {
+    if (which < 0 || which > 2) return HIREST_E_BADARG;
+    g_force_kernel = which;
+    return 0;
+}
+
 extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->out) return HIREST_E_BADARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return HIREST_E_BADARG;
-    if (a->K % BK != 0 || a->N % 4 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return HIREST_E_SHAPE;
+    if (a->K % BK != 0 || a->K % T_BK != 0 || a->N % 4 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return HIREST_E_SHAPE;
     GemmP p;
     p.A = reinterpret_cast<const bf16_t*>(a->A); p.lda = a->lda;
     p.W = reinterpret_cast<const bf16_t*>(a->W); p.ldw = a->ldw;

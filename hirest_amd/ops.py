@@ -53,6 +53,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def gemm_select_kernel(which: int):
+    """0 = automatic, 1 = force the 128x128 kernel, 2 = force the 256x256 ping-pong kernel."""
+    _lib.check(_lib.load().hirest_gemm_select_kernel(int(which)), "hirest_gemm_select_kernel")
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor,
               row_index: Optional[torch.Tensor] = None, ldx: Optional[int] = None, rows: Optional[int] = None):
     lib = _lib.load()

@@ -70,6 +70,9 @@ typedef struct hirest_gemm_args {
 } hirest_gemm_args;
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
+/* Kernel selection for tests / A-B timing: 0 = automatic (default), 1 = force the 128x128 kernel,
+ * 2 = force the 256x256 ping-pong kernel.  Results are identical up to fp32 summation order. */
+int hirest_gemm_select_kernel(int32_t which);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the last dim (biased variance, fp32 statistics), fp32 in -> bf16 or f32 out.

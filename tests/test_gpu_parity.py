@@ -53,8 +53,16 @@ def cos_rows(a, b):
 # ----------------------------------------------------------------------------------------
 # kernels
 # ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 132, 128), (257, 1408, 1408), (1000, 4224, 1408), (77, 768, 3072)])
-def test_gemm_epilogues(dev, ops, M, N, K):
+@pytest.fixture(params=[1, 2], ids=["t128", "t256"])
+def gemm_kernel(request, ops):
+    ops.gemm_select_kernel(request.param)
+    yield request.param
+    ops.gemm_select_kernel(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 132, 128), (257, 1408, 1408), (1000, 4224, 1408), (77, 768, 3072),
+                                   (513, 260, 64), (2056, 1408, 6144)])
+def test_gemm_epilogues(dev, ops, gemm_kernel, M, N, K):
     from hirest_amd import _lib
     a = synth.tensor("g.a", (M, K), 1.0, 7)
     w = synth.tensor("g.w", (N, K), 0.05, 7)
@@ -81,7 +89,7 @@ def test_gemm_epilogues(dev, ops, M, N, K):
     assert (x.cpu().double() - (resid.double() + ref)).abs().max().item() <= scale * 1e-5
 
 
-def test_gemm_detects_transpose(dev, ops):
+def test_gemm_detects_transpose(dev, ops, gemm_kernel):
     """A = I against an asymmetric W: a swapped C layout cannot pass."""
     from hirest_amd import _lib
     n = 256

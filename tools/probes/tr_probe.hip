@@ -12,10 +12,8 @@ __global__ void probe(uint16_t* out, int mode) {
     unsigned addr;
     if (mode == 0) addr = (unsigned)(uintptr_t)lds + 8 * l;
     else { int g = l >> 4, i = l & 15; addr = (unsigned)(uintptr_t)lds + 2 * (((g * 4 + (i >> 2)) * 64) + (i & 3) * 4); }
-    unsigned lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(*(uint64_t*)&lo) : "v"(0), "v"(addr) : "memory");
-    (void)hi;
-    uint64_t v = *(uint64_t*)&lo;
+    uint64_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)(v >> (16 * j));
 }
 int main() {
