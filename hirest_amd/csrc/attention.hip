@@ -159,7 +159,196 @@ int launch(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int
     return hirest_launch_status();
 }
 
+
+// =================================================================================================
+// v2: K and V both staged ROW-MAJOR by LDS-DMA (global_load_lds_dwordx4; no VGPR round trip, no
+// scattered 2-byte transposing stores), V consumed through ds_read_b64_tr_b16 (the hardware 4x16
+// transpose read): each 16-lane group reads one [4 keys][16 head-dims] block and lane i gets column i.
+// LDS image: [NPAD K rows][KP V rows], DP bf16 per row (192 B for head dim 88: chunk 11 of a row is
+// a duplicate of chunk 10 — it only ever meets the zeroed tail of the Q fragment / feeds discarded
+// output rows).  Rows past N are clamped duplicates of row N-1 (their scores are masked to -inf).
+// =================================================================================================
+template <int DH, int DP, int NT>
+struct AttnCfg2 {
+    static constexpr int NPAD = 16 * NT;
+    static constexpr int KS = (NT + 1) / 2;
+    static constexpr int KP = 32 * KS;
+    static constexpr int RS = DP * 2;              // row stride, bytes
+    static constexpr int CPR = DP / 8;             // 16-B chunks per row
+    static constexpr int NK_INSTR = NPAD * CPR / 64;
+    static constexpr int NV_INSTR = KP * CPR / 64;
+    static constexpr int LDS_BYTES = (NPAD + KP) * RS;
+};
+
+__device__ __forceinline__ void wait_vm_le(int n) {   // s_waitcnt vmcnt(n) for a wave-uniform runtime n in [0,8]
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+template <int DH, int DP, int NT>
+__global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          int N, int H, float scale_log2e, int causal) {
+    using C = AttnCfg2<DH, DP, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + C::NPAD * C::RS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * DH;
+
+    // ---- LDS-DMA: K pieces first, then V pieces (1 KiB = 64 consecutive 16-B chunks per wave-instruction)
+    int nv_mine = 0;
+    for (int i = wave; i < C::NK_INSTR; i += 8) {
+        const int ci = i * 64 + lane;
+        int row = ci / C::CPR, c = ci - row * C::CPR;
+        row = row < N ? row : N - 1;
+        c = c * 8 < DH ? c : DH / 8 - 1;
+        glds16(base + (int64_t)row * ld + D + c * 8, Ks + i * 1024);
+    }
+    for (int i = wave; i < C::NV_INSTR; i += 8) {
+        const int ci = i * 64 + lane;
+        int row = ci / C::CPR, c = ci - row * C::CPR;
+        row = row < N ? row : N - 1;
+        c = c * 8 < DH ? c : DH / 8 - 1;
+        glds16(base + (int64_t)row * ld + 2 * D + c * 8, Vs + i * 1024);
+        ++nv_mine;
+    }
+    wait_vm_le(nv_mine);            // this wave's K pieces have landed (V may still be in flight)
+    __builtin_amdgcn_s_barrier();   // ... and everybody else's
+
+    const int g = lane >> 4, c16 = lane & 15;
+    const int nqt = (N + 15) >> 4;
+    bool v_ready = false;
+    for (int qt = wave; qt < nqt; qt += 8) {
+        const int q = qt * 16 + c16;
+        const bool qvalid = q < N;
+        bf16x8 qf[DP / 32];
+#pragma unroll
+        for (int kk = 0; kk < DP / 32; ++kk) {
+            const int d = (kk * 4 + g) * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qvalid && d < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * ld + d);
+            qf[kk] = v;
+        }
+        f32x4 st[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < DP / 32; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::RS + (kk * 4 + g) * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+            }
+            st[t] = acc;
+            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        const int klimit = causal ? (q < N - 1 ? q : N - 1) : N - 1;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = t * 16 + 4 * g + i;
+                const float sv = key <= klimit ? st[t][i] : -3.0e38f;
+                st[t][i] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pz = exp2f((st[t][i] - mx) * scale_log2e);
+                st[t][i] = pz;
+                sum += pz;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        bf16x8 pf[C::KS];
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf[s][i] = (bf16_t)st[2 * s][i];
+                if (2 * s + 1 < NT) pf[s][4 + i] = (bf16_t)st[2 * s + 1][i];
+                else pf[s][4 + i] = (bf16_t)0.f;
+            }
+        }
+        if (!v_ready) {               // first q-tile of this wave: V must have landed for everybody
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            v_ready = true;
+        }
+        // ---- O^T = V^T . P^T, V^T fragments by transpose-read: block rows 4g..4g+3 (+16), lane supplies
+        // the address of its 4 contiguous values = row (c16>>2), cols 4*(c16&3).. of the [4][16] block
+        const char* vlane = Vs + (4 * g + (c16 >> 2)) * C::RS + (c16 & 3) * 8;
+#pragma unroll 1
+        for (int dt = 0; dt < DP / 16; ++dt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const char* vrow = vlane + dt * 32;
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(vrow + s * 32 * C::RS));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(vrow + (s * 32 + 16) * C::RS));
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s], acc, 0, 0, 0);
+            }
+            const int d = dt * 16 + 4 * g;
+            if (qvalid && d < DH) {
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(acc[i] * inv);
+                *reinterpret_cast<bf16x4*>(out + ((int64_t)b * N + q) * D + h * DH + d) = o;
+            }
+        }
+    }
+    if (!v_ready) {   // waves without a q-tile still owe the V barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+int g_attn_variant = 2;   // 1 = v1 (register-staged, transposing stores), 2 = v2 (LDS-DMA + transpose reads)
+
+template <int DH, int DP, int NT>
+int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
+    using C = AttnCfg2<DH, DP, NT>;
+    static bool configured = false;
+    auto kern = attention_kernel_v2<DH, DP, NT>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), C::LDS_BYTES, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
+    return hirest_launch_status();
+}
+
 }  // namespace
+
+extern "C" int hirest_attention_select_kernel(int32_t which) {
+    if (which < 1 || which > 2) return HIREST_E_BADARG;
+    g_attn_variant = which;
+    return 0;
+}
 
 extern "C" int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out, int32_t B, int32_t N, int32_t H,
                                      int32_t dh, float scale, int32_t causal, void* stream) {
@@ -168,6 +357,16 @@ extern "C" int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out, i
     const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
     bf16_t* o = reinterpret_cast<bf16_t*>(out);
     HirestProfScope prof(HIREST_PROF_ATTENTION, causal, (int64_t)B * H, N, dh, s);
+    if (g_attn_variant == 2) {
+        if (dh == 88) {
+            if (N <= 80) return launch2<88, 96, 5>(q, o, B, N, H, scale, causal, s);
+            if (N <= 272) return launch2<88, 96, 17>(q, o, B, N, H, scale, causal, s);
+        } else if (dh == 64) {
+            if (N <= 80) return launch2<64, 64, 5>(q, o, B, N, H, scale, causal, s);
+            if (N <= 272) return launch2<64, 64, 17>(q, o, B, N, H, scale, causal, s);
+        }
+        return HIREST_E_SHAPE;
+    }
     if (dh == 88) {
         if (N <= 80) return launch<88, 96, 5>(q, o, B, N, H, scale, causal, s);
         if (N <= 272) return launch<88, 96, 17>(q, o, B, N, H, scale, causal, s);

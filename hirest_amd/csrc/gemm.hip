@@ -169,11 +169,11 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) {
 
 // =================================================================================================
 // Kernel "t256": 256x256 block tile, 8 waves (2 along M x 4 along N, 128x64 each = 4x2 MFMA tiles),
-// K walked in 32-deep slabs through a 4-slot LDS ring (4 x 32 KiB).  Two wave groups (the two M
+// K walked in 32-deep slabs through an NST-slot LDS ring (5 x 32 KiB = all 160 KiB of the CU by default).  Two wave groups (the two M
 // halves) run the same program ONE BARRIER APART: in every barrier interval one group issues its
 // 8 MFMAs (256 matrix-pipe cycles) at priority 1 while the other group issues its ds_read_b128
-// fragment reads and 2 LDS-DMA pieces of the slab two ahead.  Loads are never drained: one counted
-// s_waitcnt vmcnt(4) per slab retires the slab needed next while the newest slab stays in flight.
+// fragment reads and 2 LDS-DMA pieces of the slab PD = NST-2 ahead.  Loads are never drained: one counted
+// s_waitcnt vmcnt(4*(PD-1)) per slab retires the slab needed next while the newer ones stay in flight.
 //
 // Slab image: [256 A rows + 256 W rows][4 x 16-B chunks], chunk' = chunk ^ ((row>>2)&3) (applied on
 // the LDS-DMA source address and on the fragment read) -> conflict-free ds_read_b128.
@@ -184,15 +184,23 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) {
 //  WAR  slot (s+2)&3 last held slab s-2, whose last reads complete right after G = 4s-5; the first
 //       DMA into it is issued after G = 4s-1.
 // =================================================================================================
-constexpr int T_BM = 256, T_BN = 256, T_BK = 32, T_NST = 4;
+constexpr int T_BM = 256, T_BN = 256, T_BK = 32;
 constexpr int T_SLAB = (T_BM + T_BN) * T_BK * 2;   // 32 KiB
 constexpr int T_WOFF = T_BM * T_BK * 2;            // W rows start here inside a slab
 
 #define HX_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// wait until at most `slabs` whole slabs (4 LDS-DMA pieces each, per wave) are still in flight
+__device__ __forceinline__ void wait_slabs_in_flight(int slabs) {
+    if (slabs <= 0) HX_WAIT_VM(0);
+    else if (slabs == 1) HX_WAIT_VM(4);
+    else if (slabs == 2) HX_WAIT_VM(8);
+    else HX_WAIT_VM(12);
+}
 #define HX_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int EPI>
+template <int EPI, int T_NST>
 __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
+    constexpr int PD = T_NST - 2;   // prefetch distance in slabs (slot being filled is never one being read)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -222,13 +230,13 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
         w_src[q] = p.W + (int64_t)gn * p.ldw + chunk * 8;
     }
     const int piece_off = wave * 2048;
-    auto stage_a = [&](int s) {
-        char* buf = smem + (s & (T_NST - 1)) * T_SLAB + piece_off;
+    auto stage_a = [&](int s, int slot) {
+        char* buf = smem + slot * T_SLAB + piece_off;
         glds16(a_src[0] + (int64_t)s * T_BK, buf);
         glds16(a_src[1] + (int64_t)s * T_BK, buf + 1024);
     };
-    auto stage_w = [&](int s) {
-        char* buf = smem + (s & (T_NST - 1)) * T_SLAB + T_WOFF + piece_off;
+    auto stage_w = [&](int s, int slot) {
+        char* buf = smem + slot * T_SLAB + T_WOFF + piece_off;
         glds16(w_src[0] + (int64_t)s * T_BK, buf);
         glds16(w_src[1] + (int64_t)s * T_BK, buf + 1024);
     };
@@ -248,15 +256,17 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
     const int ns = p.K / T_BK;
-    // ---- prologue: slabs 0 and 1 in flight, slab 0 landed everywhere
-    stage_a(0); stage_w(0);
-    if (ns > 1) { stage_a(1); stage_w(1); HX_WAIT_VM(4); } else { HX_WAIT_VM(0); }
+    // ---- prologue: slabs 0..PD-1 in flight, slab 0 landed everywhere
+    const int npro = ns < PD ? ns : PD;
+    for (int s = 0; s < npro; ++s) { stage_a(s, s); stage_w(s, s); }
+    wait_slabs_in_flight(npro - 1);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
+    int slot_r = 0, slot_w = PD % T_NST;
     for (int s = 0; s < ns; ++s) {
-        const char* buf = smem + (s & (T_NST - 1)) * T_SLAB;
-        const bool pre = s + 2 < ns;
+        const char* buf = smem + slot_r * T_SLAB;
+        const bool pre = s + PD < ns;
         // ================= phase a: rows [0,64) of this wave's 128 =================
         bf16x8 wf[2][2], af[2][2];
 #pragma unroll
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
             af[m][0] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 64 + koff0);
             af[m][1] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 64 + koff1);
         }
-        if (pre) stage_a(s + 2);
+        if (pre) stage_a(s + PD, slot_w);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         HX_WAIT_LGKM0();
@@ -292,7 +302,11 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
             ag[m][0] = *reinterpret_cast<const bf16x8*>(buf + a_base + (2 + m) * 32 * 64 + koff0);
             ag[m][1] = *reinterpret_cast<const bf16x8*>(buf + a_base + (2 + m) * 32 * 64 + koff1);
         }
-        if (pre) { stage_w(s + 2); HX_WAIT_VM(4); } else { HX_WAIT_VM(0); }
+        if (pre) stage_w(s + PD, slot_w);
+        {   // slab s+1 must have landed (this wave's pieces) before the next mid barrier
+            int last = s + PD < ns - 1 ? s + PD : ns - 1;
+            wait_slabs_in_flight(last - (s + 1));
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         HX_WAIT_LGKM0();
@@ -308,6 +322,8 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        slot_r = slot_r + 1 == T_NST ? 0 : slot_r + 1;
+        slot_w = slot_w + 1 == T_NST ? 0 : slot_w + 1;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
 
@@ -329,10 +345,10 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
     }
 }
 
-template <int EPI>
+template <int EPI, int T_NST>
 int launch256(GemmP p, hipStream_t s) {
     static bool configured = false;
-    auto kern = gemm_t256<EPI>;
+    auto kern = gemm_t256<EPI, T_NST>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            T_NST * T_SLAB);
@@ -346,12 +362,13 @@ int launch256(GemmP p, hipStream_t s) {
     return hirest_launch_status();
 }
 
-int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 (tests / A-B benchmarking)
+int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
 
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
-    if (g_force_kernel == 2 || (g_force_kernel == 0 && big)) return launch256<EPI>(p, s);
+    if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
+    if (g_force_kernel == 3 || (g_force_kernel == 0 && big)) return launch256<EPI, 5>(p, s);
     const int grid = 8 * p.ppx * p.nbn;
     hipLaunchKernelGGL(gemm_t128<EPI>, dim3(grid), dim3(256), 2 * STAGE_BYTES, s, p);
     return hirest_launch_status();
@@ -360,7 +377,7 @@ int launch(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    if (which < 0 || which > 2) return HIREST_E_BADARG;
+    if (which < 0 || which > 3) return HIREST_E_BADARG;
     g_force_kernel = which;
     return 0;
 }

@@ -58,6 +58,10 @@ def gemm_select_kernel(which: int):
     _lib.check(_lib.load().hirest_gemm_select_kernel(int(which)), "hirest_gemm_select_kernel")
 
 
+def attention_select_kernel(which: int):
+    _lib.check(_lib.load().hirest_attention_select_kernel(int(which)), "hirest_attention_select_kernel")
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor,
               row_index: Optional[torch.Tensor] = None, ldx: Optional[int] = None, rows: Optional[int] = None):
     lib = _lib.load()

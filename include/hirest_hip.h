@@ -71,7 +71,8 @@ typedef struct hirest_gemm_args {
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
 /* Kernel selection for tests / A-B timing: 0 = automatic (default), 1 = force the 128x128 kernel,
- * 2 = force the 256x256 ping-pong kernel.  Results are identical up to fp32 summation order. */
+ * 2 / 3 = force the 256x256 ping-pong kernel with a 4- / 5-slot LDS ring.  Results are identical
+ * (same k order per output element). */
 int hirest_gemm_select_kernel(int32_t which);
 
 /* ------------------------------------------------------------------------------------
@@ -96,6 +97,9 @@ int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_index,
 int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out,
                           int32_t B, int32_t N, int32_t H, int32_t dh,
                           float scale, int32_t causal, void* stream);
+/* 1 = register-staged kernel with a transposed V image, 2 (default) = LDS-DMA staging + hardware
+ * transpose reads.  For tests / A-B timing. */
+int hirest_attention_select_kernel(int32_t which);
 
 /* ------------------------------------------------------------------------------------
  * Patch extraction (im2col for Conv2d with kernel == stride == P, vit_model.py:198,205):

@@ -53,7 +53,7 @@ def cos_rows(a, b):
 # ----------------------------------------------------------------------------------------
 # kernels
 # ----------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2], ids=["t128", "t256"])
+@pytest.fixture(params=[1, 2, 3], ids=["t128", "t256x4", "t256x5"])
 def gemm_kernel(request, ops):
     ops.gemm_select_kernel(request.param)
     yield request.param
@@ -168,7 +168,9 @@ def _attention_ref(qkv, B, N, H, dh, causal):
 @pytest.mark.parametrize("B,N,H,dh,causal,qscale", [(2, 257, 16, 88, False, 1.0), (3, 77, 12, 64, True, 1.0),
                                                     (1, 257, 8, 88, False, 6.0), (2, 50, 12, 64, False, 1.0),
                                                     (1, 1, 2, 64, True, 1.0), (1, 272, 2, 64, False, 3.0)])
-def test_attention(dev, ops, B, N, H, dh, causal, qscale):
+@pytest.mark.parametrize("variant", [1, 2], ids=["v1", "v2"])
+def test_attention(dev, ops, B, N, H, dh, causal, qscale, variant):
+    ops.attention_select_kernel(variant)
     D = H * dh
     qkv = bf16_round(synth.tensor(f"at.{N}.{dh}", (B * N, 3 * D), 1.0, 9))
     qkv[:, :D] *= qscale   # peaky softmax when qscale > 1
@@ -176,6 +178,7 @@ def test_attention(dev, ops, B, N, H, dh, causal, qscale):
     ref = _attention_ref(qkv, B, N, H, dh, causal)
     out = torch.full((B * N, D), 9.0, dtype=torch.bfloat16, device=dev)
     ops.attention(qkv.to(torch.bfloat16).to(dev), out, B, N, H, dh, causal)
+    ops.attention_select_kernel(2)
     # P is rounded to bf16 before P.V and the output is bf16: 2 roundings of <= 2^-8 relative to max|v|
     assert (out.cpu().double() - ref).abs().max().item() <= 3 * 2 ** -8 * qkv[:, 2 * D:].abs().max().item()
 

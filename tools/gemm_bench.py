@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GEMM kernels at the EVA-CLIP-g layer shapes (random bf16 operands).
+   python tools/gemm_bench.py [--variants 1 2 3] [--frames 1024] [--iters 10] [--shapes fc1 fc2 qkv proj]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hirest_amd import _lib, ops  # noqa: E402
+
+SHAPES = {"qkv": (4224, 1408, _lib.EPI_BIAS_BF16), "proj": (1408, 1408, _lib.EPI_BIAS_RESID_F32),
+          "fc1": (6144, 1408, _lib.EPI_BIAS_GELU_BF16), "fc2": (1408, 6144, _lib.EPI_BIAS_RESID_F32),
+          "fc1_nogelu": (6144, 1408, _lib.EPI_BIAS_BF16)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", type=int, nargs="*", default=[1, 2, 3])
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--shapes", nargs="*", default=["qkv", "proj", "fc1", "fc2", "fc1_nogelu"])
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    M = a.frames * 257
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    for name in a.shapes:
+        N, K, epi = SHAPES[name]
+        A = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
+        W = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        bias = torch.randn((N,), device=dev, generator=g)
+        out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32) else torch.bfloat16)
+        for v in a.variants:
+            ops.gemm_select_kernel(v)
+            for _ in range(2):
+                ops.gemm(A, W, bias, out, epi)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                ops.gemm(A, W, bias, out, epi)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print(f"{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+        ops.gemm_select_kernel(0)
+        del A, W, out
+
+
+if __name__ == "__main__":
+    main()

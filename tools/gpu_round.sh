@@ -22,6 +22,30 @@ for k in (1,2):
     except Exception as ex: print(k,"failed",ex); print(open(f"gpurun_out/bench_k{k}.log").read()[-1500:])
 PY
   ;;
+gemm)
+  timeout 600 python tools/gemm_bench.py 2>&1 | tee gpurun_out/gemm_bench.log ;;
+pmc)
+  cd /tmp
+  rocprofv3 -L > $GRAFT_REPO_ROOT/gpurun_out/counters_list.txt 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc1 -o p -- python $GRAFT_REPO_ROOT/tools/gemm_bench.py --variants 3 --iters 3 --shapes qkv fc1 > $GRAFT_REPO_ROOT/gpurun_out/pmc1.log 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc2 -o p -- python $GRAFT_REPO_ROOT/tools/gemm_bench.py --variants 3 --iters 3 --shapes qkv fc1 > $GRAFT_REPO_ROOT/gpurun_out/pmc2.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python - <<'PY'
+import csv, glob, collections
+for d in ("pmc1","pmc2"):
+    fs = glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True)
+    print(d, fs)
+    for f in fs:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = r.get("Kernel_Name","")[:60]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+        for k, v in agg.items():
+            if "gemm" not in k: continue
+            print(k)
+            for c, val in v.items(): print(f"    {c:28s} {val / max(cnt[(k,c)],1):.4g} (per dispatch, n={cnt[(k,c)]})")
+PY
+  ;;
 bench)
   timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -c 2500 gpurun_out/bench.log ;;
 prof)
