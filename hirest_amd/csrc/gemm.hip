@@ -345,6 +345,178 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
     }
 }
 
+
+// =================================================================================================
+// Kernel "t256p": same 256x256 tile / 8 waves / 32-deep slabs / XOR-swizzled slab image as t256, but
+// software-pipelined INSIDE each wave instead of ping-ponging two wave groups: MFMA fragments are
+// double-buffered in registers one phase ahead (ds_read_b128 of the next phase and the LDS-DMA of the
+// slab PD = 3 ahead are issued under the current phase's 8 MFMAs), so the two waves of a SIMD simply
+// share the matrix pipe and hide each other's memory instructions.  One barrier per slab:
+//     phase a:  DMA A(s+3) | 8 MFMA (rows 0..63 of the wave's 128)
+//     phase b:  vmcnt(6) lgkmcnt(0) BARRIER | read all 12 fragments of slab s+1 | DMA W(s+3) | 8 MFMA (rows 64..127)
+// Ring: 4 slots.  After barrier(s) every wave has finished all reads of slab s and slab s+1 has landed
+// everywhere; DMA targets slot (s+3)&3 = slot of slab s-1, whose last reads finished before
+// barrier(s-1).  N counts this wave's pieces issued after slab s+1's: 4*(PD-2)+2 in steady state.
+// =================================================================================================
+__device__ __forceinline__ void wait_vm_pieces(int n) {
+    switch (n) {
+        case 0: HX_WAIT_VM(0); break;
+        case 2: HX_WAIT_VM(2); break;
+        case 4: HX_WAIT_VM(4); break;
+        case 6: HX_WAIT_VM(6); break;
+        case 8: HX_WAIT_VM(8); break;
+        default: HX_WAIT_VM(0); break;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
+    constexpr int NST = 4, PD = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int p_lo = xcd * p.ppx;
+    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    if (np <= 0 || j >= np * p.nbn) return;
+    const int grp = j / (GROUP_M * p.nbn);
+    const int r = j - grp * GROUP_M * p.nbn;
+    int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
+    const int nt_i = r / gcount, mt_i = p_lo + grp * GROUP_M + (r - nt_i * gcount);
+    const int M0 = mt_i * T_BM, N0 = nt_i * T_BN;
+
+    const bf16_t* a_src[2];
+    const bf16_t* w_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1;
+        int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1;
+        a_src[q] = p.A + (int64_t)gm * p.lda + chunk * 8;
+        w_src[q] = p.W + (int64_t)gn * p.ldw + chunk * 8;
+    }
+    const int piece_off = wave * 2048;
+    // DMA is issued UNCONDITIONALLY every phase (branch-free loop, constant vmcnt): past the last slab the
+    // source is clamped to the last slab and the destination is an already-consumed slot.
+    const int ns = p.K / T_BK;
+    auto stage_a = [&](int s) {
+        char* buf = smem + (s & (NST - 1)) * T_SLAB + piece_off;
+        const int sc = s < ns ? s : ns - 1;
+        glds16(a_src[0] + (int64_t)sc * T_BK, buf);
+        glds16(a_src[1] + (int64_t)sc * T_BK, buf + 1024);
+    };
+    auto stage_w = [&](int s) {
+        char* buf = smem + (s & (NST - 1)) * T_SLAB + T_WOFF + piece_off;
+        const int sc = s < ns ? s : ns - 1;
+        glds16(w_src[0] + (int64_t)sc * T_BK, buf);
+        glds16(w_src[1] + (int64_t)sc * T_BK, buf + 1024);
+    };
+
+    const int frow = lane & 31, fsw = (frow >> 2) & 3, khalf = lane >> 5;
+    const int koff0 = ((0 + khalf) ^ fsw) << 4, koff1 = ((2 + khalf) ^ fsw) << 4;
+    const int a_base = (wr * 128 + frow) * (T_BK * 2);
+    const int w_base = T_WOFF + (wc * 64 + frow) * (T_BK * 2);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    for (int s = 0; s < PD; ++s) { stage_a(s); stage_w(s); }
+    HX_WAIT_VM(8);   // 4*(PD-1): slab 0 landed
+    __builtin_amdgcn_s_barrier();
+
+    // two named fragment sets (all 12 fragments of a slab: W 2x2, A 4x2), alternated by a 2x manual unroll
+    struct Frags { bf16x8 w[2][2]; bf16x8 a[4][2]; };
+    Frags f0, f1;
+    auto load_frags = [&](const char* buf, Frags& f) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f.w[n][0] = *reinterpret_cast<const bf16x8*>(buf + w_base + n * 32 * 64 + koff0);
+            f.w[n][1] = *reinterpret_cast<const bf16x8*>(buf + w_base + n * 32 * 64 + koff1);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f.a[m][0] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 64 + koff0);
+            f.a[m][1] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 64 + koff1);
+        }
+    };
+    load_frags(smem, f0);
+
+    auto slab = [&](int s, Frags& fc, Frags& fn) {
+        // ---------------- phase a: rows [0,64) ----------------
+        stage_a(s + PD);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.w[n][ks], fc.a[m][ks], acc[m][n], 0, 0, 0);
+        // ---------------- phase b: rows [64,128) ----------------
+        __builtin_amdgcn_sched_barrier(0);
+        HX_WAIT_VM(6);   // this wave's pieces newer than slab s+1's: slab s+2 (4) + A(s+3) (2)
+        HX_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        load_frags(smem + ((s + 1) & (NST - 1)) * T_SLAB, fn);   // (past the end: a stale slot, never used)
+        stage_w(s + PD);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[2 + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.w[n][ks], fc.a[2 + m][ks], acc[2 + m][n], 0, 0, 0);
+    };
+    for (int s = 0; s < ns; s += 2) {   // ns = K/32 is even (K % 64 == 0)
+        slab(s, f0, f1);
+        slab(s + 1, f1, f0);
+    }
+    HX_WAIT_VM(0);   // no LDS-DMA may outlive the workgroup's LDS allocation
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = M0 + wr * 128 + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = N0 + wc * 64 + jn * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= p.N) continue;
+                f32x4 v = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                epilogue_store<EPI>(p, m, n, v);
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch256p(GemmP p, hipStream_t s) {
+    static bool configured = false;
+    auto kern = gemm_t256p<EPI>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           4 * T_SLAB);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
+    p.ppx = (p.nbm + 7) / 8;
+    const int grid = 8 * p.ppx * p.nbn;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 4 * T_SLAB, s, p);
+    return hirest_launch_status();
+}
+
 template <int EPI, int T_NST>
 int launch256(GemmP p, hipStream_t s) {
     static bool configured = false;
@@ -367,6 +539,7 @@ int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 w
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
+    if (g_force_kernel == 4) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
     if (g_force_kernel == 3 || (g_force_kernel == 0 && big)) return launch256<EPI, 5>(p, s);
     const int grid = 8 * p.ppx * p.nbn;
@@ -377,7 +550,7 @@ int launch(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    if (which < 0 || which > 3) return HIREST_E_BADARG;
+    if (which < 0 || which > 4) return HIREST_E_BADARG;
     g_force_kernel = which;
     return 0;
 }

@@ -17,10 +17,12 @@ SHAPES = {"qkv": (4224, 1408, _lib.EPI_BIAS_BF16), "proj": (1408, 1408, _lib.EPI
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", type=int, nargs="*", default=[1, 2, 3])
+    ap.add_argument("--variants", type=int, nargs="*", default=[1, 2, 4])
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", nargs="*", default=["qkv", "proj", "fc1", "fc2", "fc1_nogelu"])
+    ap.add_argument("--alias", action="store_true", help="lda=ldw=0: every row aliases row 0 (operands stay cache-resident): "
+                    "kernel-structure ceiling without the memory system")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M = a.frames * 257
@@ -31,18 +33,26 @@ def main():
         W = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.bfloat16)
         bias = torch.randn((N,), device=dev, generator=g)
         out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32) else torch.bfloat16)
+        import ctypes as C
+        lib = _lib.load()
+
+        def run():
+            if not a.alias:
+                return ops.gemm(A, W, bias, out, epi)
+            args = _lib.GemmArgs(A.data_ptr(), 0, W.data_ptr(), 0, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
+            _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "gemm")
         for v in a.variants:
             ops.gemm_select_kernel(v)
             for _ in range(2):
-                ops.gemm(A, W, bias, out, epi)
+                run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                ops.gemm(A, W, bias, out, epi)
+                run()
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
-            print(f"{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+            print(f"{'[alias] ' if a.alias else ''}{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
         ops.gemm_select_kernel(0)
         del A, W, out
 

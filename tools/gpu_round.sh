@@ -23,12 +23,13 @@ for k in (1,2):
 PY
   ;;
 gemm)
-  timeout 600 python tools/gemm_bench.py 2>&1 | tee gpurun_out/gemm_bench.log ;;
+  timeout 600 python tools/gemm_bench.py --shapes qkv fc2 2>&1 | tee gpurun_out/gemm_bench.log
+  timeout 600 python tools/gemm_bench.py --shapes qkv fc2 --alias 2>&1 | tee -a gpurun_out/gemm_bench.log ;;
 pmc)
   cd /tmp
   rocprofv3 -L > $GRAFT_REPO_ROOT/gpurun_out/counters_list.txt 2>&1
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc1 -o p -- python $GRAFT_REPO_ROOT/tools/gemm_bench.py --variants 3 --iters 3 --shapes qkv fc1 > $GRAFT_REPO_ROOT/gpurun_out/pmc1.log 2>&1
-  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc2 -o p -- python $GRAFT_REPO_ROOT/tools/gemm_bench.py --variants 3 --iters 3 --shapes qkv fc1 > $GRAFT_REPO_ROOT/gpurun_out/pmc2.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc1 -o p -- python $GRAFT_REPO_ROOT/tools/gemm_bench.py --variants 2 --iters 3 --shapes qkv fc2 > $GRAFT_REPO_ROOT/gpurun_out/pmc1.log 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc2 -o p -- python $GRAFT_REPO_ROOT/tools/gemm_bench.py --variants 2 --iters 3 --shapes qkv fc2 > $GRAFT_REPO_ROOT/gpurun_out/pmc2.log 2>&1
   cd $GRAFT_REPO_ROOT
   python - <<'PY'
 import csv, glob, collections
@@ -49,7 +50,7 @@ PY
 bench)
   timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -c 2500 gpurun_out/bench.log ;;
 prof)
-  cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; cd $GRAFT_REPO_ROOT
+  cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; cd $GRAFT_REPO_ROOT
   ls -R gpurun_out/prof | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); head -20 $f ;;
 esac
 done
