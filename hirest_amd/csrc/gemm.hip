@@ -26,6 +26,7 @@ struct GemmP {
     int M, N, K;
     const float* pos; int P;
     int nbm, nbn, ppx;   // tile counts, M-panels per XCD
+    int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -369,6 +370,107 @@ __device__ __forceinline__ void wait_vm_pieces(int n) {
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Epilogue of the 256x256 kernels: each wave transposes its 128x64 accumulator block through a
+// private LDS staging area, 32 rows at a time, so that global traffic is whole 128-B lines
+// (16 B per lane, 8 or 16 lanes per output row) instead of 8-B pieces scattered over 32 rows, and the
+// bias / residual / pos operands are fetched in batches instead of one dependent load per store.
+//   lane -> LDS : row (lane&31), 4 consecutive columns  (MFMA D layout with swapped operands)
+//   LDS -> HBM  : bf16 out: 4 instr x (8 rows x 128 B);  f32 out: 8 instr x (4 rows x 256 B)
+// -------------------------------------------------------------------------------------------------
+constexpr int STG_RSB = 144;                 // bf16 staging row stride (bytes): 128 + 16 pad
+constexpr int STG_RSF = 272;                 // f32 staging row stride: 256 + 16 pad
+constexpr int STG_BYTES = 32 * STG_RSF;      // per wave
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_256(const GemmP& p, f32x16 (&acc)[4][2], char* stg, int Mw, int Nw, int lane) {
+    constexpr bool OUT_BF16 = (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_QGELU_BF16);
+    const int half = lane >> 5, lrow = lane & 31;
+    f32x4 bv[2][4];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = Nw + jn * 32 + 8 * g + 4 * half;
+            bv[jn][g] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // ---- registers -> staging
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                v += bv[jn][g];
+                const int col = jn * 32 + 8 * g + 4 * half;
+                if constexpr (OUT_BF16) {
+                    if constexpr (EPI == HIREST_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if constexpr (EPI == HIREST_EPI_BIAS_QGELU_BF16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x4*>(stg + lrow * STG_RSB + col * 2) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(stg + lrow * STG_RSF + col * 4) = v;
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // ---- staging -> global, whole lines
+        const int mb = Mw + i * 32;
+        if constexpr (OUT_BF16) {
+            bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), c = lane & 7;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * STG_RSB + c * 16);
+                const int m = mb + r, n = Nw + c * 8;
+                if (m < p.M) {
+                    bf16_t* dst = outp + (int64_t)m * p.ldo + n;
+                    if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+                    else if (n + 4 <= p.N) *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        } else {
+            float* outp = reinterpret_cast<float*>(p.out);
+            f32x4 v[8], o[8];
+            int64_t off[8];
+            bool ok[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 4 + (lane >> 4), c = lane & 15;
+                v[it] = *reinterpret_cast<const f32x4*>(stg + r * STG_RSF + c * 16);
+                const int m = mb + r, n = Nw + c * 4;
+                ok[it] = m < p.M && n < p.N;
+                if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
+                    const int mm = ok[it] ? m : 0;
+                    const int b = mm / p.P, pp = mm - b * p.P;
+                    off[it] = ((int64_t)b * (p.P + 1) + 1 + pp) * p.ldo + n;
+                    o[it] = ok[it] ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    off[it] = (int64_t)m * p.ldo + n;
+                    if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32)
+                        o[it] = ok[it] ? *reinterpret_cast<const f32x4*>(outp + off[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                f32x4 w = v[it];
+                if constexpr (EPI != HIREST_EPI_BIAS_F32) w += o[it];
+                if (ok[it]) *reinterpret_cast<f32x4*>(outp + off[it]) = w;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // staging rows are rewritten next pass
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
     constexpr int NST = 4, PD = 3;
@@ -452,7 +554,7 @@ __global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
 
     auto slab = [&](int s, Frags& fc, Frags& fn) {
         // ---------------- phase a: rows [0,64) ----------------
-        stage_a(s + PD);
+        if (!(p.dbg & 1)) stage_a(s + PD);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -463,11 +565,13 @@ __global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.w[n][ks], fc.a[m][ks], acc[m][n], 0, 0, 0);
         // ---------------- phase b: rows [64,128) ----------------
         __builtin_amdgcn_sched_barrier(0);
-        HX_WAIT_VM(6);   // this wave's pieces newer than slab s+1's: slab s+2 (4) + A(s+3) (2)
-        HX_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
+        if (!(p.dbg & 2)) {
+            HX_WAIT_VM(6);   // this wave's pieces newer than slab s+1's: slab s+2 (4) + A(s+3) (2)
+            HX_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+        }
         load_frags(smem + ((s + 1) & (NST - 1)) * T_SLAB, fn);   // (past the end: a stale slot, never used)
-        stage_w(s + PD);
+        if (!(p.dbg & 1)) stage_w(s + PD);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -481,23 +585,10 @@ __global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
         slab(s, f0, f1);
         slab(s + 1, f1, f0);
     }
-    HX_WAIT_VM(0);   // no LDS-DMA may outlive the workgroup's LDS allocation
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = M0 + wr * 128 + i * 32 + (lane & 31);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = N0 + wc * 64 + jn * 32 + 8 * g + 4 * (lane >> 5);
-                if (n >= p.N) continue;
-                f32x4 v = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
-                epilogue_store<EPI>(p, m, n, v);
-            }
-        }
-    }
+    HX_WAIT_VM(0);                  // no LDS-DMA may outlive the slab ring: it becomes the epilogue staging area
+    HX_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();   // every wave is done reading slabs
+    epilogue_256<EPI>(p, acc, smem + wave * STG_BYTES, M0 + wr * 128, N0 + wc * 64, lane);
 }
 
 template <int EPI>
@@ -539,15 +630,18 @@ int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 w
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
-    if (g_force_kernel == 4) return launch256p<EPI>(p, s);
+    if (g_force_kernel == 4 || (g_force_kernel == 0 && big)) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
-    if (g_force_kernel == 3 || (g_force_kernel == 0 && big)) return launch256<EPI, 5>(p, s);
+    if (g_force_kernel == 3) return launch256<EPI, 5>(p, s);
     const int grid = 8 * p.ppx * p.nbn;
     hipLaunchKernelGGL(gemm_t128<EPI>, dim3(grid), dim3(256), 2 * STAGE_BYTES, s, p);
     return hirest_launch_status();
 }
 
 }  // namespace
+
+int g_gemm_dbg = 0;
+extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
     if (which < 0 || which > 4) return HIREST_E_BADARG;
@@ -565,6 +659,7 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.bias = a->bias; p.out = a->out; p.ldo = a->ldo;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.pos = a->pos; p.P = a->patches_per_frame;
+    p.dbg = g_gemm_dbg;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
     p.ppx = (p.nbm + 7) / 8;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -74,6 +74,9 @@ int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
  * 2 / 3 = force the 256x256 ping-pong kernel with a 4- / 5-slot LDS ring.  Results are identical
  * (same k order per output element). */
 int hirest_gemm_select_kernel(int32_t which);
+/* TIMING EXPERIMENTS ONLY (results become wrong): bit0 = skip the main-loop LDS-DMA, bit1 = skip the
+ * main-loop barrier and waits of the t256p kernel.  0 restores normal operation. */
+int hirest_gemm_debug_mode(int32_t bits);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the last dim (biased variance, fp32 statistics), fp32 in -> bf16 or f32 out.
