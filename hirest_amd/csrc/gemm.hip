@@ -353,11 +353,11 @@ __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
 // double-buffered in registers one phase ahead (ds_read_b128 of the next phase and the LDS-DMA of the
 // slab PD = 3 ahead are issued under the current phase's 8 MFMAs), so the two waves of a SIMD simply
 // share the matrix pipe and hide each other's memory instructions.  One barrier per slab:
-//     phase a:  DMA A(s+3) | 8 MFMA (rows 0..63 of the wave's 128)
-//     phase b:  vmcnt(6) lgkmcnt(0) BARRIER | read all 12 fragments of slab s+1 | DMA W(s+3) | 8 MFMA (rows 64..127)
+//     vmcnt(4) lgkmcnt(0) BARRIER | 16 MFMA (slab s), each shadowing one of: 12 fragment reads of slab s+1,
+//                                   4 LDS-DMA pieces of slab s+3
 // Ring: 4 slots.  After barrier(s) every wave has finished all reads of slab s and slab s+1 has landed
 // everywhere; DMA targets slot (s+3)&3 = slot of slab s-1, whose last reads finished before
-// barrier(s-1).  N counts this wave's pieces issued after slab s+1's: 4*(PD-2)+2 in steady state.
+// barrier(s-1).  vmcnt(4): the only pieces of this wave newer than slab s+1's are slab s+2's four.
 // =================================================================================================
 __device__ __forceinline__ void wait_vm_pieces(int n) {
     switch (n) {
@@ -553,33 +553,35 @@ __global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
     load_frags(smem, f0);
 
     auto slab = [&](int s, Frags& fc, Frags& fn) {
-        // ---------------- phase a: rows [0,64) ----------------
-        if (!(p.dbg & 1)) stage_a(s + PD);
+        // slab s+1 has landed for this wave (pieces newer than it: slab s+2's 4) -> publish with the barrier
+        HX_WAIT_VM(4);
+        HX_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        // fragment reads of slab s+1, DMA of slab s+3 and this slab's 16 MFMAs; the sched_group_barrier
+        // sequence below interleaves them (one memory instruction in each MFMA's shadow) instead of
+        // letting all 8 waves burst 12 ds_read_b128 into the LDS queue right after the barrier.
+        load_frags(smem + ((s + 1) & (NST - 1)) * T_SLAB, fn);   // (past the end: a stale slot, never used)
+        stage_a(s + PD);
+        stage_w(s + PD);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.w[n][ks], fc.a[m][ks], acc[m][n], 0, 0, 0);
-        // ---------------- phase b: rows [64,128) ----------------
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(p.dbg & 2)) {
-            HX_WAIT_VM(6);   // this wave's pieces newer than slab s+1's: slab s+2 (4) + A(s+3) (2)
-            HX_WAIT_LGKM0();
-            __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
         }
-        load_frags(smem + ((s + 1) & (NST - 1)) * T_SLAB, fn);   // (past the end: a stale slot, never used)
-        if (!(p.dbg & 1)) stage_w(s + PD);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (LDS-DMA piece)
+        }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[2 + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.w[n][ks], fc.a[2 + m][ks], acc[2 + m][n], 0, 0, 0);
     };
     for (int s = 0; s < ns; s += 2) {   // ns = K/32 is even (K % 64 == 0)
         slab(s, f0, f1);
@@ -589,6 +591,172 @@ __global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
     HX_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();   // every wave is done reading slabs
     epilogue_256<EPI>(p, acc, smem + wave * STG_BYTES, M0 + wr * 128, N0 + wc * 64, lane);
+}
+
+
+// =================================================================================================
+// Kernel "t256q": t256p with 64-deep K steps so that every LDS-DMA wave-instruction fetches whole
+// 128-B lines (8 rows x 128 B).  Measured on MI355X (tools/probes/dma_probe.hip): LDS-DMA streaming of
+// L2-resident rows tops out at 30 GB/s per CU with 64-B row segments and 47 GB/s per CU with 128-B
+// segments — the 32-deep-slab kernel sat exactly on the former ceiling.
+//
+// Ring: 2 slots x 64 KiB (A 256 rows + W 256 rows, 128 B each, chunk' = chunk ^ ((row>>1)&7)).
+// One iteration = one 32-deep half of a step (16 MFMAs per wave), fragments prefetched one iteration ahead:
+//   it 2t   : [lgkmcnt(0) BARRIER]            16 MFMA (step t, k 0..31)  | read frags (step t, k 32..63)
+//   it 2t+1 : [vmcnt(0) lgkmcnt(0) BARRIER]   16 MFMA (step t, k 32..63) | read frags (step t+1, k 0..31)
+//                                                                        | DMA step t+2 -> slot t&1 (8 pieces)
+// RAW: step t+1's pieces were issued during iteration 2t-1 and are waited for (vmcnt(0): nothing newer
+// exists yet) before barrier(2t+1).  WAR: slot t&1 is last read during iteration 2t (k 32..63 of step t);
+// those reads are complete before barrier(2t+1), the DMA is issued after it.
+// =================================================================================================
+constexpr int Q_BK = 64;
+constexpr int Q_STEP = (T_BM + T_BN) * Q_BK * 2;   // 64 KiB
+constexpr int Q_WOFF = T_BM * Q_BK * 2;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_t256q(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int p_lo = xcd * p.ppx;
+    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    if (np <= 0 || j >= np * p.nbn) return;
+    const int grp = j / (GROUP_M * p.nbn);
+    const int r = j - grp * GROUP_M * p.nbn;
+    int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
+    const int nt_i = r / gcount, mt_i = p_lo + grp * GROUP_M + (r - nt_i * gcount);
+    const int M0 = mt_i * T_BM, N0 = nt_i * T_BN;
+
+    // LDS-DMA pieces: 1 KiB = 8 rows x 128 B; this wave owns A pieces 4w..4w+3 and W pieces 4w..4w+3
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1;
+        int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1;
+        a_src[q] = p.A + (int64_t)gm * p.lda + chunk * 8;
+        w_src[q] = p.W + (int64_t)gn * p.ldw + chunk * 8;
+    }
+    const int nst = p.K / Q_BK;
+    const int piece_off = wave * 4096;
+    auto stage = [&](int t) {   // DMA of step t (clamped past the end: dummy refetch into a consumed slot)
+        char* buf = smem + (t & 1) * Q_STEP + piece_off;
+        const int tc = t < nst ? t : nst - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(a_src[q] + (int64_t)tc * Q_BK, buf + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(w_src[q] + (int64_t)tc * Q_BK, buf + Q_WOFF + q * 1024);
+    };
+
+    const int frow = lane & 31, fsw = (frow >> 1) & 7, khalf = lane >> 5;
+    const int a_base = (wr * 128 + frow) * (Q_BK * 2);
+    const int w_base = Q_WOFF + (wc * 64 + frow) * (Q_BK * 2);
+    int koff[4];   // chunk offsets for (h, ks): chunk = 4h + 2ks + khalf
+#pragma unroll
+    for (int c = 0; c < 4; ++c) koff[c] = ((2 * c + khalf) ^ fsw) << 4;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    struct Frags { bf16x8 w[2][2]; bf16x8 a[4][2]; };
+    Frags f0, f1;
+    auto load_frags = [&](const char* buf, int h, Frags& f) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f.w[n][0] = *reinterpret_cast<const bf16x8*>(buf + w_base + n * 32 * 128 + koff[2 * h]);
+            f.w[n][1] = *reinterpret_cast<const bf16x8*>(buf + w_base + n * 32 * 128 + koff[2 * h + 1]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f.a[m][0] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 128 + koff[2 * h]);
+            f.a[m][1] = *reinterpret_cast<const bf16x8*>(buf + a_base + m * 32 * 128 + koff[2 * h + 1]);
+        }
+    };
+    auto mfma16 = [&](Frags& fc) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.w[n][ks], fc.a[m][ks], acc[m][n], 0, 0, 0);
+    };
+
+    // ---- prologue: steps 0 and 1 in flight, step 0 landed, first fragments in registers
+    stage(0);
+    stage(1);
+    HX_WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    load_frags(smem, 0, f0);
+
+    for (int t = 0; t < nst; ++t) {
+        const char* cur = smem + (t & 1) * Q_STEP;
+        const char* nxt = smem + ((t + 1) & 1) * Q_STEP;
+        // ---- iteration 2t: k 0..31 of step t
+        HX_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, 1, f1);
+        mfma16(f0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- iteration 2t+1: k 32..63 of step t
+        HX_WAIT_VM(0);
+        HX_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(nxt, 0, f0);          // (past the end: stale data, never used)
+        stage(t + 2);
+        mfma16(f1);
+        // (the DMA writes LDS, so the compiler keeps it behind the fragment reads: reads first, then DMA)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    HX_WAIT_VM(0);
+    HX_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    epilogue_256<EPI>(p, acc, smem + wave * STG_BYTES, M0 + wr * 128, N0 + wc * 64, lane);
+}
+
+template <int EPI>
+int launch256q(GemmP p, hipStream_t s) {
+    static bool configured = false;
+    auto kern = gemm_t256q<EPI>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * Q_STEP);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
+    p.ppx = (p.nbm + 7) / 8;
+    const int grid = 8 * p.ppx * p.nbn;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * Q_STEP, s, p);
+    return hirest_launch_status();
 }
 
 template <int EPI>
@@ -630,6 +798,7 @@ int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 w
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
+    if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4 || (g_force_kernel == 0 && big)) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
     if (g_force_kernel == 3) return launch256<EPI, 5>(p, s);
@@ -644,7 +813,7 @@ int g_gemm_dbg = 0;
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    if (which < 0 || which > 4) return HIREST_E_BADARG;
+    if (which < 0 || which > 5) return HIREST_E_BADARG;
     g_force_kernel = which;
     return 0;
 }

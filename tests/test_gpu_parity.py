@@ -53,7 +53,7 @@ def cos_rows(a, b):
 # ----------------------------------------------------------------------------------------
 # kernels
 # ----------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4], ids=["t128", "t256x4", "t256x5", "t256p"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["t128", "t256x4", "t256x5", "t256p", "t256q"])
 def gemm_kernel(request, ops):
     ops.gemm_select_kernel(request.param)
     yield request.param
