@@ -798,8 +798,8 @@ int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 w
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
-    if (g_force_kernel == 5) return launch256q<EPI>(p, s);
-    if (g_force_kernel == 4 || (g_force_kernel == 0 && big)) return launch256p<EPI>(p, s);
+    if (g_force_kernel == 5 || (g_force_kernel == 0 && big)) return launch256q<EPI>(p, s);
+    if (g_force_kernel == 4) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
     if (g_force_kernel == 3) return launch256<EPI, 5>(p, s);
     const int grid = 8 * p.ppx * p.nbn;

@@ -5,16 +5,17 @@ out=$1; filt=$2; shift 3
 mkdir -p $out
 export TMPDIR=/tmp
 declare -a PASSES=(
- "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
- "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD"
- "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum"
- "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_GATE_EN1_sum"
+ "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_CMD_FIFO_FULL SQ_LDS_IDX_ACTIVE"
+ "GRBM_GUI_ACTIVE"
+ "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum"
+ "TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum"
- "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUSY_sum SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_BF16"
+ "TCC_EA0_RDREQ_sum TCC_BUSY_sum"
+ "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
 )
 i=0
 for p in "${PASSES[@]}"; do
-  ( cd /tmp && rocprofv3 --pmc $p --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/p$i -o p -- "$@" > $GRAFT_REPO_ROOT/$out/p$i.log 2>&1 )
+  ( cd /tmp && timeout 90 rocprofv3 --pmc $p --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/p$i -o p -- "$@" > $GRAFT_REPO_ROOT/$out/p$i.log 2>&1 )
   i=$((i+1))
 done
 python - "$out" "$filt" <<'PY'
