@@ -213,6 +213,10 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
     for (int i = wave; i < C::NK_INSTR; i += 8) {
         const int ci = i * 64 + lane;
         int row = ci / C::CPR, c = ci - row * C::CPR;
+        // K image is XOR-swizzled inside each 4-chunk group: position p holds chunk (p&~3)|((p&3)^f(row)),
+        // f(row) = (-(row>>2))&3 — makes the S^T fragment reads (16 rows x one chunk per 16-lane group)
+        // hit 16 distinct 16-B slots at the 192-B row stride (was a 2-way conflict).
+        c = (c & ~3) | ((c & 3) ^ ((-(row >> 2)) & 3));
         row = row < N ? row : N - 1;
         c = c * 8 < DH ? c : DH / 8 - 1;
         glds16(base + (int64_t)row * ld + D + c * 8, Ks + i * 1024);
@@ -229,6 +233,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
     __builtin_amdgcn_s_barrier();   // ... and everybody else's
 
     const int g = lane >> 4, c16 = lane & 15;
+    const int gk = g ^ ((-(c16 >> 2)) & 3);   // swizzled chunk-in-group for this lane's K rows
     const int nqt = (N + 15) >> 4;
     bool v_ready = false;
     for (int qt = wave; qt < nqt; qt += 8) {
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < DP / 32; ++kk) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::RS + (kk * 4 + g) * 16);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::RS + (kk * 4 + gk) * 16);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
             }
             st[t] = acc;

@@ -64,6 +64,68 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
     }
 }
 
+// Bulk variant for the per-layer LayerNorms (rows >> CUs): each wave owns R consecutive rows and issues
+// all of their loads before the first reduction, so R x NV x 16 B per lane are in flight (the one-row
+// kernel is latency-bound at ~2.9 TB/s); grid-strided so the launch is a few thousand blocks.
+template <int NV, int R>
+__global__ __launch_bounds__(256) void layernorm_rows_bulk(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, bf16_t* __restrict__ out, int64_t ldo, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int nv = D >> 2;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    f32x4 g[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        g[i] = c < nv ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b[i] = c < nv ? *reinterpret_cast<const f32x4*>(beta + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row0 = wave_global * R; row0 < rows; row0 += nwaves * R) {
+        f32x4 v[R][NV];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r < rows ? row0 + r : rows - 1;
+            const float* xr = x + (int64_t)row * ldx;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                v[r][i] = c < nv ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+            const float mean = wave_sum(s) / (float)D;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (lane + 64 * i < nv) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mean; q += d * d; }
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+            if (row0 + r < rows) {
+                bf16_t* orow = out + (int64_t)(row0 + r) * ldo;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < nv) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[r][i][e] - mean) * rstd * g[i][e] + b[i][e]);
+                        *reinterpret_cast<bf16x4*>(orow + 4 * c) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Patch extraction.  One thread produces 8 consecutive k-columns (16 B of bf16) of one patch row.
 // Column k = c*P*P + ph*P + pw (conv weight flatten order, vit_model.py:198).
@@ -191,6 +253,16 @@ extern "C" int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_
     if (D <= 0 || D % 4 != 0 || D > 8192 || ldx % 4 != 0 || ldo % 4 != 0) return HIREST_E_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HirestProfScope prof(HIREST_PROF_LAYERNORM, 0, rows, D, 0, s);
+    if (!out_is_f32 && !row_index && rows >= 8192 && D <= 6 * 256) {   // the per-layer LayerNorms
+        const int nv = (D / 4 + 63) / 64;
+        const int grid = 256 * 8;
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+#define LNB_CASE(NVV) \
+    case NVV: hipLaunchKernelGGL((layernorm_rows_bulk<NVV, 4>), dim3(grid), dim3(256), 0, s, x, ldx, gamma, beta, eps, o, ldo, rows, D); \
+        return hirest_launch_status();
+        switch (nv) { LNB_CASE(1) LNB_CASE(2) LNB_CASE(3) LNB_CASE(4) LNB_CASE(5) LNB_CASE(6) default: break; }
+#undef LNB_CASE
+    }
     if (out_is_f32) return launch_ln<true>(x, ldx, row_index, gamma, beta, eps, out, ldo, rows, D, s);
     return launch_ln<false>(x, ldx, row_index, gamma, beta, eps, out, ldo, rows, D, s);
 }

@@ -700,41 +700,55 @@ __global__ __launch_bounds__(512) void gemm_t256q(GemmP p) {
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, f0);
 
-    for (int t = 0; t < nst; ++t) {
-        const char* cur = smem + (t & 1) * Q_STEP;
-        const char* nxt = smem + ((t + 1) & 1) * Q_STEP;
-        // ---- iteration 2t: k 0..31 of step t
-        HX_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(cur, 1, f1);
-        mfma16(f0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    // Waves whose 64 output columns (or 128 rows) lie entirely in the padding of a ragged edge tile
+    // (N = 1408 = 5.5 tiles: half the waves of every 6th tile) skip fragments and MFMAs — they only keep
+    // the DMA and barrier schedule.  The chip is power-limited here, so idle matrix pipes are not wasted.
+    const bool active = (N0 + wc * 64 < p.N) && (M0 + wr * 128 < p.M);
+    if (active) {
+        for (int t = 0; t < nst; ++t) {
+            const char* cur = smem + (t & 1) * Q_STEP;
+            const char* nxt = smem + ((t + 1) & 1) * Q_STEP;
+            // ---- iteration 2t: k 0..31 of step t
+            HX_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(cur, 1, f1);
+            mfma16(f0);
+    #pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- iteration 2t+1: k 32..63 of step t
+            HX_WAIT_VM(0);
+            HX_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(nxt, 0, f0);          // (past the end: stale data, never used)
+            stage(t + 2);
+            mfma16(f1);
+            // (the DMA writes LDS, so the compiler keeps it behind the fragment reads: reads first, then DMA)
+    #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+    #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- iteration 2t+1: k 32..63 of step t
-        HX_WAIT_VM(0);
-        HX_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(nxt, 0, f0);          // (past the end: stale data, never used)
-        stage(t + 2);
-        mfma16(f1);
-        // (the DMA writes LDS, so the compiler keeps it behind the fragment reads: reads first, then DMA)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    } else {
+        for (int t = 0; t < nst; ++t) {
+            HX_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            HX_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+            stage(t + 2);
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
     HX_WAIT_VM(0);
     HX_WAIT_LGKM0();

@@ -137,7 +137,8 @@ def test_patchify_uint8_fused_normalize(dev, ops):
     assert d <= 2 ** -6  # at most one bf16 ulp at |x| < 2.7 (fp32 op-order differences before rounding)
 
 
-@pytest.mark.parametrize("rows,D,eps", [(257 * 2, 1408, 1e-6), (77, 768, 1e-5), (10, 512, 1e-12), (5, 384, 1e-5), (9, 6144, 1e-5)])
+@pytest.mark.parametrize("rows,D,eps", [(257 * 2, 1408, 1e-6), (77, 768, 1e-5), (10, 512, 1e-12), (5, 384, 1e-5), (9, 6144, 1e-5),
+                                          (8227, 1408, 1e-6), (9001, 768, 1e-5)])
 def test_layernorm(dev, ops, rows, D, eps):
     from oracle import ref_cpu as O
     x = synth.tensor("ln.x", (rows, D), 2.0, 5, mean=0.3)
