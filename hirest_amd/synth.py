@@ -248,3 +248,28 @@ def openai_clip_shapes(c: dict) -> Dict[str, Tuple[int, ...]]:
 
 def openai_clip_state_dict(c: dict, seed: int) -> Dict[str, torch.Tensor]:
     return state_dict(openai_clip_shapes(c), seed)
+
+
+# ----------------------------------------------------------------------------------
+# Joint model (MomentModel minus the frozen EVA-CLIP): schema = the reference's own state-dict keys
+# (tests/golden/joint_schema.json, dumped from the real module)
+# ----------------------------------------------------------------------------------
+
+def joint_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str, torch.Tensor]:
+    out = {}
+    for name, shape in shapes.items():
+        leaf = name.split(".")[-1]
+        if "LayerNorm" in name or "visual_norm2d" in name or name.startswith("asr_enc_layer.0"):
+            std, mean = (0.1, 1.0) if leaf == "weight" else (0.05, 0.0)
+        elif leaf == "bias":
+            std, mean = 0.02, 0.0
+        elif "predictor" in name:
+            std, mean = 0.05, 0.0
+        elif name.endswith("query.weight") or name.endswith("key.weight"):
+            std, mean = 0.06, 0.0          # non-trivial attention logits
+        elif "embed" in name.lower():
+            std, mean = 0.05, 0.0
+        else:
+            std, mean = 0.03, 0.0
+        out[name] = tensor(name, shape, std, seed, mean)
+    return out

@@ -280,3 +280,152 @@ def compute_iou(a, b) -> float:
     inter = max(0, min(b[1], a[1]) - max(b[0], a[0]))
     union = min(max(b[1], a[1]) - min(b[0], a[0]), b[1] - b[0] + a[1] - a[0])
     return float(inter) / (union + 1e-8)
+
+
+# ----------------------------------------------------------------------------------
+# Joint model: fusion + 2-layer BERT-style encoder + heads (modeling.py:155-224, module_visual.py)
+# ----------------------------------------------------------------------------------
+
+_V = "clip4cap_model.visual."
+
+
+def joint_time_grid(vis_mask: torch.Tensor) -> torch.Tensor:
+    """modeling.py:176-193: per sample (linspace(0,1,n)-0.5)*2 over its n valid frames, zero padded."""
+    B, T = vis_mask.shape
+    out = torch.zeros(B, T)
+    for b in range(B):
+        n = int(vis_mask[b].sum())
+        out[b, :n] = (torch.linspace(0, 1, n) - 0.5) * 2
+    return out
+
+
+def joint_fusion(sd: SD, vis, text, asr, vis_mask, moment_mask, boundary_mask=None) -> torch.Tensor:
+    """foward_moment_shared up to the encoder input (modeling.py:155-199).  TF-style LayerNorm eps 1e-12
+    (until_module.py:40-53) on the mapped frames, torch LayerNorm (eps 1e-5) inside asr_enc_layer."""
+    v = vis @ sd["clip_g_map.weight"].t() + sd["clip_g_map.bias"]
+    v = layer_norm(v, sd["clip4cap_model.normalize_video.visual_norm2d.weight"],
+                   sd["clip4cap_model.normalize_video.visual_norm2d.bias"], 1e-12)
+    t = text @ sd["clip_g_map_text.weight"].t() + sd["clip_g_map_text.bias"]
+    t = t / t.norm(dim=-1, keepdim=True)
+    f = v * t.unsqueeze(1)
+    a = layer_norm(asr, sd["asr_enc_layer.0.weight"], sd["asr_enc_layer.0.bias"], 1e-5)
+    f = f + (a @ sd["asr_enc_layer.1.weight"].t() + sd["asr_enc_layer.1.bias"])
+    if boundary_mask is not None:
+        f = f + sd["boundary_embed.weight"][boundary_mask]
+    tg = joint_time_grid(vis_mask).unsqueeze(-1)
+    te = torch.tanh(tg @ sd["temporal_embed.0.weight"].t() + sd["temporal_embed.0.bias"])
+    f = f + (te @ sd["temporal_embed.2.weight"].t() + sd["temporal_embed.2.bias"])
+    return f + sd["mask_embed.weight"][moment_mask]
+
+
+def visual_encoder(sd: SD, f: torch.Tensor, heads: int = 12, layers: int = 2) -> torch.Tensor:
+    """VisualModel.forward with an all-zeros mask (modeling.py:208 passes zeros, module_visual.py:406-414
+    turns that into a UNIFORM -10000 added to every score in fp32 — SURVEY hazard H3 — reproduced here)."""
+    B, T, _ = f.shape
+    x = f @ sd[_V + "embeddings.word_embeddings.weight"].t() + sd[_V + "embeddings.word_embeddings.bias"]
+    x = x + sd[_V + "embeddings.position_embeddings.weight"][:T]
+    x = layer_norm(x, sd[_V + "embeddings.LayerNorm.weight"], sd[_V + "embeddings.LayerNorm.bias"], 1e-12)
+    D = x.shape[-1]
+    dh = D // heads
+    for i in range(layers):
+        p = _V + f"encoder.layer.{i}."
+        q = (x @ sd[p + "attention.self.query.weight"].t() + sd[p + "attention.self.query.bias"]).view(B, T, heads, dh).transpose(1, 2)
+        k = (x @ sd[p + "attention.self.key.weight"].t() + sd[p + "attention.self.key.bias"]).view(B, T, heads, dh).transpose(1, 2)
+        v = (x @ sd[p + "attention.self.value.weight"].t() + sd[p + "attention.self.value.bias"]).view(B, T, heads, dh).transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(dh) + (-10000.0)
+        c = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, T, D)
+        a = layer_norm(c @ sd[p + "attention.output.dense.weight"].t() + sd[p + "attention.output.dense.bias"] + x,
+                       sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], 1e-12)
+        h = gelu_erf(a @ sd[p + "intermediate.dense.weight"].t() + sd[p + "intermediate.dense.bias"])
+        x = layer_norm(h @ sd[p + "output.dense.weight"].t() + sd[p + "output.dense.bias"] + a,
+                       sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
+    return x
+
+
+def joint_features(sd: SD, vis, text, asr, vis_mask, moment_mask, boundary_mask=None) -> torch.Tensor:
+    return visual_encoder(sd, joint_fusion(sd, vis, text, asr, vis_mask, moment_mask, boundary_mask))
+
+
+def head_logits(sd: SD, feats: torch.Tensor, name: str) -> torch.Tensor:
+    """nn.Linear(768, 1).squeeze(2) (modeling.py:80-99, 218-219, 319)."""
+    return (feats @ sd[name + ".0.weight"].t() + sd[name + ".0.bias"]).squeeze(2)
+
+
+def moment_retrieval(sd: SD, vis, text, asr, vis_mask, moment_mask):
+    """test_moment_retrieval (modeling.py:272-310): masked argmax of start / end logits -> [[s, e]]."""
+    feats = joint_features(sd, vis, text, asr, vis_mask, moment_mask)
+    s, e = head_logits(sd, feats, "start_predictor"), head_logits(sd, feats, "end_predictor")
+    s = s.masked_fill(vis_mask == 0, -1e10)
+    e = e.masked_fill(vis_mask == 0, -1e10)
+    return torch.stack([s.argmax(1), e.argmax(1)], -1).tolist(), s, e
+
+
+def segmentation_walk(scores: Sequence[float], max_idx: int, threshold: float):
+    """The per-sample threshold walk of modeling.py:399-433.  Returns (left, right) or None when skipped."""
+    max_score = scores[max_idx]
+    if max_score < 0.00001:
+        return None
+    left = right = max_idx
+    while (scores[left] / max_score) > threshold:
+        if left == 0:
+            break
+        left -= 1
+    while (scores[right] / max_score) > threshold:
+        if right == len(scores) - 1:
+            break
+        right += 1
+    if left == 0 or right == 0:
+        return None
+    return left, right
+
+
+def segmentation_postprocess(steps: List[List[int]], last_bound: int) -> List[int]:
+    """modeling.py:435-463: sort by start, flatten, drop values past the moment end, set(), sort, then keep
+    bounds at least 5 apart — the LAST candidate is never appended (range(1, len-1), modeling.py:458)."""
+    steps = sorted(steps, key=lambda x: x[0])
+    flat = [v for st in steps for v in st]
+    while flat[-1] > last_bound:
+        flat.pop(-1)
+    temp = sorted(set(flat))
+    out = [temp[0]]
+    cur = temp[0]
+    for i in range(1, len(temp) - 1):
+        if temp[i] - cur >= 5:
+            out.append(temp[i])
+            cur = temp[i]
+    return out
+
+
+def moment_segmentation(sd: SD, vis, text, asr, vis_mask, bounds, threshold: float = 0.5, max_iter: int = 20):
+    """test_moment_segmentation (modeling.py:353-474)."""
+    B, T = vis_mask.shape
+    starts, lasts = bounds[:, 0].tolist(), bounds[:, 1].tolist()
+    moment_mask = torch.zeros(B, T, dtype=torch.long)
+    boundary_mask = torch.zeros(B, T, dtype=torch.long)
+    steps = [[[starts[b], starts[b]]] for b in range(B)]
+    for b in range(B):
+        moment_mask[b, starts[b]:lasts[b] + 1] = 1
+        boundary_mask[b, starts[b]] = 1
+    first_logits = None
+    for it in range(max_iter):
+        feats = joint_features(sd, vis, text, asr, vis_mask, moment_mask, boundary_mask)
+        logits = head_logits(sd, feats, "segment_predictor")
+        if first_logits is None:
+            first_logits = logits.clone()
+        logits = logits.masked_fill(moment_mask == 0, -torch.finfo(logits.dtype).max)
+        probs = torch.softmax(logits, dim=1)
+        amax = probs.argmax(dim=1)
+        for b in range(B):
+            w = segmentation_walk(probs[b].tolist(), int(amax[b]), threshold)
+            if w is None:
+                continue
+            l, r = w
+            moment_mask[b, l:r + 1] = 0
+            boundary_mask[b, l] = 1
+            boundary_mask[b, r] = 1
+            steps[b].append([l, r])
+    out = []
+    for b in range(B):
+        steps[b].append([lasts[b], lasts[b]])
+        out.append(segmentation_postprocess(steps[b], lasts[b]))
+    return out, first_logits

@@ -213,6 +213,122 @@ def gen_eval():
     print("wrote retrieval_eval.json", res)
 
 
+
+def build_reference_moment_model():
+    """Construct the REAL reference MomentModel (modeling.py:18-129) with the offline work-arounds of
+    SURVEY 8c: stub the packages it imports but does not use on this path, skip the three file / network
+    loads in its constructor, and replace the 1.2 B-parameter EVA-CLIP build by a dummy (the joint model
+    only ever calls clip_model.encode_text, whose output the fixtures pass in as an explicit input)."""
+    d = tempfile.mkdtemp(prefix="hirest_stubs2_")
+    for mod, body in {"kornia": "", "boto3": "", "srt": "",
+                      "botocore/__init__": "", "botocore/exceptions": "class ClientError(Exception):\n    pass\n",
+                      "pycocoevalcap/__init__": "", "pycocoevalcap/bleu/__init__": "", "pycocoevalcap/bleu/bleu": "class Bleu:\n    pass\n",
+                      "pycocoevalcap/rouge/__init__": "", "pycocoevalcap/rouge/rouge": "class Rouge:\n    pass\n",
+                      "pycocoevalcap/cider/__init__": "", "pycocoevalcap/cider/cider": "class Cider:\n    pass\n",
+                      "pycocoevalcap/meteor/__init__": "", "pycocoevalcap/meteor/meteor": "class Meteor:\n    pass\n"}.items():
+        path = os.path.join(d, mod + ".py")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(body)
+    sys.path.insert(0, d)
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    sys.path.append(f"{REF}/clip4caption")
+    import modeling as ref_modeling
+    from modules import until_config, module_bert
+    import eva_clip as ref_eva_clip
+
+    class _Tok:
+        vocab = {"[PAD]": 0, "[UNK]": 100, "[CLS]": 101, "[SEP]": 102}
+
+        def convert_ids_to_tokens(self, ids):
+            return [str(i) for i in ids]
+    ref_modeling.BertTokenizer.from_pretrained = classmethod(lambda cls, *a, **k: _Tok())
+    orig_get_config = until_config.PretrainedConfig.get_config.__func__
+
+    def get_config(cls, name, cache_dir, type_vocab_size, state_dict, task_config=None):
+        if cls is module_bert.BertConfig:
+            return module_bert.BertConfig(30522, 768, 12, 12, 3072, max_position_embeddings=512, type_vocab_size=2), state_dict
+        return orig_get_config(cls, name, cache_dir, type_vocab_size, state_dict, task_config=task_config)
+    until_config.PretrainedConfig.get_config = classmethod(get_config)
+
+    class _DummyClip(torch.nn.Module):
+        def encode_text(self, ids):
+            raise RuntimeError("text features are passed explicitly in the fixtures")
+    ref_eva_clip.build_eva_model_and_transforms = lambda *a, **k: (_DummyClip(), None)
+    real_load = torch.load
+    torch.load = lambda *a, **k: None
+    try:
+        from args import get_parser
+        args = get_parser().parse_args(["--data_dir", "x", "--video_feature_dir", "x"])
+        torch.manual_seed(0)
+        model = ref_modeling.MomentModel(n_frames=-1, asr_dim=384, args=args)
+    finally:
+        torch.load = real_load
+    model.eval()
+    return model, args
+
+
+def joint_inputs(name, B, T, seed):
+    """C4-style synthetic batch: L2-normalised frame features, sparse ASR features, ragged lengths."""
+    vis = synth.tensor(f"{name}.vis", (B, T, 1024), 1.0, seed)
+    vis = vis / vis.norm(dim=-1, keepdim=True)
+    asr = synth.tensor(f"{name}.asr", (B, T, 384), 0.05, seed)
+    gaps = synth.uniform_pm1(f"{name}.gap", B * T, seed).reshape(B, T) > 0.2      # ~40 % all-zero rows
+    asr = asr * torch.from_numpy(~gaps).float()[..., None]
+    text = synth.tensor(f"{name}.text", (B, 1024), 1.0, seed)
+    lens = [T - (b * T) // (3 * B) for b in range(B)]                             # ragged
+    vis_mask = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate(lens):
+        vis_mask[b, :n] = 1
+        vis[b, n:] = 0
+        asr[b, n:] = 0
+    bounds = torch.tensor([[int(0.1 * n), int(0.8 * n)] for n in lens], dtype=torch.long)
+    moment_mask = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        moment_mask[b, bounds[b, 0]:bounds[b, 1] + 1] = 1
+    return vis, asr, text, vis_mask, moment_mask, bounds
+
+
+def gen_joint():
+    model, args = build_reference_moment_model()
+    names = [k for k in model.state_dict().keys() if not k.startswith("clip_model.")]
+    shapes = {k: tuple(model.state_dict()[k].shape) for k in names}
+    with open(os.path.join(HERE, "joint_schema.json"), "w") as f:
+        json.dump({k: list(v) for k, v in shapes.items()}, f)
+    sd = synth.joint_state_dict(shapes, 31)
+    print(model.load_state_dict(sd, strict=False))
+    n_train = sum(p.numel() for n, p in model.named_parameters() if not n.startswith("clip_model."))
+    print("joint params", n_train)
+    out = {"n_params": n_train}
+    for case, (B, T) in {"a": (3, 64), "b": (2, 300)}.items():
+        vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"joint.{case}", B, T, 41)
+        model.clip_model.encode_text = lambda ids, _t=text: _t          # explicit text features
+        ids = torch.zeros(B, 77, dtype=torch.long)
+        with torch.no_grad():
+            feats = model.foward_moment_shared(vis, text, vis_mask, moment_mask=moment_mask, asr_feats=asr)
+            mr = model.forward_moment_retrieval(vis, text, video_mask=vis_mask, moment_mask=moment_mask, asr_feats=asr)
+            batch = {"tasks": ["moment_retrieval"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask,
+                     "asr_feats": asr, "clip_text_ids": ids,
+                     "moment_retrieval_start_target": torch.zeros(B, dtype=torch.long),
+                     "moment_retrieval_end_target": torch.zeros(B, dtype=torch.long)}
+            pred_mr = model.test_step(batch)["prediction"]
+            bm0 = torch.zeros(B, T, dtype=torch.long)
+            for b in range(B):
+                bm0[b, bounds[b, 0]] = 1
+            seg0 = model.forward_moment_segmentation(vis, text, vis_mask, moment_mask, asr_feats=asr, boundary_mask=bm0)
+            batch = {"tasks": ["moment_segmentation"], "vis_feats": vis, "vis_mask": vis_mask, "asr_feats": asr,
+                     "clip_text_ids": ids, "moment_bound_frames": bounds}
+            res = model.test_step(batch)
+        rows = [0, 1, T // 2, T - 1]
+        out[case] = {"B": B, "T": T, "pred_moment_retrieval": pred_mr, "pred_segmentation": res["prediction"]}
+        save(f"joint_{case}.npz", feats_rows=np32(feats[:, rows]), rows=np.array(rows),
+             start_logits=np32(mr["start_logits"]), end_logits=np32(mr["end_logits"]), seg_logits_iter0=np32(seg0))
+    with open(os.path.join(HERE, "joint_predictions.json"), "w") as f:
+        json.dump(out, f)
+    print(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -230,6 +346,7 @@ def main():
         "eval": gen_eval,
         "openai_b32": lambda: gen_openai("openai_b32", synth.OPENAI_VIT_B32, 1, 64, 16, prompts=prompts),
         "eva_g14": lambda: gen_eva("eva_g14", synth.EVA_CLIP_G_14, 3, 2, 8),
+        "joint": gen_joint,
     }
     for name, fn in jobs.items():
         if args.only and name not in args.only:
