@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhirest_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "score.hip", "tower.hip", "profile.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "score.hip", "tower.hip", "profile.hip", "joint.hip"]
 ARCH = "gfx950"
 
 

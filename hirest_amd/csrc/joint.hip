@@ -1,0 +1,442 @@
+// Joint-model (MomentModel) kernels: the moment-retrieval / moment-segmentation heads of
+// /root/reference/modeling.py:155-474 over precomputed per-second frame features.
+//
+// Everything here is fp32 end to end.  The reference runs this model in fp32 and its outputs are frame
+// INDICES (argmax of start/end logits, the iterative threshold walk); bf16 operands would move logits by
+// ~1e-2 and flip near-ties, so this path uses the exact-fp32 matrix instructions
+// (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, 1/16 of the bf16 rate) — at 10-90 GFLOP per video the
+// whole model is still a few hundred microseconds.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+ resid[m][n]) (+ periodic[(m % period)][n])
+// 64x64 tile, 4 waves (2x2) of one 32x32 MFMA tile each, K staged 16 deep through padded LDS.
+// Operands are swapped (a = W, b = A) so a lane owns 4 consecutive columns of one row.
+// ---------------------------------------------------------------------------------------------
+struct GemmF {
+    const float* A; int64_t lda;
+    const float* W; int64_t ldw;
+    const float* bias;
+    const float* resid; int64_t ldr;
+    const float* periodic; int period;
+    float* out; int64_t ldo;
+    int M, N, K, act;   // act: 0 none, 1 gelu (erf), 2 tanh
+};
+
+constexpr int FK = 16, FLD = FK + 1;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
+    __shared__ float As[64 * FLD];
+    __shared__ float Ws[64 * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M0 = blockIdx.y * 64, N0 = blockIdx.x * 64;
+    // staging: thread -> (row = tid/4, 4 consecutive k = (tid%4)*4)
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    int gm = M0 + srow; gm = gm < p.M ? gm : p.M - 1;
+    int gn = N0 + srow; gn = gn < p.N ? gn : p.N - 1;
+    const float* ap = p.A + (int64_t)gm * p.lda + sk;
+    const float* wp = p.W + (int64_t)gn * p.ldw + sk;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int arow = (wm * 32 + (lane & 31)) * FLD + (lane >> 5);
+    const int wrow = (wn * 32 + (lane & 31)) * FLD + (lane >> 5);
+    for (int k0 = 0; k0 < p.K; k0 += FK) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k0);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + k0);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { As[srow * FLD + sk + e] = av[e]; Ws[srow * FLD + sk + e] = wv[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < FK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + kk], As[arow + kk], acc, 0, 0, 0);
+    }
+    const int m = M0 + wm * 32 + (lane & 31);
+    if (m >= p.M) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = N0 + wn * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= p.N) continue;
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        }
+        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+        if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
+        *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 flash attention, head dim 64, full (unmasked) attention over T keys with the reference's uniform
+// additive constant: s = fl(fl(q.k * scale) + add_const) (module_visual.py:164-176 with the all-zeros mask
+// of modeling.py:208 -> -10000 on every score, SURVEY hazard H3), softmax, @ v.
+// One wave per 32 queries; keys in tiles of 32 staged through LDS by the 4 waves of a block.
+//   S^T = K.Q^T   (lane = query, registers = keys)  -> softmax statistics are lane-local + one shuffle
+//   O^T = V^T.P^T  P is reused in place as the B operand: k-step r pairs key kap(r,0) (lanes < 32) with
+//                  kap(r,1) = kap(r,0)+4 (lanes >= 32), which is exactly what each half-wave holds in reg r.
+// ---------------------------------------------------------------------------------------------
+constexpr int ADH = 64, ALD = ADH + 1;
+
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           int T, int H, float scale, float add_const) {
+    __shared__ float Ks[32 * ALD];
+    __shared__ float Vs[32 * ALD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int qblocks = (T + 127) / 128;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
+    const int b = bh / H, h = bh - b * H;
+    const int D = H * ADH;
+    const int64_t ld = 3 * (int64_t)D;
+    const float* base = qkv + (int64_t)b * T * ld + h * ADH;
+    const int q = qb * 128 + wave * 32 + l31;
+    const bool qvalid = q < T;
+    // Q^T fragments: B operand [k = d][j = query]: lane holds Q[q][2s + half] for s = 0..31
+    float qf[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qf[s] = qvalid ? base[(int64_t)q * ld + 2 * s + half] : 0.f;
+    f32x16 o0, o1;   // O^T rows d = 0..31 and 32..63, column = query
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    float mrun = -3.0e38f, lrun = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * 16; i += 256) {   // 32 keys x 16 float4
+            const int kr = i >> 4, c = (i & 15) * 4;
+            const int key = k0 + kr < T ? k0 + kr : T - 1;
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + D + c);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + 2 * D + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { Ks[kr * ALD + c + e] = kv[e]; Vs[kr * ALD + c + e] = vv[e]; }
+        }
+        __syncthreads();
+        f32x16 st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)   // A operand: K[key = l31][d = 2s + half]
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * ALD + 2 * s + half], qf[s], st, 0, 0, 0);
+        float tmax = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float sv = st[r] * scale;
+            sv = sv + add_const;
+            sv = key < T ? sv : -3.0e38f;
+            st[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float pz = __expf(st[r] - mnew); st[r] = pz; psum += pz; }
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {   // k-step r: keys kap(r,0) | kap(r,1); A operand V^T[d = l31 (+32)][key]
+            const int kr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kr * ALD + l31], st[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kr * ALD + 32 + l31], st[r], o1, 0, 0, 0);
+        }
+    }
+    if (!qvalid) return;
+    const float inv = 1.0f / lrun;
+    float* orow = out + ((int64_t)b * T + q) * D + h * ADH;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {   // O^T rows (reg&3) + 8*(reg>>2) + 4*half = d
+        const int d = 8 * g + 4 * half;
+        *reinterpret_cast<f32x4*>(orow + d) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+        *reinterpret_cast<f32x4*>(orow + 32 + d) = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+    }
+}
+
+// base[b,t,:] = v[b,t,:] * tn[b,:] + asr[b,t,:] + temporal[b,t,:]     (loop-invariant part of modeling.py:167-195)
+__global__ __launch_bounds__(256) void joint_base_kernel(const float* __restrict__ v, const float* __restrict__ tproj,
+                                                        const float* __restrict__ asr, const float* __restrict__ temporal,
+                                                        float* __restrict__ base, int B, int T, int E) {
+    __shared__ float red[4];
+    __shared__ float inv_norm;
+    // one block per (b, chunk of rows); text L2 norm recomputed per block (E = 512: trivial)
+    const int b = blockIdx.y;
+    const float* tp = tproj + (int64_t)b * E;
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) ss += tp[e] * tp[e];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) inv_norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    const float nrm = inv_norm;
+    const int nv = E >> 2;
+    const int rows_per_block = 16;
+    const int t0 = blockIdx.x * rows_per_block;
+    for (int i = threadIdx.x; i < rows_per_block * nv; i += 256) {
+        const int t = t0 + i / nv, c = (i % nv) * 4;
+        if (t >= T) break;
+        const int64_t off = ((int64_t)b * T + t) * E + c;
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(v + off);
+        f32x4 tn = *reinterpret_cast<const f32x4*>(tp + c);
+        tn[0] /= nrm; tn[1] /= nrm; tn[2] /= nrm; tn[3] /= nrm;
+        f32x4 r = vv * tn;
+        r += *reinterpret_cast<const f32x4*>(asr + off);
+        r += *reinterpret_cast<const f32x4*>(temporal + off);
+        *reinterpret_cast<f32x4*>(base + off) = r;
+    }
+}
+
+// temporal input: tin[b,t,:] = tanh(time(b,t) * w1 + b1), time = (linspace(0,1,n_b)[t]-0.5)*2 for t < n_b else 0
+// (modeling.py:176-195; linspace(0,1,1) = [0]).  One thread per 4 channels.
+__global__ __launch_bounds__(256) void joint_time_kernel(const int32_t* __restrict__ n_valid, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, float* __restrict__ tin, int B, int T, int E) {
+    const int nv = E >> 2;
+    const int64_t total = (int64_t)B * T * nv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % nv) * 4;
+        const int64_t row = idx / nv;
+        const int t = (int)(row % T), b = (int)(row / T);
+        const int n = n_valid[b];
+        float tm = 0.f;
+        if (t < n) {
+            // torch.linspace(0, 1, n): step = 1/(n-1); values i*step for the first half, 1-(n-1-i)*step for the second
+            float lin;
+            if (n == 1) lin = 0.f;
+            else {
+                const float step = 1.0f / (float)(n - 1);
+                lin = t < n / 2 ? (float)t * step : 1.0f - (float)(n - 1 - t) * step;
+            }
+            tm = (lin - 0.5f) * 2.0f;
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = tanhf(tm * w1[c + e] + b1[c + e]);
+        *reinterpret_cast<f32x4*>(tin + row * E + c) = o;
+    }
+}
+
+// f[b,t,:] = base[b,t,:] (+ boundary_embed[bmask[b,t]]) + mask_embed[mmask[b,t]]    (modeling.py:171-173,197-198)
+__global__ __launch_bounds__(256) void joint_mask_add_kernel(const float* __restrict__ base, const int32_t* __restrict__ mmask,
+                                                            const int32_t* __restrict__ bmask, const float* __restrict__ mask_embed,
+                                                            const float* __restrict__ boundary_embed, float* __restrict__ f,
+                                                            int64_t rows, int E) {
+    const int nv = E >> 2;
+    const int64_t total = rows * nv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % nv) * 4;
+        const int64_t row = idx / nv;
+        f32x4 r = *reinterpret_cast<const f32x4*>(base + row * E + c);
+        if (bmask) r += *reinterpret_cast<const f32x4*>(boundary_embed + (int64_t)bmask[row] * E + c);
+        r += *reinterpret_cast<const f32x4*>(mask_embed + (int64_t)mmask[row] * E + c);
+        *reinterpret_cast<f32x4*>(f + row * E + c) = r;
+    }
+}
+
+// up to 3 Linear(D,1) heads: logits[h][row] = <x[row], w_h> + b_h  (modeling.py:218-219,319); one wave per row
+__global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x, int64_t rows, int D, int nheads,
+                                                   const float* __restrict__ w0, const float* __restrict__ w1,
+                                                   const float* __restrict__ w2, const float* __restrict__ bias3,
+                                                   float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + c);
+        s0 += xv[0] * a[0] + xv[1] * a[1] + xv[2] * a[2] + xv[3] * a[3];
+        if (nheads > 1) { const f32x4 bq = *reinterpret_cast<const f32x4*>(w1 + c); s1 += xv[0] * bq[0] + xv[1] * bq[1] + xv[2] * bq[2] + xv[3] * bq[3]; }
+        if (nheads > 2) { const f32x4 cq = *reinterpret_cast<const f32x4*>(w2 + c); s2 += xv[0] * cq[0] + xv[1] * cq[1] + xv[2] * cq[2] + xv[3] * cq[3]; }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        logits[row] = s0 + bias3[0];
+        if (nheads > 1) logits[rows + row] = s1 + bias3[1];
+        if (nheads > 2) logits[2 * rows + row] = s2 + bias3[2];
+    }
+}
+
+// per-sample masked argmax: out[b] = argmax_t (mask[b,t] ? logits[b,t] : fill)   (modeling.py:294-298), first maximum
+__global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restrict__ logits, const int32_t* __restrict__ mask,
+                                                           float fill, int T, int32_t* __restrict__ out) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int t = tid; t < T; t += 256) {
+        const float v = mask[(int64_t)b * T + t] ? logits[(int64_t)b * T + t] : fill;
+        if (v > best || (v == best && t < bi)) { best = v; bi = t; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+        out[b] = bi;
+    }
+}
+
+// One iteration of the segmentation loop for every sample (modeling.py:393-433), entirely on device:
+// masked softmax over T, argmax, threshold walk (Python-float = double arithmetic, like scores.tolist()),
+// zero moment_mask[l..r], set boundary_mask[l] and [r], append [l,r] to the sample's step list.
+__global__ __launch_bounds__(256) void segmentation_step_kernel(const float* __restrict__ logits, int32_t* __restrict__ mmask,
+                                                               int32_t* __restrict__ bmask, int T, double threshold,
+                                                               int32_t* __restrict__ steps, int32_t* __restrict__ nsteps,
+                                                               int max_steps, float* __restrict__ probs_out) {
+    extern __shared__ float pr[];     // [T] probabilities
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    __shared__ float s_max, s_sum;
+    __shared__ int s_arg;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* mm = mmask + (int64_t)b * T;
+    int32_t* bm = bmask + (int64_t)b * T;
+    const float NEG = -3.4028234663852886e38f;   // -finfo(float32).max
+    float mx = -INFINITY;
+    for (int t = tid; t < T; t += 256) {
+        const float v = mm[t] ? logits[(int64_t)b * T + t] : NEG;
+        pr[t] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) s_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    mx = s_max;
+    float sum = 0.f;
+    for (int t = tid; t < T; t += 256) { const float e = expf(pr[t] - mx); pr[t] = e; sum += e; }
+    sum = wave_sum(sum);
+    __syncthreads();
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (tid == 0) s_sum = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const float tot = s_sum;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int t = tid; t < T; t += 256) {
+        const float pz = pr[t] / tot;
+        pr[t] = pz;
+        if (probs_out) probs_out[(int64_t)b * T + t] = pz;
+        if (pz > best || (pz == best && t < bi)) { best = pz; bi = t; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { red[wave] = best; redi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (red[w] > best || (red[w] == best && redi[w] < bi)) { best = red[w]; bi = redi[w]; }
+        s_arg = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int max_idx = s_arg;
+        const double max_score = (double)pr[max_idx];
+        if (!(max_score < 0.00001)) {
+            int left = max_idx, right = max_idx;
+            while (((double)pr[left] / max_score) > threshold) { if (left == 0) break; --left; }
+            while (((double)pr[right] / max_score) > threshold) { if (right == T - 1) break; ++right; }
+            if (!(left == 0 || right == 0)) {
+                for (int t = left; t <= right; ++t) mm[t] = 0;
+                bm[left] = 1; bm[right] = 1;
+                const int n = nsteps[b];
+                if (n < max_steps) { steps[((int64_t)b * max_steps + n) * 2] = left; steps[((int64_t)b * max_steps + n) * 2 + 1] = right; nsteps[b] = n + 1; }
+            }
+        }
+    }
+}
+
+inline int grid1d(int64_t total, int cap = 4096) { int64_t g = (total + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
+
+}  // namespace
+
+extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                               const float* resid, int64_t ldr, const float* periodic, int32_t period,
+                               float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return HIREST_E_BADARG;
+    if (K % FK != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
+    GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,
+                                    float scale, float add_const, void* stream) {
+    if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh != ADH) return HIREST_E_SHAPE;
+    const int qblocks = (T + 127) / 128;
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, out, T, H,
+                       scale, add_const);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_joint_time_features(const int32_t* n_valid, const float* w1, const float* b1, float* tin, int32_t B,
+                                          int32_t T, int32_t E, void* stream) {
+    if (!n_valid || !w1 || !b1 || !tin || B <= 0 || T <= 0 || E % 4 != 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(joint_time_kernel, dim3(grid1d((int64_t)B * T * (E / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       n_valid, w1, b1, tin, B, T, E);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_joint_base(const float* v, const float* text_proj, const float* asr, const float* temporal, float* base,
+                                 int32_t B, int32_t T, int32_t E, void* stream) {
+    if (!v || !text_proj || !asr || !temporal || !base || B <= 0 || T <= 0 || E % 4 != 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(joint_base_kernel, dim3((T + 15) / 16, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), v, text_proj,
+                       asr, temporal, base, B, T, E);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_joint_mask_add(const float* base, const int32_t* moment_mask, const int32_t* boundary_mask,
+                                     const float* mask_embed, const float* boundary_embed, float* f, int64_t rows, int32_t E,
+                                     void* stream) {
+    if (!base || !moment_mask || !mask_embed || !f || rows <= 0 || E % 4 != 0) return HIREST_E_BADARG;
+    if (boundary_mask && !boundary_embed) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(joint_mask_add_kernel, dim3(grid1d(rows * (E / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), base,
+                       moment_mask, boundary_mask, mask_embed, boundary_embed, f, rows, E);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_linear_heads(const float* x, int64_t rows, int32_t D, int32_t nheads, const float* w0, const float* w1,
+                                   const float* w2, const float* bias3, float* logits, void* stream) {
+    if (!x || !w0 || !bias3 || !logits || rows <= 0 || nheads < 1 || nheads > 3 || D % 4 != 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(heads_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, rows, D,
+                       nheads, w0, w1 ? w1 : w0, w2 ? w2 : w0, bias3, logits);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_masked_argmax(const float* logits, const int32_t* mask, float fill, int32_t B, int32_t T, int32_t* out,
+                                    void* stream) {
+    if (!logits || !mask || !out || B <= 0 || T <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(masked_argmax_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, mask, fill, T, out);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_segmentation_step(const float* logits, int32_t* moment_mask, int32_t* boundary_mask, int32_t B, int32_t T,
+                                        double threshold, int32_t* steps, int32_t* nsteps, int32_t max_steps, float* probs_out,
+                                        void* stream) {
+    if (!logits || !moment_mask || !boundary_mask || !steps || !nsteps || B <= 0 || T <= 0 || T > 16384) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(segmentation_step_kernel, dim3(B), dim3(256), T * sizeof(float), reinterpret_cast<hipStream_t>(stream), logits,
+                       moment_mask, boundary_mask, T, threshold, steps, nsteps, max_steps, probs_out);
+    return hirest_launch_status();
+}

@@ -1,0 +1,321 @@
+"""Drop-in for the inference side of the reference's joint model, ``MomentModel.test_step``
+(/root/reference/modeling.py:141-153): moment retrieval (modeling.py:272-310) and iterative moment
+segmentation (modeling.py:353-474) over precomputed 1-fps EVA-CLIP frame features + ASR features.
+
+Same constructor arguments, batch dict keys (hirest_dataset.py:409-531: ``tasks``, ``vis_feats``,
+``vis_mask``, ``moment_mask``, ``asr_feats``, ``clip_text_ids``, ``moment_bound_frames``) and result dict
+(``prediction`` / ``raw_predictions``) as the reference; the parameter tree reproduces the reference's
+state-dict keys (``clip_g_map``, ``asr_enc_layer.{0,1}``, ``temporal_embed.{0,2}``, ``mask_embed``,
+``boundary_embed``, ``{start,end,segment}_predictor.0``, ``clip4cap_model.visual.*`` ...), so a reference
+``BEST.pth`` loads with ``load_state_dict(strict=False)`` exactly as ``trainer_base.py:128-147`` does.
+
+All math runs in the fp32 kernels of csrc/joint.hip (+ the LayerNorm kernel).  What differs from the
+reference is where time goes: the 20 segmentation iterations run back to back on the device —
+masks, softmax, arg-max, threshold walk and step list are device state, with ONE device->host copy at the
+end instead of B x 20 ``.cpu().tolist()`` syncs — and the loop-invariant part of the fusion is hoisted.
+Step captioning (modeling.py:556-632) is not implemented here yet and raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from copy import deepcopy
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _p(*shape):
+    return nn.Parameter(torch.zeros(*shape))
+
+
+class _Lin(nn.Module):
+    def __init__(self, out_f, in_f):
+        super().__init__()
+        self.weight, self.bias = _p(out_f, in_f), _p(out_f)
+
+
+class _LN(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight, self.bias = _p(d), _p(d)
+
+
+class _Emb(nn.Module):
+    def __init__(self, n, d):
+        super().__init__()
+        self.weight = _p(n, d)
+
+
+def _seq(**mods):
+    m = nn.Module()
+    for k, v in mods.items():
+        m.add_module(k, v)
+    return m
+
+
+class MomentModel(nn.Module):
+    """modeling.py:18-129 (inference subset).  ``clip_model`` may be a hirest_amd.EVA_CLIP (its
+    ``encode_text`` is what test_step calls, modeling.py:286,364) or None when text features are fed
+    through ``batch['text_feat']`` (the commented-out alternative at modeling.py:284)."""
+
+    def __init__(self, n_frames=-1, asr_dim=-1, args=None, clip_model=None, max_position_embeddings=2048):
+        super().__init__()
+        self.args, self.n_frames, self.asr_dim = args, n_frames, asr_dim
+        self.use_asr = asr_dim > 0
+        E, H = 512, 768
+        if self.use_asr:
+            self.asr_enc_layer = _seq(**{"0": _LN(asr_dim), "1": _Lin(E, asr_dim)})
+        self.temporal_embed = _seq(**{"0": _Lin(E, 1), "2": _Lin(E, E)})
+        self.mask_embed, self.boundary_embed = _Emb(2, E), _Emb(2, E)
+        self.start_predictor = _seq(**{"0": _Lin(1, H)})
+        self.end_predictor = _seq(**{"0": _Lin(1, H)})
+        self.segment_predictor = _seq(**{"0": _Lin(1, H)})
+        vis = nn.Module()
+        vis.embeddings = _seq(word_embeddings=_Lin(H, E), position_embeddings=_Emb(max_position_embeddings, H), LayerNorm=_LN(H))
+        layers = []
+        for _ in range(getattr(args, "visual_num_hidden_layers", 2) if args is not None else 2):
+            lay = nn.Module()
+            lay.attention = nn.Module()
+            lay.attention.self = _seq(query=_Lin(H, H), key=_Lin(H, H), value=_Lin(H, H))
+            lay.attention.output = _seq(dense=_Lin(H, H), LayerNorm=_LN(H))
+            lay.intermediate = _seq(dense=_Lin(4 * H, H))
+            lay.output = _seq(dense=_Lin(H, 4 * H), LayerNorm=_LN(H))
+            layers.append(lay)
+        vis.encoder = nn.Module()
+        vis.encoder.layer = nn.ModuleList(layers)
+        self.clip4cap_model = nn.Module()
+        self.clip4cap_model.visual = vis
+        self.clip4cap_model.normalize_video = _seq(visual_norm2d=_LN(E))
+        self.clip_g_map, self.clip_g_map_text = _Lin(E, 1024), _Lin(E, 1024)
+        self.clip_model = clip_model
+        self.heads = 12
+        self._cache = None
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _apply(self, fn, *a, **k):
+        self._cache = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._cache = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def freeze_clip(self):   # modeling.py:126-129
+        if self.clip_model is not None:
+            for p in self.clip_model.parameters():
+                p.requires_grad = False
+            self.clip_model.eval()
+
+    def _w(self):
+        """fp32 contiguous device views + fused QKV weights, built once per parameter version."""
+        if self._cache is not None:
+            return self._cache
+        dev = self.clip_g_map.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("hirest_amd.MomentModel runs on MI355X only (no CPU fallback); move the model to a GPU")
+        f = lambda t: t.detach().float().contiguous()
+        c = {"dev": dev}
+        for name, prm in self.named_parameters():
+            if not name.startswith("clip_model."):
+                c[name] = f(prm)
+        for i, lay in enumerate(self.clip4cap_model.visual.encoder.layer):
+            s = lay.attention.self
+            c[f"qkv_w.{i}"] = torch.cat([f(s.query.weight), f(s.key.weight), f(s.value.weight)], 0).contiguous()
+            c[f"qkv_b.{i}"] = torch.cat([f(s.query.bias), f(s.key.bias), f(s.value.bias)], 0).contiguous()
+        c["head_bias"] = torch.cat([f(getattr(m, "0").bias) for m in
+                                    (self.start_predictor, self.end_predictor, self.segment_predictor)]).contiguous()
+        self._cache = c
+        return c
+
+    # ------------------------------------------------------------------ kernels
+    @staticmethod
+    def _gemm(a, w, bias, out=None, resid=None, periodic=None, period=0, act=0):
+        lib = _lib.load()
+        M, K = a.shape
+        N = w.shape[0]
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _lib.check(lib.hirest_gemm_f32(a.data_ptr(), K, w.data_ptr(), w.shape[1], bias.data_ptr() if bias is not None else None,
+                                       resid.data_ptr() if resid is not None else None, N,
+                                       periodic.data_ptr() if periodic is not None else None, period,
+                                       out.data_ptr(), N, M, N, K, act, ops.stream_ptr()), "hirest_gemm_f32")
+        return out
+
+    @staticmethod
+    def _ln(x, w, b, eps):
+        out = torch.empty_like(x)
+        return ops.layernorm(x, w, b, eps, out)
+
+    def _encoder(self, f2d: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """VisualModel.forward (module_visual.py:396-424): embeddings + 2 post-LN layers, fp32."""
+        c, lib = self._w(), _lib.load()
+        V = "clip4cap_model.visual."
+        x = self._gemm(f2d, c[V + "embeddings.word_embeddings.weight"], c[V + "embeddings.word_embeddings.bias"],
+                       periodic=c[V + "embeddings.position_embeddings.weight"], period=T)
+        x = self._ln(x, c[V + "embeddings.LayerNorm.weight"], c[V + "embeddings.LayerNorm.bias"], 1e-12)
+        D = x.shape[1]
+        for i in range(len(self.clip4cap_model.visual.encoder.layer)):
+            p = V + f"encoder.layer.{i}."
+            qkv = self._gemm(x, c[f"qkv_w.{i}"], c[f"qkv_b.{i}"])
+            ctx = torch.empty_like(x)
+            _lib.check(lib.hirest_attention_f32(qkv.data_ptr(), ctx.data_ptr(), B, T, self.heads, D // self.heads,
+                                                (D // self.heads) ** -0.5, -10000.0, ops.stream_ptr()), "hirest_attention_f32")
+            a = self._gemm(ctx, c[p + "attention.output.dense.weight"], c[p + "attention.output.dense.bias"], resid=x)
+            a = self._ln(a, c[p + "attention.output.LayerNorm.weight"], c[p + "attention.output.LayerNorm.bias"], 1e-12)
+            h = self._gemm(a, c[p + "intermediate.dense.weight"], c[p + "intermediate.dense.bias"], act=1)
+            y = self._gemm(h, c[p + "output.dense.weight"], c[p + "output.dense.bias"], resid=a)
+            x = self._ln(y, c[p + "output.LayerNorm.weight"], c[p + "output.LayerNorm.bias"], 1e-12)
+        return x
+
+    def _fusion_base(self, vis, text, asr, vis_mask) -> torch.Tensor:
+        """Loop-invariant part of foward_moment_shared (modeling.py:158-195): v*t + asr + temporal."""
+        c, lib = self._w(), _lib.load()
+        B, T, _ = vis.shape
+        E = 512
+        v = self._gemm(vis.reshape(B * T, -1), c["clip_g_map.weight"], c["clip_g_map.bias"])
+        v = self._ln(v, c["clip4cap_model.normalize_video.visual_norm2d.weight"],
+                     c["clip4cap_model.normalize_video.visual_norm2d.bias"], 1e-12)
+        tproj = self._gemm(text, c["clip_g_map_text.weight"], c["clip_g_map_text.bias"])
+        if self.use_asr:
+            a = self._ln(asr.reshape(B * T, -1).contiguous(), c["asr_enc_layer.0.weight"], c["asr_enc_layer.0.bias"], 1e-5)
+            a = self._gemm(a, c["asr_enc_layer.1.weight"], c["asr_enc_layer.1.bias"])
+        else:
+            a = torch.zeros((B * T, E), dtype=torch.float32, device=vis.device)
+        n_valid = vis_mask.sum(dim=-1).to(torch.int32).contiguous()
+        tin = torch.empty((B * T, E), dtype=torch.float32, device=vis.device)
+        _lib.check(lib.hirest_joint_time_features(n_valid.data_ptr(), c["temporal_embed.0.weight"].data_ptr(),
+                                                  c["temporal_embed.0.bias"].data_ptr(), tin.data_ptr(), B, T, E,
+                                                  ops.stream_ptr()), "hirest_joint_time_features")
+        temporal = self._gemm(tin, c["temporal_embed.2.weight"], c["temporal_embed.2.bias"])
+        base = torch.empty((B * T, E), dtype=torch.float32, device=vis.device)
+        _lib.check(lib.hirest_joint_base(v.data_ptr(), tproj.data_ptr(), a.data_ptr(), temporal.data_ptr(), base.data_ptr(),
+                                         B, T, E, ops.stream_ptr()), "hirest_joint_base")
+        return base
+
+    def _features(self, base, moment_mask_i32, boundary_mask_i32, B, T) -> torch.Tensor:
+        c, lib = self._w(), _lib.load()
+        f = torch.empty_like(base)
+        _lib.check(lib.hirest_joint_mask_add(base.data_ptr(), moment_mask_i32.data_ptr(),
+                                             boundary_mask_i32.data_ptr() if boundary_mask_i32 is not None else None,
+                                             c["mask_embed.weight"].data_ptr(), c["boundary_embed.weight"].data_ptr(),
+                                             f.data_ptr(), B * T, 512, ops.stream_ptr()), "hirest_joint_mask_add")
+        return self._encoder(f, B, T)
+
+    def _heads(self, feats, which: List[str]) -> torch.Tensor:
+        c, lib = self._w(), _lib.load()
+        rows, D = feats.shape
+        names = {"start": ("start_predictor.0.weight", 0), "end": ("end_predictor.0.weight", 1), "segment": ("segment_predictor.0.weight", 2)}
+        ws = [c[names[w][0]] for w in which]
+        bias3 = torch.stack([c["head_bias"][names[w][1]] for w in which]).contiguous()
+        bias3 = torch.cat([bias3, torch.zeros(3 - len(which), device=bias3.device)]).contiguous()
+        logits = torch.empty((len(which), rows), dtype=torch.float32, device=feats.device)
+        _lib.check(lib.hirest_linear_heads(feats.data_ptr(), rows, D, len(which), ws[0].data_ptr(),
+                                           ws[1].data_ptr() if len(ws) > 1 else None, ws[2].data_ptr() if len(ws) > 2 else None,
+                                           bias3.data_ptr(), logits.data_ptr(), ops.stream_ptr()), "hirest_linear_heads")
+        return logits
+
+    # ------------------------------------------------------------------ reference interface
+    def _text_feat(self, batch, device):
+        if "text_feat" in batch:
+            return batch["text_feat"].to(device).float().contiguous()
+        if self.clip_model is None:
+            raise RuntimeError("MomentModel needs clip_model (encode_text) or batch['text_feat']")
+        return self.clip_model.encode_text(batch["clip_text_ids"].to(device)).float().contiguous()
+
+    def test_step(self, batch, **kwargs):
+        task = batch["tasks"][0]
+        if task == "moment_retrieval":
+            return self.test_moment_retrieval(batch, **kwargs)
+        elif task == "moment_segmentation":
+            return self.test_moment_segmentation(batch, **kwargs)
+        elif task == "step_captioning":
+            raise NotImplementedError("step_captioning is not implemented in hirest_amd yet")
+        else:
+            raise NotImplementedError
+
+    def train_step(self, batch):
+        raise NotImplementedError("hirest_amd.MomentModel is inference-only (training is out of scope, SURVEY 2.1 #9)")
+
+    @torch.no_grad()
+    def forward_moment_retrieval(self, video_feats, text_feat, video_mask=None, moment_mask=None, asr_feats=None):
+        """modeling.py:212-224: returns {'start_logits','end_logits'} [B,T] (fp32, unmasked)."""
+        B, T, _ = video_feats.shape
+        video_feats = video_feats.float().contiguous()
+        if video_mask is None:
+            video_mask = torch.ones((B, T), dtype=torch.long, device=video_feats.device)
+        base = self._fusion_base(video_feats, text_feat, asr_feats.float().contiguous() if asr_feats is not None else None, video_mask)
+        feats = self._features(base, moment_mask.to(torch.int32).contiguous(), None, B, T)
+        lg = self._heads(feats, ["start", "end"])
+        return {"start_logits": lg[0].reshape(B, T), "end_logits": lg[1].reshape(B, T), "feats": feats.reshape(B, T, -1)}
+
+    @torch.no_grad()
+    def test_moment_retrieval(self, batch, **kwargs):
+        lib = _lib.load()
+        dev = self._w()["dev"]
+        vis, vmask, mmask = batch["vis_feats"].to(dev), batch["vis_mask"].to(dev), batch["moment_mask"].to(dev)
+        asr = batch["asr_feats"].to(dev) if self.use_asr else None
+        out = self.forward_moment_retrieval(vis, self._text_feat(batch, dev), vmask, mmask, asr)
+        B, T = vmask.shape
+        m32 = vmask.to(torch.int32).contiguous()
+        pred = torch.empty((2, B), dtype=torch.int32, device=dev)
+        for i, k in enumerate(("start_logits", "end_logits")):
+            _lib.check(lib.hirest_masked_argmax(out[k].contiguous().data_ptr(), m32.data_ptr(), -1e10, B, T,
+                                                pred[i].data_ptr(), ops.stream_ptr()), "hirest_masked_argmax")
+        return {"prediction": pred.t().cpu().tolist()}
+
+    @torch.no_grad()
+    def test_moment_segmentation(self, batch, threshold=0.15, return_trace=False, **kwargs):
+        lib = _lib.load()
+        dev = self._w()["dev"]
+        vis, vmask = batch["vis_feats"].to(dev).float().contiguous(), batch["vis_mask"].to(dev)
+        asr = batch["asr_feats"].to(dev).float().contiguous() if self.use_asr else None
+        text = self._text_feat(batch, dev)
+        B, T = vmask.shape
+        starts = batch["moment_bound_frames"][:, 0].tolist()
+        lasts = batch["moment_bound_frames"][:, 1].tolist()
+        mm = torch.zeros((B, T), dtype=torch.int32)
+        bm = torch.zeros((B, T), dtype=torch.int32)
+        for b in range(B):
+            mm[b, starts[b]:lasts[b] + 1] = 1
+            bm[b, starts[b]] = 1
+        mm, bm = mm.to(dev), bm.to(dev)
+        thr = float(getattr(self.args, "moment_segmentation_difference_threshold", 0.5)) if self.args is not None else 0.5
+        iters = int(getattr(self.args, "moment_segmentation_max_iterations", 20)) if self.args is not None else 20
+        steps = torch.zeros((B, iters, 2), dtype=torch.int32, device=dev)
+        nsteps = torch.zeros((B,), dtype=torch.int32, device=dev)
+        base = self._fusion_base(vis, text, asr, vmask)
+        first_logits = None
+        for it in range(iters):                                   # no host sync inside the loop
+            feats = self._features(base, mm, bm, B, T)
+            logits = self._heads(feats, ["segment"])[0].contiguous()
+            if it == 0 and return_trace:
+                first_logits = logits.reshape(B, T).clone()
+            _lib.check(lib.hirest_segmentation_step(logits.data_ptr(), mm.data_ptr(), bm.data_ptr(), B, T, thr,
+                                                    steps.data_ptr(), nsteps.data_ptr(), iters, None, ops.stream_ptr()),
+                       "hirest_segmentation_step")
+        steps_h, n_h = steps.cpu().tolist(), nsteps.cpu().tolist()    # the only device->host copy
+        preds = []
+        for b in range(B):                                         # modeling.py:435-463, pure Python ints
+            sp = [[starts[b], starts[b]]] + [list(s) for s in steps_h[b][:n_h[b]]] + [[lasts[b], lasts[b]]]
+            sp.sort(key=lambda x: x[0])
+            flat = [v for s in sp for v in s]
+            while flat[-1] > lasts[b]:
+                flat.pop(-1)
+            temp = sorted(set(flat))
+            keep, cur = [temp[0]], temp[0]
+            for i in range(1, len(temp) - 1):
+                if temp[i] - cur >= 5:
+                    keep.append(temp[i])
+                    cur = temp[i]
+            preds.append(keep)
+        res = {"raw_predictions": deepcopy(preds), "prediction": preds}
+        if return_trace:
+            res["first_logits"] = first_logits
+        return res

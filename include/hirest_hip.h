@@ -196,6 +196,42 @@ int hirest_text_forward(const hirest_text_tower* t, const int64_t* tokens, int32
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Joint model (MomentModel) path — fp32 end to end, because its outputs are frame INDICES
+ * (modeling.py:155-474; clip4caption/modules/module_visual.py:104-264,396-424).
+ * ------------------------------------------------------------------------------------ */
+/* out = act(A @ W^T + bias) (+ resid) (+ periodic[m % period]) in exact fp32 (k-ordered fmaf chain on
+ * v_mfma_f32_32x32x2_f32).  act: 0 none, 1 gelu(erf), 2 tanh.  K % 16 == 0, N % 4 == 0.
+ * Replaces the nn.Linear layers of the fusion, VisualEmbeddings (periodic = position embeddings),
+ * VisualSelfOutput / VisualOutput (resid = the residual that precedes the post-LayerNorm). */
+int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                    const float* resid, int64_t ldr, const float* periodic, int32_t period,
+                    float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+/* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*64]; no key masking (the
+ * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3). */
+int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,
+                         float scale, float add_const, void* stream);
+/* tin[b,t,:] = tanh(time(b,t)*w1 + b1), time = (linspace(0,1,n_valid[b])[t]-0.5)*2, 0 past n_valid (modeling.py:176-195) */
+int hirest_joint_time_features(const int32_t* n_valid, const float* w1, const float* b1, float* tin,
+                               int32_t B, int32_t T, int32_t E, void* stream);
+/* base = v * (text_proj/||text_proj||)[:,None,:] + asr + temporal   (modeling.py:163-195, loop invariant) */
+int hirest_joint_base(const float* v, const float* text_proj, const float* asr, const float* temporal, float* base,
+                      int32_t B, int32_t T, int32_t E, void* stream);
+/* f = base (+ boundary_embed[boundary_mask]) + mask_embed[moment_mask]   (modeling.py:171-173,197-198) */
+int hirest_joint_mask_add(const float* base, const int32_t* moment_mask, const int32_t* boundary_mask,
+                          const float* mask_embed, const float* boundary_embed, float* f, int64_t rows, int32_t E,
+                          void* stream);
+/* up to three Linear(D,1) heads: logits[h*rows + r] = <x[r], w_h> + bias3[h] */
+int hirest_linear_heads(const float* x, int64_t rows, int32_t D, int32_t nheads, const float* w0, const float* w1,
+                        const float* w2, const float* bias3, float* logits, void* stream);
+/* out[b] = argmax_t (mask[b,t] ? logits[b,t] : fill), first maximum (modeling.py:294-298) */
+int hirest_masked_argmax(const float* logits, const int32_t* mask, float fill, int32_t B, int32_t T, int32_t* out,
+                         void* stream);
+/* one iteration of test_moment_segmentation's loop body for all samples, on device (modeling.py:393-433) */
+int hirest_segmentation_step(const float* logits, int32_t* moment_mask, int32_t* boundary_mask, int32_t B, int32_t T,
+                             double threshold, int32_t* steps, int32_t* nsteps, int32_t max_steps, float* probs_out,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Optional per-launch timing (bench.py's live roofline measurement).  When enabled, every
  * GEMM / attention / LayerNorm launch is bracketed by hipEventRecord on ITS launch stream;
  * hirest_profile_collect synchronises those events and returns one record per launch.

@@ -1,0 +1,98 @@
+"""GPU parity of the joint-model path (BASELINE configs[3]): fp32 kernels of csrc/joint.hip through the
+C ABI vs fp64 references, and hirest_amd.MomentModel.test_step vs the REAL reference MomentModel's outputs
+(tests/golden/joint_*.npz, joint_predictions.json).  Boundary indices / boundary lists must be exact."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from hirest_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("M,N,K,act", [(64, 64, 16, 0), (193, 768, 768, 1), (300, 2304, 768, 0), (77, 512, 1024, 2), (130, 768, 3072, 0)])
+def test_gemm_f32(dev, M, N, K, act):
+    from hirest_amd.moment_model import MomentModel
+    a = synth.tensor("jf.a", (M, K), 1.0, 1)
+    w = synth.tensor("jf.w", (N, K), 0.05, 1)
+    b = synth.tensor("jf.b", (N,), 0.3, 1)
+    r = synth.tensor("jf.r", (M, N), 1.0, 1)
+    pos = synth.tensor("jf.p", (50, N), 0.5, 1)
+    ref = a.double() @ w.double().t() + b.double()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.tanh(ref)
+    ref = ref + r.double() + pos.double()[torch.arange(M) % 50]
+    out = MomentModel._gemm(a.to(dev), w.to(dev), b.to(dev), resid=r.to(dev), periodic=pos.to(dev), period=50, act=act)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 64, 12), (1, 300, 12), (1, 33, 2), (1, 700, 3)])
+def test_attention_f32_with_constant_shift(dev, B, T, H):
+    from hirest_amd import _lib, ops
+    D = H * 64
+    qkv = synth.tensor(f"ja.{T}", (B * T, 3 * D), 1.0, 2)
+    q, k, v = qkv.reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s32 = (q @ k.transpose(-1, -2)) / 8.0 + (-10000.0)          # fp32 on purpose: the shift quantises (hazard H3)
+    ref = (torch.softmax(s32.double(), -1) @ v.double()).transpose(1, 2).reshape(B * T, D)
+    out = torch.empty((B * T, D), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().hirest_attention_f32(qkv.to(dev).data_ptr(), out.data_ptr(), B, T, H, 64, 0.125, -10000.0,
+                                                ops.stream_ptr()), "attention_f32")
+    # q.k summation order differs from torch's by ~1e-6, which the 9.8e-4 quantisation can turn into one ulp(1e4)
+    # on isolated scores: bound = a few 1e-3 relative on the probabilities
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-3 * v.abs().max().item()
+
+
+def _case(golden_dir, case):
+    sys.path.insert(0, golden_dir)
+    from make_golden import joint_inputs
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    pred = json.load(open(os.path.join(golden_dir, "joint_predictions.json")))[case]
+    g = np.load(os.path.join(golden_dir, f"joint_{case}.npz"))
+    return shapes, pred, g, joint_inputs(f"joint.{case}", pred["B"], pred["T"], 41)
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_moment_model_vs_reference(dev, golden_dir, case):
+    import hirest_amd
+    shapes, pred, g, (vis, asr, text, vis_mask, moment_mask, bounds) = _case(golden_dir, case)
+    sd = synth.joint_state_dict(shapes, 31)
+
+    class Args:
+        visual_num_hidden_layers = 2
+        moment_segmentation_difference_threshold = 0.5
+        moment_segmentation_max_iterations = 20
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=Args())
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.missing_keys                                   # every parameter we own is in the reference schema
+    model = model.to(dev).eval()
+    B, T = pred["B"], pred["T"]
+    out = model.forward_moment_retrieval(vis.to(dev), text.to(dev), vis_mask.to(dev), moment_mask.to(dev), asr.to(dev))
+    rows = list(g["rows"])
+    fr = out["feats"][:, rows].cpu().numpy()
+    assert np.abs(fr - g["feats_rows"]).max() / np.abs(g["feats_rows"]).max() < 1e-3
+    valid = vis_mask.numpy() == 1
+    assert np.abs(out["start_logits"].cpu().numpy() - g["start_logits"])[valid].max() < 2e-3
+    assert np.abs(out["end_logits"].cpu().numpy() - g["end_logits"])[valid].max() < 2e-3
+    batch = {"tasks": ["moment_retrieval"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask,
+             "asr_feats": asr, "text_feat": text}
+    assert model.test_step(batch)["prediction"] == pred["pred_moment_retrieval"]       # exact frame indices
+    batch = {"tasks": ["moment_segmentation"], "vis_feats": vis, "vis_mask": vis_mask, "asr_feats": asr,
+             "text_feat": text, "moment_bound_frames": bounds}
+    res = model.test_step(batch, return_trace=True)
+    assert np.abs(res["first_logits"].cpu().numpy() - g["seg_logits_iter0"]).max() < 2e-3
+    assert res["prediction"] == pred["pred_segmentation"]                               # exact boundary lists (IoU 1.0)
+    with pytest.raises(NotImplementedError):
+        model.test_step({"tasks": ["something_else"]})
