@@ -1,0 +1,59 @@
+"""BASELINE configs[2] in miniature: the full video-retrieval data path on the GPU (encode frames -> mean-pool
++ L2 -> score 'queries' -> top-k) against the CPU oracle on the same corpus.  Ground truth is defined as in
+SURVEY 8d: GT(q) = the oracle's top-1 video; 'matched R@k' = fraction of queries whose GT is in the GPU top-k."""
+import numpy as np
+import pytest
+import torch
+
+from hirest_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_retrieval_matched_recall_and_shard_invariance():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import hirest_amd
+    from hirest_amd import retrieval
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    cfg, seed = synth.EVA_CLIP_TINY, 11
+    V, F, Q = 40, 4, 24
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}")
+    model = model.to(dev).eval()
+    sd = synth.eva_clip_state_dict(cfg, seed)
+    # video v's frames = base_v + 0.1 * noise_f (a non-degenerate corpus)
+    base = synth.frames("ret.base", (V, 1, 3, 224, 224), 5)
+    frames = base + 0.1 * synth.frames("ret.noise", (V, F, 3, 224, 224), 6)
+    tok = synth.tokens("ret.tok", Q, 7)
+    # ---- CPU oracle
+    fe = O.eva_encode_image(sd, frames.reshape(V * F, 3, 224, 224), cfg).reshape(V, F, -1)
+    vn = O.pool_video(fe)
+    tn = O.l2_normalize(O.eva_encode_text(sd, tok, cfg))
+    s_ref = O.similarity(tn, vn)
+    gt = s_ref.argmax(dim=1)
+    # ---- GPU path
+    pooled = retrieval.encode_videos(model, frames.to(dev))
+    texts = retrieval.encode_texts(model, tok.to(dev))
+    scores, val, idx = retrieval.retrieve(texts, pooled, 10)
+    idx = idx.cpu().long()
+    for k in (1, 5, 10):
+        r = (idx[:, :k] == gt[:, None]).any(dim=1).float().mean().item()
+        margin = (s_ref.topk(2, dim=1).values[:, 0] - s_ref.topk(2, dim=1).values[:, 1]).min().item()
+        print(f"matched R@{k} = {100 * r:.1f} %  (min oracle top-1 margin {margin:.2e}, max |score diff| "
+              f"{(scores.cpu() - s_ref).abs().max().item():.2e})")
+        if k >= 5:
+            assert r == 1.0
+    # R@1 can only differ where the oracle's top-1 margin is below the bf16 score error
+    err = (scores.cpu() - s_ref).abs().max().item()
+    top2 = s_ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * err
+    assert torch.equal(idx[safe, 0], gt[safe])
+    # ---- data-parallel invariance: two "ranks" encoding contiguous halves == one rank (bit-exact rows)
+    lo0, hi0, _ = retrieval.shard_range(V, 0, 2)
+    lo1, hi1, _ = retrieval.shard_range(V, 1, 2)
+    both = torch.cat([retrieval.encode_videos(model, frames[lo0:hi0].to(dev)),
+                      retrieval.encode_videos(model, frames[lo1:hi1].to(dev))])
+    assert torch.equal(both, pooled)
+    _, _, idx2 = retrieval.retrieve(texts, both, 10)
+    assert torch.equal(idx2.cpu().long(), idx)
