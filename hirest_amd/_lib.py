@@ -36,7 +36,8 @@ class VisionTower(C.Structure):
                [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("blocks", C.POINTER(BlockWeights)),
                 ("norm_g", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
-                ("image_mean", C.c_void_p), ("image_std", C.c_void_p)]
+                ("image_mean", C.c_void_p), ("image_std", C.c_void_p),
+                ("ln_pre_g", C.c_void_p), ("ln_pre_b", C.c_void_p), ("out_all_tokens", C.c_int32)]
 
 
 class TextTower(C.Structure):

@@ -330,7 +330,189 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
     }
 }
 
-int g_attn_variant = 2;   // 1 = v1 (register-staged, transposing stores), 2 = v2 (LDS-DMA + transpose reads)
+
+// =================================================================================================
+// v3: one PERSISTENT workgroup (9 waves) per frame walking its H heads.  K is double-buffered in LDS and V
+// single-buffered (2 x 51 KiB + 54 KiB = 156 KiB of the CU's 160): the LDS-DMA of K(h+1) runs under all of
+// head h, the DMA of V(h) under the first S^T of head h, so staging — a third of v2's time, which ran one
+// (frame, head) per workgroup with nothing to overlap — disappears behind compute.  9 waves instead of 8:
+// the 17 query tiles of 257 tokens become 2 rounds (2,2,...,2,1) instead of 3.
+//   per head:  vmcnt(0) | BARRIER A (K(h) landed everywhere, head h-1 finished everywhere)
+//              DMA V(h), DMA K(h+1) | S^T + softmax of the first tile | vmcnt(#K pieces) BARRIER B (V(h) landed)
+//              P.V ... remaining tiles
+// =================================================================================================
+template <int DH, int DP, int NT>
+__global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          int N, int H, float scale_log2e, int causal) {
+    using C = AttnCfg2<DH, DP, NT>;
+    constexpr int NW = 9;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Vs = smem + 2 * C::NPAD * C::RS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const bf16_t* fbase = qkv + (int64_t)b * N * ld;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int gk = g ^ ((-(c16 >> 2)) & 3);
+    const int nqt = (N + 15) >> 4;
+
+    auto dma_k = [&](int h, char* dst) -> int {
+        int n = 0;
+        for (int i = wave; i < C::NK_INSTR; i += NW) {
+            const int ci = i * 64 + lane;
+            int row = ci / C::CPR, c = ci - row * C::CPR;
+            c = (c & ~3) | ((c & 3) ^ ((-(row >> 2)) & 3));
+            row = row < N ? row : N - 1;
+            c = c * 8 < DH ? c : DH / 8 - 1;
+            glds16(fbase + (int64_t)row * ld + D + h * DH + c * 8, dst + i * 1024);
+            ++n;
+        }
+        return n;
+    };
+    auto dma_v = [&](int h) {
+        for (int i = wave; i < C::NV_INSTR; i += NW) {
+            const int ci = i * 64 + lane;
+            int row = ci / C::CPR, c = ci - row * C::CPR;
+            row = row < N ? row : N - 1;
+            c = c * 8 < DH ? c : DH / 8 - 1;
+            glds16(fbase + (int64_t)row * ld + 2 * D + h * DH + c * 8, Vs + i * 1024);
+        }
+    };
+
+    dma_k(0, smem);
+    for (int h = 0; h < H; ++h) {
+        const bf16_t* base = fbase + h * DH;
+        const char* Ks = smem + (h & 1) * (C::NPAD * C::RS);
+        // Q fragments of this wave's first tile: loaded and retired BEFORE any new DMA is issued, so the
+        // compiler's wait for them cannot drain the V / K(h+1) transfers that are about to start
+        int qt = wave;
+        bf16x8 qf[DP / 32];
+        auto load_q = [&](int qtile) {
+            const int q = qtile * 16 + c16;
+#pragma unroll
+            for (int kk = 0; kk < DP / 32; ++kk) {
+                const int d = (kk * 4 + g) * 8;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (q < N && d < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * ld + d);
+                qf[kk] = v;
+            }
+        };
+        if (qt < nqt) load_q(qt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K(h) pieces (issued one head ago) + the Q loads
+#pragma unroll
+        for (int kk = 0; kk < DP / 32; ++kk) asm volatile("" : "+v"(qf[kk]));
+        __builtin_amdgcn_s_barrier();                          // A: K(h) everywhere, head h-1 done everywhere
+        dma_v(h);
+        const int nk_next = h + 1 < H ? dma_k(h + 1, smem + ((h + 1) & 1) * (C::NPAD * C::RS)) : 0;
+        bool v_ready = false;
+        for (; qt < nqt; qt += NW) {
+            const int q = qt * 16 + c16;
+            const bool qvalid = q < N;
+            if (qt != wave) load_q(qt);
+            f32x4 st[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < DP / 32; ++kk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::RS + (kk * 4 + gk) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+                }
+                st[t] = acc;
+                __builtin_amdgcn_sched_barrier(0);   // 9 waves -> 168 VGPRs: bound the hoisting of K fragment reads
+            }
+            const int klimit = causal ? (q < N - 1 ? q : N - 1) : N - 1;
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = t * 16 + 4 * g + i;
+                    const float sv = key <= klimit ? st[t][i] : -3.0e38f;
+                    st[t][i] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // exponentiate and pack to bf16 pair by pair (keeps the fp32 scores' live range short: 9 waves -> 168 VGPRs)
+            float sum = 0.f;
+            bf16x8 pf[C::KS];
+#pragma unroll
+            for (int s2 = 0; s2 < C::KS; ++s2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p0 = exp2f((st[2 * s2][i] - mx) * scale_log2e);
+                    sum += p0;
+                    pf[s2][i] = (bf16_t)p0;
+                    if (2 * s2 + 1 < NT) {
+                        const float p1 = exp2f((st[2 * s2 + 1][i] - mx) * scale_log2e);
+                        sum += p1;
+                        pf[s2][4 + i] = (bf16_t)p1;
+                    } else {
+                        pf[s2][4 + i] = (bf16_t)0.f;
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            if (!v_ready) {
+                wait_vm_le(nk_next);                 // V(h) pieces were issued before the K(h+1) pieces
+                __builtin_amdgcn_s_barrier();        // B: V(h) everywhere
+                v_ready = true;
+            }
+            const char* vlane = Vs + (4 * g + (c16 >> 2)) * C::RS + (c16 & 3) * 8;
+#pragma unroll 1
+            for (int dt = 0; dt < DP / 16; ++dt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const char* vrow = vlane + dt * 32;
+#pragma unroll
+                for (int s2 = 0; s2 < C::KS; ++s2) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(vrow + s2 * 32 * C::RS));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(vrow + (s2 * 32 + 16) * C::RS));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], acc, 0, 0, 0);
+                    if (s2 % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+                const int d = dt * 16 + 4 * g;
+                if (qvalid && d < DH) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(acc[i] * inv);
+                    *reinterpret_cast<bf16x4*>(out + ((int64_t)b * N + q) * D + h * DH + d) = o;
+                }
+            }
+        }
+        if (!v_ready) {
+            wait_vm_le(nk_next);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int DH, int DP, int NT>
+int launch3(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
+    using C = AttnCfg2<DH, DP, NT>;
+    constexpr int LDS = (2 * C::NPAD + C::KP) * C::RS;
+    static_assert(LDS <= 163840, "K x2 + V must fit the CU's LDS");
+    static bool configured = false;
+    auto kern = attention_kernel_v3<DH, DP, NT>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(576), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
+    return hirest_launch_status();
+}
+
+int g_attn_variant = 3;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame; default for N > 80)
+//   // 1 = v1 (register-staged, transposing stores), 2 = v2 (LDS-DMA + transpose reads)
 
 template <int DH, int DP, int NT>
 int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
@@ -350,7 +532,7 @@ int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, in
 }  // namespace
 
 extern "C" int hirest_attention_select_kernel(int32_t which) {
-    if (which < 1 || which > 2) return HIREST_E_BADARG;
+    if (which < 1 || which > 3) return HIREST_E_BADARG;
     g_attn_variant = which;
     return 0;
 }
@@ -362,7 +544,11 @@ extern "C" int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out, i
     const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
     bf16_t* o = reinterpret_cast<bf16_t*>(out);
     HirestProfScope prof(HIREST_PROF_ATTENTION, causal, (int64_t)B * H, N, dh, s);
-    if (g_attn_variant == 2) {
+    if (g_attn_variant == 3 && N > 80 && N <= 272 && B >= 64) {
+        if (dh == 88) return launch3<88, 96, 17>(q, o, B, N, H, scale, causal, s);
+        if (dh == 64) return launch3<64, 64, 17>(q, o, B, N, H, scale, causal, s);
+    }
+    if (g_attn_variant >= 2) {
         if (dh == 88) {
             if (N <= 80) return launch2<88, 96, 5>(q, o, B, N, H, scale, causal, s);
             if (N <= 272) return launch2<88, 96, 17>(q, o, B, N, H, scale, causal, s);

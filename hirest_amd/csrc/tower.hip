@@ -94,8 +94,15 @@ extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* f
     CHECK(gemm(big, t->kpad, t->patch_w, t->kpad, t->patch_b, x, D, B * P, D, t->kpad, HIREST_EPI_PATCH_POS_F32, stream,
                t->pos, P));
     CHECK(hirest_write_cls_rows(x, D, t->cls, t->pos, B, T, D, stream));
+    if (t->ln_pre_g)   // model.py:261 ln_pre, in place on the fp32 stream (row-local, so in place is safe)
+        CHECK(hirest_layernorm(x, D, nullptr, t->ln_pre_g, t->ln_pre_b, t->ln_eps, x, D, 1, B * T, D, stream));
     for (int l = 0; l < t->layers; ++l)
         CHECK(run_block(t->blocks[l], x, h, big, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps, t->act, 0, stream));
+    if (t->out_all_tokens) {   // ln_post + proj on every token row; out is [B*T, embed_dim]
+        CHECK(hirest_layernorm(x, D, nullptr, t->norm_g, t->norm_b, t->ln_eps, h, D, 0, B * T, D, stream));
+        CHECK(gemm(h, D, t->head_w, D, t->head_b, out, t->embed_dim, B * T, t->embed_dim, D, HIREST_EPI_BIAS_F32, stream));
+        return 0;
+    }
     // norm on the CLS rows only (LayerNorm is per-row, so norm(x)[:,0] == norm(x[:,0])), then head
     CHECK(hirest_layernorm(x, (int64_t)T * D, nullptr, t->norm_g, t->norm_b, t->ln_eps, h, D, 0, B, D, stream));
     CHECK(gemm(h, D, t->head_w, D, t->head_b, out, t->embed_dim, B, t->embed_dim, D, HIREST_EPI_BIAS_F32, stream));

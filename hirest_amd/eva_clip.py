@@ -172,7 +172,7 @@ class VisionTower(_Tower):
             hold(ops.to_bf16(pw)), hold(self._f32(self.patch_embed.proj.bias)),
             hold(self._f32(self.cls_token).reshape(-1)), hold(self._f32(self.pos_embed).reshape(self.num_tokens, D)),
             blocks, hold(self._f32(self.norm.weight)), hold(self._f32(self.norm.bias)),
-            hold(self._bf16(self.head.weight)), hold(self._f32(self.head.bias)), hold(mean), hold(std))
+            hold(self._bf16(self.head.weight)), hold(self._f32(self.head.bias)), hold(mean), hold(std), None, None, 0)
         self._prepared = {"device": device, "desc": desc, "blocks": blocks, "keep": keep}
         return self._prepared
 

@@ -171,6 +171,10 @@ typedef struct hirest_vision_tower {       /* EVA ViT (vit_model.py:248-351) */
     const hirest_bf16* head_w;             /* [embed_dim, width] */
     const float* head_b;                   /* [embed_dim] or NULL */
     const float* image_mean; const float* image_std; /* device [3], used when in_dtype==2 */
+    /* OpenAI-CLIP ViT variant as vendored by the reference (EVA_clip/model.py:216-273): */
+    const float* ln_pre_g; const float* ln_pre_b;    /* LayerNorm right after cls/pos (NULL = none) */
+    int32_t out_all_tokens;  /* 0: norm -> CLS row -> head = [B,E];  1: ln_post + proj on every token = [B,T,E]
+                                (the caller drops token 0: model.py:269-273 returns the patch tokens) */
 } hirest_vision_tower;
 
 size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B);

@@ -168,8 +168,9 @@ def _attention_ref(qkv, B, N, H, dh, causal):
 
 @pytest.mark.parametrize("B,N,H,dh,causal,qscale", [(2, 257, 16, 88, False, 1.0), (3, 77, 12, 64, True, 1.0),
                                                     (1, 257, 8, 88, False, 6.0), (2, 50, 12, 64, False, 1.0),
-                                                    (1, 1, 2, 64, True, 1.0), (1, 272, 2, 64, False, 3.0)])
-@pytest.mark.parametrize("variant", [1, 2], ids=["v1", "v2"])
+                                                    (1, 1, 2, 64, True, 1.0), (1, 272, 2, 64, False, 3.0),
+                                                    (70, 257, 16, 88, False, 2.0), (66, 200, 4, 64, True, 1.0)])
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["v1", "v2", "v3"])
 def test_attention(dev, ops, B, N, H, dh, causal, qscale, variant):
     ops.attention_select_kernel(variant)
     D = H * dh
@@ -179,7 +180,7 @@ def test_attention(dev, ops, B, N, H, dh, causal, qscale, variant):
     ref = _attention_ref(qkv, B, N, H, dh, causal)
     out = torch.full((B * N, D), 9.0, dtype=torch.bfloat16, device=dev)
     ops.attention(qkv.to(torch.bfloat16).to(dev), out, B, N, H, dh, causal)
-    ops.attention_select_kernel(2)
+    ops.attention_select_kernel(3)
     # P is rounded to bf16 before P.V and the output is bf16: 2 roundings of <= 2^-8 relative to max|v|
     assert (out.cpu().double() - ref).abs().max().item() <= 3 * 2 ** -8 * qkv[:, 2 * D:].abs().max().item()
 
@@ -270,3 +271,46 @@ def test_eva_g14_full_size_vs_reference(dev, golden_dir):
     # bf16 NCHW input = same result as f32 input holding bf16-representable values
     imb = img.to(torch.bfloat16)
     assert torch.equal(model.encode_image(imb), model.encode_image(imb.float()))
+
+
+# ----------------------------------------------------------------------------------------
+# OpenAI-CLIP ViT as vendored by the reference (EVA_clip/model.py) — BASELINE configs[0] on the GPU
+# ----------------------------------------------------------------------------------------
+def test_openai_clip_tiny_vs_reference(dev, golden_dir):
+    from hirest_amd import clip
+    g = np.load(os.path.join(golden_dir, "openai_tiny.npz"))
+    c, seed = synth.OPENAI_VIT_TINY, int(g["seed"])
+    sd = synth.openai_clip_state_dict(c, seed)
+    model = clip.build_model(sd).to(dev)
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    img = synth.frames("openai_tiny.img", (int(g["n_img"]), 3, 224, 224), seed + 1).to(dev)
+    pt = model.encode_image(img)
+    assert pt.shape == (int(g["n_img"]), 49, c["embed_dim"])          # patch tokens, CLS dropped (hazard H4)
+    _check_embed(pt.reshape(-1, c["embed_dim"]).cpu(), torch.from_numpy(g["patch_tokens_sample"]).reshape(-1, c["embed_dim"]), "openai tiny patch tokens")
+    _check_embed(model.encode_text(torch.from_numpy(g["tokens"]).to(dev)).cpu(), torch.from_numpy(g["text_embed"]), "openai tiny text")
+
+
+def test_openai_clip_b32_config1_vs_reference(dev, golden_dir):
+    """ViT-B/32, 64 frames + 16 real prompts: frame embedding = mean of projected patch tokens, cosine top-5."""
+    from hirest_amd import clip
+    g = np.load(os.path.join(golden_dir, "openai_b32.npz"))
+    c, seed = synth.OPENAI_VIT_B32, int(g["seed"])
+    model = clip.build_model(synth.openai_clip_state_dict(c, seed)).to(dev)
+    img = synth.frames("openai_b32.img", (int(g["n_img"]), 3, 224, 224), seed + 1).to(dev)
+    fe = model.encode_image(img).mean(dim=1)
+    te = model.encode_text(torch.from_numpy(g["tokens"]).to(dev))
+    _check_embed(fe.cpu(), torch.from_numpy(g["frame_embed"]), "ViT-B/32 frame embed")
+    _check_embed(te.cpu(), torch.from_numpy(g["text_embed"]), "ViT-B/32 text embed")
+    from hirest_amd import ops as o
+    cos = o.similarity(o.pool_l2norm(te.unsqueeze(1).contiguous()), o.pool_l2norm(fe.unsqueeze(1).contiguous())).cpu()
+    ref = torch.from_numpy(g["cosine"])
+    err = (cos - ref).abs().max().item()
+    print(f"config 1 cosine matrix: max |diff| {err:.2e}")
+    assert err < 2e-2
+    # top-5 ids: exact wherever the reference's margins exceed the bf16 score error
+    r5 = ref.topk(6, dim=1).values
+    safe = (r5[:, :5] - r5[:, 1:6]).min(dim=1).values > 2 * err
+    got = cos.topk(5, dim=1).indices
+    assert torch.equal(got[safe], torch.from_numpy(g["top5"])[safe])
+    print(f"top-5 ids exact on {int(safe.sum())}/{len(safe)} queries with safe margins; "
+          f"overall set agreement {np.mean([len(set(a.tolist()) & set(b.tolist())) / 5 for a, b in zip(got, torch.from_numpy(g['top5']))]):.3f}")
