@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 //              DMA V(h), DMA K(h+1) | S^T + softmax of the first tile | vmcnt(#K pieces) BARRIER B (V(h) landed)
 //              P.V ... remaining tiles
 // =================================================================================================
-template <int DH, int DP, int NT>
+template <int DH, int DP, int NT, bool FAST>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
 __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           int N, int H, float scale_log2e, int causal) {
     using C = AttnCfg2<DH, DP, NT>;
@@ -413,41 +413,47 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
             if (qt != wave) load_q(qt);
             f32x4 st[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; t += 2) {   // two key tiles at a time: independent accumulators hide the MFMA latency
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < DP / 32; ++kk) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::RS + (kk * 4 + gk) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+                    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::RS + (kk * 4 + gk) * 16);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[kk], a0, 0, 0, 0);
+                    if (t + 1 < NT) {
+                        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Ks + ((t + 1) * 16 + c16) * C::RS + (kk * 4 + gk) * 16);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[kk], a1, 0, 0, 0);
+                    }
                 }
-                st[t] = acc;
-                __builtin_amdgcn_sched_barrier(0);   // 9 waves -> 168 VGPRs: bound the hoisting of K fragment reads
+                st[t] = a0;
+                if (t + 1 < NT) st[t + 1] = a1;
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // mask (only tiles that can contain masked keys pay for it), row max
             const int klimit = causal ? (q < N - 1 ? q : N - 1) : N - 1;
             float mx = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                if (!FAST || t == NT - 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int key = t * 16 + 4 * g + i;
-                    const float sv = key <= klimit ? st[t][i] : -3.0e38f;
-                    st[t][i] = sv;
-                    mx = fmaxf(mx, sv);
+                    for (int i = 0; i < 4; ++i) st[t][i] = (t * 16 + 4 * g + i) <= klimit ? st[t][i] : -3.0e38f;
                 }
+                mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // exponentiate and pack to bf16 pair by pair (keeps the fp32 scores' live range short: 9 waves -> 168 VGPRs)
+            // p = 2^(s*c - mx*c): one fma + one v_exp_f32 per score (arguments are <= 0; underflow flushes to 0)
+            const float nmc = -mx * scale_log2e;
             float sum = 0.f;
             bf16x8 pf[C::KS];
 #pragma unroll
             for (int s2 = 0; s2 < C::KS; ++s2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float p0 = exp2f((st[2 * s2][i] - mx) * scale_log2e);
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(st[2 * s2][i], scale_log2e, nmc));
                     sum += p0;
                     pf[s2][i] = (bf16_t)p0;
                     if (2 * s2 + 1 < NT) {
-                        const float p1 = exp2f((st[2 * s2 + 1][i] - mx) * scale_log2e);
+                        const float p1 = __builtin_amdgcn_exp2f(fmaf(st[2 * s2 + 1][i], scale_log2e, nmc));
                         sum += p1;
                         pf[s2][4 + i] = (bf16_t)p1;
                     } else {
@@ -464,25 +470,28 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
                 v_ready = true;
             }
             const char* vlane = Vs + (4 * g + (c16 >> 2)) * C::RS + (c16 & 3) * 8;
-#pragma unroll 1
-            for (int dt = 0; dt < DP / 16; ++dt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const char* vrow = vlane + dt * 32;
+            f32x4 oacc[DP / 16];
 #pragma unroll
-                for (int s2 = 0; s2 < C::KS; ++s2) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(vrow + s2 * 32 * C::RS));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(vrow + (s2 * 32 + 16) * C::RS));
+            for (int dt = 0; dt < DP / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < C::KS; ++s2) {
+#pragma unroll
+                for (int dt = 0; dt < DP / 16; ++dt) {   // DP/16 independent accumulators per key step
+                    const char* vrow = vlane + dt * 32 + s2 * 32 * C::RS;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vrow));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vrow + 16 * C::RS));
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], acc, 0, 0, 0);
-                    if (s2 % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DP / 16; ++dt) {
                 const int d = dt * 16 + 4 * g;
                 if (qvalid && d < DH) {
                     bf16x4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(acc[i] * inv);
+                    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(oacc[dt][i] * inv);
                     *reinterpret_cast<bf16x4*>(out + ((int64_t)b * N + q) * D + h * DH + d) = o;
                 }
             }
@@ -495,13 +504,13 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DH, int DP, int NT>
+template <int DH, int DP, int NT, bool FAST>
 int launch3(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
     using C = AttnCfg2<DH, DP, NT>;
     constexpr int LDS = (2 * C::NPAD + C::KP) * C::RS;
     static_assert(LDS <= 163840, "K x2 + V must fit the CU's LDS");
     static bool configured = false;
-    auto kern = attention_kernel_v3<DH, DP, NT>;
+    auto kern = attention_kernel_v3<DH, DP, NT, FAST>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
@@ -545,8 +554,11 @@ extern "C" int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out, i
     bf16_t* o = reinterpret_cast<bf16_t*>(out);
     HirestProfScope prof(HIREST_PROF_ATTENTION, causal, (int64_t)B * H, N, dh, s);
     if (g_attn_variant == 3 && N > 80 && N <= 272 && B >= 64) {
-        if (dh == 88) return launch3<88, 96, 17>(q, o, B, N, H, scale, causal, s);
-        if (dh == 64) return launch3<64, 64, 17>(q, o, B, N, H, scale, causal, s);
+        const bool fast = !causal && N > 256;
+        if (dh == 88) return fast ? launch3<88, 96, 17, true>(q, o, B, N, H, scale, causal, s)
+                                  : launch3<88, 96, 17, false>(q, o, B, N, H, scale, causal, s);
+        if (dh == 64) return fast ? launch3<64, 64, 17, true>(q, o, B, N, H, scale, causal, s)
+                                  : launch3<64, 64, 17, false>(q, o, B, N, H, scale, causal, s);
     }
     if (g_attn_variant >= 2) {
         if (dh == 88) {

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the attention kernels at the EVA-CLIP-g shape (B frames x 16 heads, 257 tokens, dh 88)."""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hirest_amd import ops  # noqa: E402
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", type=int, nargs="*", default=[2, 3])
+ap.add_argument("--frames", type=int, default=1024)
+ap.add_argument("--iters", type=int, default=10)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+B, N, H, dh = a.frames, 257, 16, 88
+g = torch.Generator(device=dev); g.manual_seed(0)
+qkv = torch.randn((B * N, 3 * H * dh), device=dev, generator=g).to(torch.bfloat16)
+out = torch.empty((B * N, H * dh), device=dev, dtype=torch.bfloat16)
+for v in a.variants:
+    ops.attention_select_kernel(v)
+    for _ in range(2):
+        ops.attention(qkv, out, B, N, H, dh, False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        ops.attention(qkv, out, B, N, H, dh, False)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    print(f"attention variant {v}: {ms:.3f} ms  {4.0 * B * H * N * N * dh / ms / 1e9:.0f} TFLOP/s (algorithmic)", flush=True)
