@@ -193,6 +193,12 @@ def state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str, torch
     for name, shape in shapes.items():
         std, mean = _init_rule(name, shape)
         out[name] = tensor(name, shape, std, seed, mean)
+    # the decoder's input embedding and its LM-head matrix are ONE tied parameter in the reference
+    # (module_decoder.py:171-176,284-285): a checkpoint carries the same values under both names
+    tied_a = "clip4cap_model.decoder.embeddings.word_embeddings.weight"
+    tied_b = "clip4cap_model.decoder.classifier.cls.predictions.decoder.weight"
+    if tied_a in out and tied_b in out:
+        out[tied_a] = out[tied_b]
     return out
 
 
@@ -272,4 +278,10 @@ def joint_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str,
         else:
             std, mean = 0.03, 0.0
         out[name] = tensor(name, shape, std, seed, mean)
+    # the decoder's input embedding and its LM-head matrix are ONE tied parameter in the reference
+    # (module_decoder.py:171-176,284-285): a checkpoint carries the same values under both names
+    tied_a = "clip4cap_model.decoder.embeddings.word_embeddings.weight"
+    tied_b = "clip4cap_model.decoder.classifier.cls.predictions.decoder.weight"
+    if tied_a in out and tied_b in out:
+        out[tied_a] = out[tied_b]
     return out

@@ -429,3 +429,127 @@ def moment_segmentation(sd: SD, vis, text, asr, vis_mask, bounds, threshold: flo
         steps[b].append([lasts[b], lasts[b]])
         out.append(segmentation_postprocess(steps[b], lasts[b]))
     return out, first_logits
+
+
+# ----------------------------------------------------------------------------------
+# Step captioning: trim_feats + 2-layer decoder + beam search (modeling.py:529-632,
+# clip4caption/modules/module_decoder.py:279-406, modules/beam.py:31-123, clip4caption/train.py:511-599)
+# ----------------------------------------------------------------------------------
+
+_DEC = "clip4cap_model.decoder."
+BOS_ID, EOS_ID = 101, 102          # '[CLS]' / '[SEP]' of the BERT vocab (beam.py:24-29 via the tokenizer)
+
+
+def trim_feats(feats: torch.Tensor, moment_mask: torch.Tensor, max_frames: int) -> torch.Tensor:
+    """modeling.py:529-554: keep the frames inside the moment; truncate to max_frames, or nearest-neighbour
+    upsample with the bucket rule count[(j*F)//N : ((j+1)*F)//N]."""
+    out = []
+    for b in range(feats.shape[0]):
+        z = feats[b][moment_mask[b] == 1]
+        N = z.shape[0]
+        if max_frames < N:
+            z = z[:max_frames]
+        else:
+            idx = []
+            for j in range(N):
+                idx += [j] * (((j + 1) * max_frames) // N - (j * max_frames) // N)
+            x = torch.zeros((max_frames, z.shape[1]))
+            for pos, j in enumerate(idx):
+                x[pos] = z[j]
+            z = x
+        out.append(z)
+    return torch.stack(out)
+
+
+def _mha(sd: SD, p: str, q_in, kv_in, add_mask, heads: int = 12):
+    """MultiHeadAttention (module_decoder.py:194-240): scores/sqrt(dh) + additive mask, softmax, context."""
+    B, Lq, D = q_in.shape
+    Lk = kv_in.shape[1]
+    dh = D // heads
+    q = (q_in @ sd[p + "att.query.weight"].t() + sd[p + "att.query.bias"]).view(B, Lq, heads, dh).transpose(1, 2)
+    k = (kv_in @ sd[p + "att.key.weight"].t() + sd[p + "att.key.bias"]).view(B, Lk, heads, dh).transpose(1, 2)
+    v = (kv_in @ sd[p + "att.value.weight"].t() + sd[p + "att.value.bias"]).view(B, Lk, heads, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh) + add_mask
+    c = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Lq, D)
+    # BertSelfOutput: LayerNorm(dense(ctx) + q_in)  (module_decoder.py:110-123, 262-271)
+    return layer_norm(c @ sd[p + "output.dense.weight"].t() + sd[p + "output.dense.bias"] + q_in,
+                      sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
+
+
+def decoder_logits(sd: SD, input_ids: torch.Tensor, enc: torch.Tensor, layers: int = 2) -> torch.Tensor:
+    """DecoderModel.forward (module_decoder.py:372-406) with answer_mask = ones and encoder_mask = ZEROS
+    (modeling.py:591), i.e. a uniform -10000 on every cross-attention score and -10000 above the diagonal of the
+    self-attention (not -inf).  Returns [R, t, vocab]."""
+    R, t = input_ids.shape
+    x = sd[_DEC + "embeddings.word_embeddings.weight"][input_ids] + sd[_DEC + "embeddings.position_embeddings.weight"][:t]
+    x = layer_norm(x, sd[_DEC + "embeddings.LayerNorm.weight"], sd[_DEC + "embeddings.LayerNorm.bias"], 1e-12)
+    self_mask = torch.triu(torch.ones(t, t), diagonal=1) * -10000.0
+    for i in range(layers):
+        p = _DEC + f"decoder.layer.{i}."
+        s = _mha(sd, p + "slf_attn.", x, x, self_mask)
+        d = _mha(sd, p + "enc_attn.", s, enc, -10000.0)
+        h = gelu_erf(d @ sd[p + "intermediate.dense.weight"].t() + sd[p + "intermediate.dense.bias"])
+        x = layer_norm(h @ sd[p + "output.dense.weight"].t() + sd[p + "output.dense.bias"] + d,
+                       sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
+    c = _DEC + "classifier.cls.predictions."
+    h = gelu_erf(x @ sd[c + "transform.dense.weight"].t() + sd[c + "transform.dense.bias"])
+    h = layer_norm(h, sd[c + "transform.LayerNorm.weight"], sd[c + "transform.LayerNorm.bias"], 1e-12)
+    return h @ sd[c + "decoder.weight"].t() + sd[c + "bias"]
+
+
+class RefBeam:
+    """beam.py:31-123 restated on plain Python lists (scores are fp32 values)."""
+
+    def __init__(self, size: int):
+        self.size, self.done = size, False
+        self.scores = torch.zeros(size)
+        self.prev_ks: List[List[int]] = []
+        self.next_ys: List[List[int]] = [[BOS_ID] * size]
+
+    def hypothesis(self, k: int) -> List[int]:
+        hyp = []
+        for j in range(len(self.prev_ks) - 1, -1, -1):
+            hyp.append(self.next_ys[j + 1][k])
+            k = self.prev_ks[j][k]
+        return hyp[::-1]
+
+    def current_state(self) -> List[List[int]]:
+        if len(self.next_ys) == 1:
+            return [[BOS_ID] for _ in range(self.size)]
+        keys = torch.sort(self.scores, 0, True)[1].tolist()
+        return [[BOS_ID] + self.hypothesis(k) for k in keys]
+
+    def advance(self, word_logprob: torch.Tensor) -> bool:
+        V = word_logprob.shape[1]
+        lk = word_logprob + self.scores.unsqueeze(1) if self.prev_ks else word_logprob[0]
+        best, ids = lk.reshape(-1).topk(self.size, 0, True, True)
+        self.scores = best
+        prev = (ids // V).tolist()
+        self.prev_ks.append(prev)
+        self.next_ys.append((ids - (ids // V) * V).tolist())
+        if self.next_ys[-1][0] == EOS_ID:
+            self.done = True
+        return self.done
+
+
+def step_captioning(sd: SD, vis, text, asr, moment_mask, beams: int = 5, max_frames: int = 20, max_words: int = 48):
+    """test_step_captioning (modeling.py:556-632): returns the best hypothesis (token ids) per sample."""
+    B = vis.shape[0]
+    v = trim_feats(vis, moment_mask, max_frames)
+    a = trim_feats(asr, moment_mask, max_frames)
+    ones = torch.ones((B, max_frames), dtype=torch.long)
+    enc = joint_features(sd, v, text, a, ones, ones)
+    bms = [RefBeam(beams) for _ in range(B)]
+    active = list(range(B))
+    for t in range(1, max_words + 1):
+        seqs = torch.tensor([s for b in active for s in bms[b].current_state()], dtype=torch.long)
+        enc_rpt = torch.cat([enc[b:b + 1].expand(beams, -1, -1) for b in active], 0)
+        logp = torch.log_softmax(decoder_logits(sd, seqs, enc_rpt)[:, -1, :], dim=1).view(len(active), beams, -1)
+        active = [b for i, b in enumerate(active) if not bms[b].advance(logp[i])]
+        if not active:
+            break
+    out = []
+    for b in range(B):
+        k = torch.sort(bms[b].scores, 0, True)[1][0].item()
+        out.append(bms[b].hypothesis(k))
+    return out, enc

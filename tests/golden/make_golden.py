@@ -329,6 +329,38 @@ def gen_joint():
     print(out)
 
 
+def gen_caption():
+    """test_step_captioning (modeling.py:556-632) of the real MomentModel: trim_feats, fusion + encoder on 20
+    frames, beam search over the 2-layer decoder.  The tokenizer stub maps ids to their decimal strings, so the
+    'caption' is the token-id sequence (ids only)."""
+    model, args = build_reference_moment_model()
+    names = [k for k in model.state_dict().keys() if not k.startswith("clip_model.")]
+    shapes = {k: tuple(model.state_dict()[k].shape) for k in names}
+    sd = synth.joint_state_dict(shapes, 31)
+    # make [SEP]=102 reachable so that some beams terminate early: bias it up
+    sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
+    print(model.load_state_dict(sd, strict=False))
+    out = {}
+    for case, (B, T, beams) in {"a": (3, 64, 3), "b": (2, 300, 5)}.items():
+        vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"cap.{case}", B, T, 47)
+        # moments of different lengths: shorter than, equal to and longer than max_frames (20): all three trim branches
+        lens = [7, 20, 37][:B]
+        moment_mask = torch.zeros(B, T, dtype=torch.long)
+        for b in range(B):
+            moment_mask[b, 5 + b:5 + b + lens[b]] = 1
+        model.clip_model.encode_text = lambda ids, _t=text: _t
+        batch = {"tasks": ["step_captioning"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask,
+                 "asr_feats": asr, "clip_text_ids": torch.zeros(B, 77, dtype=torch.long)}
+        with torch.no_grad():
+            trimmed = model.trim_feats(vis, moment_mask, B, vis.device)
+            res = model.test_step(batch, num_beams=beams)
+        out[case] = {"B": B, "T": T, "beams": beams, "lens": lens, "prediction": res["prediction"]}
+        save(f"caption_{case}.npz", trimmed_rows=np32(trimmed[:, [0, 7, 19]]))
+        print(case, res["prediction"])
+    with open(os.path.join(HERE, "caption_predictions.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -347,6 +379,7 @@ def main():
         "openai_b32": lambda: gen_openai("openai_b32", synth.OPENAI_VIT_B32, 1, 64, 16, prompts=prompts),
         "eva_g14": lambda: gen_eva("eva_g14", synth.EVA_CLIP_G_14, 3, 2, 8),
         "joint": gen_joint,
+        "caption": gen_caption,
     }
     for name, fn in jobs.items():
         if args.only and name not in args.only:

@@ -160,3 +160,25 @@ def test_joint_model_matches_reference(golden_dir, case):
     seg, first = O.moment_segmentation(sd, vis, text, asr, vis_mask, bounds)
     assert np.abs(first.numpy() - g["seg_logits_iter0"]).max() < 1e-3
     assert seg == pred["pred_segmentation"]                        # boundary lists: exact
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_step_captioning_matches_reference(golden_dir, case):
+    """trim_feats + fusion/encoder on 20 frames + 2-layer decoder + beam search vs the real MomentModel
+    (token ids exact; the reference's tokenizer is stubbed to print ids)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden import joint_inputs
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    sd = synth.joint_state_dict(shapes, 31)
+    sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
+    pred = json.load(open(os.path.join(golden_dir, "caption_predictions.json")))[case]
+    g = load(golden_dir, f"caption_{case}.npz")
+    B, T = pred["B"], pred["T"]
+    vis, asr, text, vis_mask, _, _ = joint_inputs(f"cap.{case}", B, T, 47)
+    moment_mask = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        moment_mask[b, 5 + b:5 + b + pred["lens"][b]] = 1
+    assert np.array_equal(O.trim_feats(vis, moment_mask, 20)[:, [0, 7, 19]].numpy(), g["trimmed_rows"])
+    hyps, _ = O.step_captioning(sd, vis, text, asr, moment_mask, beams=pred["beams"])
+    assert [" ".join(str(i) for i in h) for h in hyps] == pred["prediction"]
