@@ -87,24 +87,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int ADH = 64, ALD = ADH + 1;
 
-__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           int T, int H, float scale, float add_const) {
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
+                                                           const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
+                                                           int Tq, int T, int H, float scale, float add_const, float causal_penalty) {
     __shared__ float Ks[32 * ALD];
     __shared__ float Vs[32 * ALD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int qblocks = (T + 127) / 128;
+    const int qblocks = (Tq + 127) / 128;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
     const int b = bh / H, h = bh - b * H;
     const int D = H * ADH;
-    const int64_t ld = 3 * (int64_t)D;
-    const float* base = qkv + (int64_t)b * T * ld + h * ADH;
+    const float* qbase = qp + (int64_t)b * Tq * ldq + h * ADH;
+    const float* kbase = kp + (int64_t)b * T * ldkv + h * ADH;
+    const float* vbase = vp + (int64_t)b * T * ldkv + h * ADH;
     const int q = qb * 128 + wave * 32 + l31;
-    const bool qvalid = q < T;
+    const bool qvalid = q < Tq;
     // Q^T fragments: B operand [k = d][j = query]: lane holds Q[q][2s + half] for s = 0..31
     float qf[32];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) qf[s] = qvalid ? base[(int64_t)q * ld + 2 * s + half] : 0.f;
+    for (int s = 0; s < 32; ++s) qf[s] = qvalid ? qbase[(int64_t)q * ldq + 2 * s + half] : 0.f;
     f32x16 o0, o1;   // O^T rows d = 0..31 and 32..63, column = query
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         for (int i = tid; i < 32 * 16; i += 256) {   // 32 keys x 16 float4
             const int kr = i >> 4, c = (i & 15) * 4;
             const int key = k0 + kr < T ? k0 + kr : T - 1;
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + D + c);
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + 2 * D + c);
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + c);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Ks[kr * ALD + c + e] = kv[e]; Vs[kr * ALD + c + e] = vv[e]; }
         }
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float sv = st[r] * scale;
-            sv = sv + add_const;
+            sv = sv + (key > q ? add_const + causal_penalty : add_const);   // additive masks, exactly as the reference adds them
             sv = key < T ? sv : -3.0e38f;
             st[r] = sv;
             tmax = fmaxf(tmax, sv);
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     }
     if (!qvalid) return;
     const float inv = 1.0f / lrun;
-    float* orow = out + ((int64_t)b * T + q) * D + h * ADH;
+    float* orow = out + ((int64_t)b * Tq + q) * D + h * ADH;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {   // O^T rows (reg&3) + 8*(reg>>2) + 4*half = d
         const int d = 8 * g + 4 * half;
@@ -385,9 +387,56 @@ extern "C" int hirest_attention_f32(const float* qkv, float* out, int32_t B, int
                                     float scale, float add_const, void* stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
     if (dh != ADH) return HIREST_E_SHAPE;
+    const int64_t ld = 3 * (int64_t)H * ADH;
     const int qblocks = (T + 127) / 128;
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, out, T, H,
-                       scale, add_const);
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, ld,
+                       qkv + H * ADH, qkv + 2 * H * ADH, ld, out, T, T, H, scale, add_const, 0.f);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out,
+                                        int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, float add_const,
+                                        float causal_penalty, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh != ADH || ldq % 4 != 0 || ldkv % 4 != 0) return HIREST_E_SHAPE;
+    const int qblocks = (Tq + 127) / 128;
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
+                       ldkv, out, Tq, Tk, H, scale, add_const, causal_penalty);
+    return hirest_launch_status();
+}
+
+// out[r][v] = x[r][v] - logsumexp(x[r]) + row_add[r]   (log_softmax of train.py:563-564 fused with the beam score add of beam.py:76)
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ row_add,
+                                                         float* __restrict__ out, int64_t ldo, int V) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (int64_t)r * ldx;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, xr[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    mx = bc;
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) s += expf(xr[i] - mx);
+    s = wave_sum(s);
+    __syncthreads();
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) bc = logf((red[0] + red[1]) + (red[2] + red[3]));
+    __syncthreads();
+    const float lse = bc, add = row_add ? row_add[r] : 0.f;
+    float* o = out + (int64_t)r * ldo;
+    for (int i = tid; i < V; i += 256) o[i] = ((xr[i] - mx) - lse) + add;
+}
+
+extern "C" int hirest_log_softmax_f32(const float* x, int64_t ldx, const float* row_add, float* out, int64_t ldo, int32_t rows,
+                                      int32_t V, void* stream) {
+    if (!x || !out || rows <= 0 || V <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, row_add, out, ldo, V);
     return hirest_launch_status();
 }
 

@@ -13,7 +13,8 @@ All math runs in the fp32 kernels of csrc/joint.hip (+ the LayerNorm kernel).  W
 reference is where time goes: the 20 segmentation iterations run back to back on the device —
 masks, softmax, arg-max, threshold walk and step list are device state, with ONE device->host copy at the
 end instead of B x 20 ``.cpu().tolist()`` syncs — and the loop-invariant part of the fusion is hoisted.
-Step captioning (modeling.py:556-632) is not implemented here yet and raises NotImplementedError.
+Step captioning (modeling.py:556-632): trim_feats, the same fusion/encoder on 20 frames, then beam search over the
+2-layer decoder — decoder math in the fp32 kernels, beam bookkeeping on the host as in the reference.
 """
 from __future__ import annotations
 
@@ -93,6 +94,33 @@ class MomentModel(nn.Module):
         self.clip4cap_model = nn.Module()
         self.clip4cap_model.visual = vis
         self.clip4cap_model.normalize_video = _seq(visual_norm2d=_LN(E))
+        # caption decoder (clip4caption/modules/module_decoder.py:279-406); LM head tied to the input embedding
+        vocab = 30522
+        dec = nn.Module()
+        dec.embeddings = _seq(word_embeddings=_Emb(vocab, H), position_embeddings=_Emb(512, H), LayerNorm=_LN(H))
+        dlayers = []
+        for _ in range(getattr(args, "decoder_num_hidden_layers", 2) if args is not None else 2):
+            lay = nn.Module()
+            for nm in ("slf_attn", "enc_attn"):
+                att = nn.Module()
+                att.att = _seq(query=_Lin(H, H), key=_Lin(H, H), value=_Lin(H, H))
+                att.output = _seq(dense=_Lin(H, H), LayerNorm=_LN(H))
+                lay.add_module(nm, att)
+            lay.intermediate = _seq(dense=_Lin(4 * H, H))
+            lay.output = _seq(dense=_Lin(H, 4 * H), LayerNorm=_LN(H))
+            dlayers.append(lay)
+        dec.decoder = nn.Module()
+        dec.decoder.layer = nn.ModuleList(dlayers)
+        pred = nn.Module()
+        pred.bias = _p(vocab)
+        pred.transform = _seq(dense=_Lin(H, H), LayerNorm=_LN(H))
+        pred.decoder = nn.Module()
+        pred.decoder.weight = dec.embeddings.word_embeddings.weight       # tied (module_decoder.py:171-176)
+        dec.classifier = nn.Module()
+        dec.classifier.cls = nn.Module()
+        dec.classifier.cls.predictions = pred
+        self.clip4cap_model.decoder = dec
+        self.tokenizer_vocab = None      # optional id -> token list (BERT vocab is not available offline)
         self.clip_g_map, self.clip_g_map_text = _Lin(E, 1024), _Lin(E, 1024)
         self.clip_model = clip_model
         self.heads = 12
@@ -129,6 +157,12 @@ class MomentModel(nn.Module):
             s = lay.attention.self
             c[f"qkv_w.{i}"] = torch.cat([f(s.query.weight), f(s.key.weight), f(s.value.weight)], 0).contiguous()
             c[f"qkv_b.{i}"] = torch.cat([f(s.query.bias), f(s.key.bias), f(s.value.bias)], 0).contiguous()
+        for i, lay in enumerate(self.clip4cap_model.decoder.decoder.layer):
+            sa, ea = lay.slf_attn.att, lay.enc_attn.att
+            c[f"dec_qkv_w.{i}"] = torch.cat([f(sa.query.weight), f(sa.key.weight), f(sa.value.weight)], 0).contiguous()
+            c[f"dec_qkv_b.{i}"] = torch.cat([f(sa.query.bias), f(sa.key.bias), f(sa.value.bias)], 0).contiguous()
+            c[f"dec_kv_w.{i}"] = torch.cat([f(ea.key.weight), f(ea.value.weight)], 0).contiguous()
+            c[f"dec_kv_b.{i}"] = torch.cat([f(ea.key.bias), f(ea.value.bias)], 0).contiguous()
         c["head_bias"] = torch.cat([f(getattr(m, "0").bias) for m in
                                     (self.start_predictor, self.end_predictor, self.segment_predictor)]).contiguous()
         self._cache = c
@@ -236,7 +270,7 @@ class MomentModel(nn.Module):
         elif task == "moment_segmentation":
             return self.test_moment_segmentation(batch, **kwargs)
         elif task == "step_captioning":
-            raise NotImplementedError("step_captioning is not implemented in hirest_amd yet")
+            return self.test_step_captioning(batch, **kwargs)
         else:
             raise NotImplementedError
 
@@ -318,4 +352,124 @@ class MomentModel(nn.Module):
         res = {"raw_predictions": deepcopy(preds), "prediction": preds}
         if return_trace:
             res["first_logits"] = first_logits
+        return res
+
+
+    # ------------------------------------------------------------------ step captioning (modeling.py:529-632)
+    @staticmethod
+    def _trim_index(mask_row: List[int], max_frames: int) -> List[int]:
+        """Row indices selected by trim_feats (modeling.py:529-554) for one sample; -1 = zero row."""
+        sel = [i for i, m in enumerate(mask_row) if m == 1]
+        N = len(sel)
+        if N == 0:
+            return [-1] * max_frames
+        if max_frames < N:
+            return sel[:max_frames]
+        idx = []
+        for j in range(N):
+            idx += [sel[j]] * (((j + 1) * max_frames) // N - (j * max_frames) // N)
+        return idx + [-1] * (max_frames - len(idx))
+
+    def _trim(self, feats: torch.Tensor, moment_mask: torch.Tensor, max_frames: int) -> torch.Tensor:
+        B = feats.shape[0]
+        rows = [self._trim_index(moment_mask[b].tolist(), max_frames) for b in range(B)]
+        idx = torch.tensor(rows, dtype=torch.long, device=feats.device)
+        out = torch.gather(feats, 1, idx.clamp(min=0).unsqueeze(-1).expand(-1, -1, feats.shape[-1]))   # pure data movement
+        return (out * (idx >= 0).unsqueeze(-1)).contiguous()
+
+    def _decoder_last_logprob(self, ids: torch.Tensor, enc_kv: List[torch.Tensor], row_add: torch.Tensor) -> torch.Tensor:
+        """DecoderModel.forward on the whole prefix (no KV cache, like the reference), then log_softmax of the LAST
+        position + row_add (train.py:547-566, beam.py:76).  ids [R,t] int64, enc_kv[i] [R,20,1536] -> [R, vocab]."""
+        c, lib = self._w(), _lib.load()
+        Dp = "clip4cap_model.decoder."
+        R, t = ids.shape
+        H, Dm = self.heads, 768
+        x = torch.empty((R * t, Dm), dtype=torch.float32, device=ids.device)
+        _lib.check(lib.hirest_embed_tokens(ids.contiguous().data_ptr(), c[Dp + "embeddings.word_embeddings.weight"].data_ptr(),
+                                           c[Dp + "embeddings.position_embeddings.weight"].data_ptr(), x.data_ptr(), None,
+                                           R, t, Dm, c[Dp + "embeddings.word_embeddings.weight"].shape[0], ops.stream_ptr()),
+                   "hirest_embed_tokens")
+        x = self._ln(x, c[Dp + "embeddings.LayerNorm.weight"], c[Dp + "embeddings.LayerNorm.bias"], 1e-12)
+        scale = (Dm // H) ** -0.5
+        for i in range(len(self.clip4cap_model.decoder.decoder.layer)):
+            p = Dp + f"decoder.layer.{i}."
+            qkv = self._gemm(x, c[f"dec_qkv_w.{i}"], c[f"dec_qkv_b.{i}"])
+            ctx = torch.empty_like(x)
+            _lib.check(lib.hirest_attention_f32_qkv(qkv.data_ptr(), 3 * Dm, qkv.data_ptr() + 4 * Dm, qkv.data_ptr() + 8 * Dm, 3 * Dm,
+                                                    ctx.data_ptr(), R, t, t, H, Dm // H, scale, 0.0, -10000.0, ops.stream_ptr()),
+                       "self attention")
+            s1 = self._gemm(ctx, c[p + "slf_attn.output.dense.weight"], c[p + "slf_attn.output.dense.bias"], resid=x)
+            s1 = self._ln(s1, c[p + "slf_attn.output.LayerNorm.weight"], c[p + "slf_attn.output.LayerNorm.bias"], 1e-12)
+            q2 = self._gemm(s1, c[p + "enc_attn.att.query.weight"], c[p + "enc_attn.att.query.bias"])
+            kv = enc_kv[i]
+            Tk = kv.shape[1]
+            _lib.check(lib.hirest_attention_f32_qkv(q2.data_ptr(), Dm, kv.data_ptr(), kv.data_ptr() + 4 * Dm, 2 * Dm, ctx.data_ptr(),
+                                                    R, t, Tk, H, Dm // H, scale, -10000.0, 0.0, ops.stream_ptr()), "cross attention")
+            d = self._gemm(ctx, c[p + "enc_attn.output.dense.weight"], c[p + "enc_attn.output.dense.bias"], resid=s1)
+            d = self._ln(d, c[p + "enc_attn.output.LayerNorm.weight"], c[p + "enc_attn.output.LayerNorm.bias"], 1e-12)
+            hmid = self._gemm(d, c[p + "intermediate.dense.weight"], c[p + "intermediate.dense.bias"], act=1)
+            y = self._gemm(hmid, c[p + "output.dense.weight"], c[p + "output.dense.bias"], resid=d)
+            x = self._ln(y, c[p + "output.LayerNorm.weight"], c[p + "output.LayerNorm.bias"], 1e-12)
+        last = x.reshape(R, t, Dm)[:, -1, :].contiguous()                     # dec_output[:, -1, :] (train.py:562)
+        cp = Dp + "classifier.cls.predictions."
+        hh = self._gemm(last, c[cp + "transform.dense.weight"], c[cp + "transform.dense.bias"], act=1)
+        hh = self._ln(hh, c[cp + "transform.LayerNorm.weight"], c[cp + "transform.LayerNorm.bias"], 1e-12)
+        logits = self._gemm(hh, c[Dp + "embeddings.word_embeddings.weight"], c[cp + "bias"])
+        V = logits.shape[1]
+        out = torch.empty_like(logits)
+        _lib.check(lib.hirest_log_softmax_f32(logits.data_ptr(), V, row_add.data_ptr(), out.data_ptr(), V, R, V, ops.stream_ptr()),
+                   "hirest_log_softmax_f32")
+        return out
+
+    @torch.no_grad()
+    def test_step_captioning(self, batch, num_beams=5, return_ids=False, **kwargs):
+        """modeling.py:556-632.  Returns {'prediction': [str]} (token strings joined like the reference; ids are
+        printed as decimal strings when no BERT vocab is attached via ``tokenizer_vocab``)."""
+        from .beam import BeamState, BOS_ID
+        lib = _lib.load()
+        dev = self._w()["dev"]
+        c = self._w()
+        max_frames = int(getattr(self.args, "max_frames_step_captioning", 20)) if self.args is not None else 20
+        max_words = int(getattr(self.args, "max_words", 48)) if self.args is not None else 48
+        vis = batch["vis_feats"].to(dev).float()
+        mmask = batch["moment_mask"]
+        B = vis.shape[0]
+        v = self._trim(vis, mmask.to(dev), max_frames)
+        a = self._trim(batch["asr_feats"].to(dev).float(), mmask.to(dev), max_frames) if self.use_asr else None
+        text = self._text_feat(batch, dev)
+        ones = torch.ones((B, max_frames), dtype=torch.long, device=dev)
+        base = self._fusion_base(v, text, a, ones)
+        enc = self._features(base, ones.to(torch.int32).contiguous(), None, B, max_frames)          # [B*F, 768]
+        # encoder-side K/V of the cross-attention are loop invariant: once per layer, [B, F, 1536]
+        enc_kv_all = [self._gemm(enc, c[f"dec_kv_w.{i}"], c[f"dec_kv_b.{i}"]).reshape(B, max_frames, -1)
+                      for i in range(len(self.clip4cap_model.decoder.decoder.layer))]
+        beams = [BeamState(num_beams) for _ in range(B)]
+        active = list(range(B))
+        for t in range(1, max_words + 1):
+            seqs = [s for b in active for s in beams[b].current_state()]
+            ids = torch.tensor(seqs, dtype=torch.long, device=dev)
+            sel = torch.tensor([b for b in active for _ in range(num_beams)], dtype=torch.long, device=dev)
+            enc_kv = [kv.index_select(0, sel).contiguous() for kv in enc_kv_all]
+            # row_add = running beam scores (beam.py:76); on the first step only beam 0 competes (beam.py:78)
+            add = torch.tensor([(x if (t > 1 or k == 0) else -3.0e38) for b in active
+                                for k, x in enumerate(beams[b].scores)], dtype=torch.float32, device=dev)
+            logp = self._decoder_last_logprob(ids, enc_kv, add)                                     # [n*beam, V]
+            n, V = len(active), logp.shape[1]
+            val, idx = ops.topk(logp.reshape(n, num_beams * V), num_beams)
+            val_h, idx_h = val.cpu().tolist(), idx.cpu().tolist()
+            active = [b for i, b in enumerate(active) if not beams[b].advance(val_h[i], idx_h[i], V)]
+            if not active:
+                break
+        hyps = [bm.best_hypothesis() for bm in beams]
+        texts = []
+        for h in hyps:
+            toks = [self.tokenizer_vocab[i] if self.tokenizer_vocab is not None else str(i) for i in h]
+            if "[SEP]" in toks:
+                toks = toks[:toks.index("[SEP]")]
+            if "[PAD]" in toks:
+                toks = toks[:toks.index("[PAD]")]
+            texts.append(" ".join(toks).replace(" ##", "").strip("##").strip())
+        res = {"prediction": texts}
+        if return_ids:
+            res["token_ids"] = hyps
         return res

@@ -214,6 +214,14 @@ int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, co
  * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3). */
 int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,
                          float scale, float add_const, void* stream);
+/* General form: separate q [B*Tq, ldq] and k/v [B*Tk, ldkv] (cross-attention), plus `causal_penalty` added to
+ * every score with key > query (the decoder's self-attention adds -10000 there, NOT -inf: module_decoder.py:394-397). */
+int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out,
+                             int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, float add_const,
+                             float causal_penalty, void* stream);
+/* out[r][:] = log_softmax(x[r][:]) + row_add[r]  (train.py:563-564 + the beam score add of beam.py:76); row_add may be NULL */
+int hirest_log_softmax_f32(const float* x, int64_t ldx, const float* row_add, float* out, int64_t ldo, int32_t rows,
+                           int32_t V, void* stream);
 /* tin[b,t,:] = tanh(time(b,t)*w1 + b1), time = (linspace(0,1,n_valid[b])[t]-0.5)*2, 0 past n_valid (modeling.py:176-195) */
 int hirest_joint_time_features(const int32_t* n_valid, const float* w1, const float* b1, float* tin,
                                int32_t B, int32_t T, int32_t E, void* stream);

@@ -96,3 +96,32 @@ def test_moment_model_vs_reference(dev, golden_dir, case):
     assert res["prediction"] == pred["pred_segmentation"]                               # exact boundary lists (IoU 1.0)
     with pytest.raises(NotImplementedError):
         model.test_step({"tasks": ["something_else"]})
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_step_captioning_vs_reference(dev, golden_dir, case):
+    """BASELINE configs[4] in miniature: trim_feats + encoder + beam-searched decoder; token ids exact vs the
+    REAL reference MomentModel.test_step (tests/golden/caption_predictions.json)."""
+    import hirest_amd
+    sys.path.insert(0, golden_dir)
+    from make_golden import joint_inputs
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    sd = synth.joint_state_dict(shapes, 31)
+    sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
+    pred = json.load(open(os.path.join(golden_dir, "caption_predictions.json")))[case]
+    g = np.load(os.path.join(golden_dir, f"caption_{case}.npz"))
+    B, T = pred["B"], pred["T"]
+    vis, asr, text, vis_mask, _, _ = joint_inputs(f"cap.{case}", B, T, 47)
+    moment_mask = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        moment_mask[b, 5 + b:5 + b + pred["lens"][b]] = 1
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).eval()
+    trimmed = model._trim(vis.to(dev), moment_mask.to(dev), 20)
+    assert np.array_equal(trimmed[:, [0, 7, 19]].cpu().numpy(), g["trimmed_rows"])
+    batch = {"tasks": ["step_captioning"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask,
+             "asr_feats": asr, "text_feat": text}
+    res = model.test_step(batch, num_beams=pred["beams"], return_ids=True)
+    assert res["prediction"] == pred["prediction"]
+    assert [" ".join(str(i) for i in h) for h in res["token_ids"]] == pred["prediction"]
