@@ -163,6 +163,13 @@ class MomentModel(nn.Module):
             c[f"dec_qkv_b.{i}"] = torch.cat([f(sa.query.bias), f(sa.key.bias), f(sa.value.bias)], 0).contiguous()
             c[f"dec_kv_w.{i}"] = torch.cat([f(ea.key.weight), f(ea.value.weight)], 0).contiguous()
             c[f"dec_kv_b.{i}"] = torch.cat([f(ea.key.bias), f(ea.value.bias)], 0).contiguous()
+        # LM head: vocab padded to a multiple of 4 rows for the GEMM's 4-wide epilogue; pad logits are -3e38 so they
+        # vanish in the log-softmax and can never enter the top-k
+        we = f(self.clip4cap_model.decoder.embeddings.word_embeddings.weight)
+        vb = f(self.clip4cap_model.decoder.classifier.cls.predictions.bias)
+        padn = (-we.shape[0]) % 4
+        c["lm_w"] = torch.cat([we, torch.zeros((padn, we.shape[1]), device=dev)], 0).contiguous() if padn else we
+        c["lm_b"] = torch.cat([vb, torch.full((padn,), -3.0e38, device=dev)]).contiguous() if padn else vb
         c["head_bias"] = torch.cat([f(getattr(m, "0").bias) for m in
                                     (self.start_predictor, self.end_predictor, self.segment_predictor)]).contiguous()
         self._cache = c
@@ -414,7 +421,7 @@ class MomentModel(nn.Module):
         cp = Dp + "classifier.cls.predictions."
         hh = self._gemm(last, c[cp + "transform.dense.weight"], c[cp + "transform.dense.bias"], act=1)
         hh = self._ln(hh, c[cp + "transform.LayerNorm.weight"], c[cp + "transform.LayerNorm.bias"], 1e-12)
-        logits = self._gemm(hh, c[Dp + "embeddings.word_embeddings.weight"], c[cp + "bias"])
+        logits = self._gemm(hh, c["lm_w"], c["lm_b"])
         V = logits.shape[1]
         out = torch.empty_like(logits)
         _lib.check(lib.hirest_log_softmax_f32(logits.data_ptr(), V, row_add.data_ptr(), out.data_ptr(), V, R, V, ops.stream_ptr()),
