@@ -50,7 +50,7 @@ PY
 bench)
   timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -c 2500 gpurun_out/bench.log ;;
 prof)
-  cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; cd $GRAFT_REPO_ROOT
+  cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; cd $GRAFT_REPO_ROOT
   ls -R gpurun_out/prof | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); head -20 $f ;;
 esac
 done
