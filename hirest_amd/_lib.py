@@ -94,6 +94,11 @@ _SIGNATURES = {
     "hirest_masked_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "hirest_segmentation_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p,
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hirest_preprocess_plan_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "hirest_preprocess_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
+    "hirest_preprocess_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "hirest_preprocess_u8": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hirest_vision_workspace_bytes": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),
     "hirest_vision_forward": (C.c_int, [C.POINTER(VisionTower), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -68,6 +68,23 @@ def frames(name: str, shape, seed: int) -> torch.Tensor:
     return tensor(name, shape, 1.0, seed)
 
 
+def rgb_frames(name: str, shape, seed: int) -> np.ndarray:
+    """Synthetic decoded video frames, uint8 [..., H, W, 3]: 8x8-pixel flat blocks (hard edges, so the bicubic
+    resampler's negative lobes overshoot and the 0/255 clamps are exercised) with per-pixel noise on half of them."""
+    shape = tuple(int(v) for v in shape)
+    *lead, h, w, c = shape
+    nb = int(np.prod(lead)) if lead else 1
+    fine = ((uniform_pm1(name + ".fine", nb * h * w * c, seed) + 1.0) * 128.0).astype(np.int64).clip(0, 255)
+    fine = fine.reshape(nb, h, w, c)
+    bh, bw = (h + 7) // 8, (w + 7) // 8
+    coarse = ((uniform_pm1(name + ".coarse", nb * bh * bw * c, seed) + 1.0) * 128.0).astype(np.int64).clip(0, 255)
+    coarse = np.repeat(np.repeat(coarse.reshape(nb, bh, bw, c), 8, axis=1), 8, axis=2)[:, :h, :w]
+    pick = uniform_pm1(name + ".pick", nb * bh * bw, seed).reshape(nb, bh, bw, 1) > 0.0
+    pick = np.repeat(np.repeat(pick, 8, axis=1), 8, axis=2)[:, :h, :w]
+    out = np.where(pick, coarse, (coarse + fine) // 2).astype(np.uint8)
+    return out.reshape(shape)
+
+
 def tokens(name: str, batch: int, seed: int, context_length: int = 77,
            vocab_size: int = 49408) -> torch.Tensor:
     """Synthetic CLIP token rows: [SOT] ids... [EOT] 0-padding (clip.py:196-232 layout).

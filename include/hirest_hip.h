@@ -244,6 +244,30 @@ int hirest_segmentation_step(const float* logits, int32_t* moment_mask, int32_t*
                              void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Frame preprocessing on device (eva_clip.py:125-153 / clip.py:79-86):
+ *   Resize(size, BICUBIC) -> CenterCrop(size) [-> ToTensor -> Normalize]
+ * on raw RGB uint8 frames [B, in_h, in_w, 3], bit-exact with Pillow's 8-bit resampler
+ * (Image.resize(..., BICUBIC): antialiased separable filter, 22-bit fixed-point weights,
+ * horizontal pass rounded to uint8, then vertical) and torchvision's size / crop rules.
+ * Only the size x size crop is computed.
+ *
+ * The weight tables depend on (in_h, in_w, size) only: hirest_preprocess_plan fills a HOST
+ * blob of hirest_preprocess_plan_bytes bytes (double-precision arithmetic identical to
+ * Pillow's precompute_coeffs/normalize_coeffs_8bpc); the caller copies it to the device once
+ * and passes the device copy to every hirest_preprocess_u8 call.
+ * out_kind 0: uint8 NHWC [B,size,size,3] (feed hirest_vision_forward in_dtype 2: normalisation
+ *             fused into patch extraction);
+ * out_kind 1: f32 NCHW [B,3,size,size] = (x/255 - mean)/std, the reference transform's tensor.
+ * workspace: hirest_preprocess_workspace_bytes (the horizontally resampled rows).
+ * ------------------------------------------------------------------------------------ */
+int64_t hirest_preprocess_plan_bytes(int32_t in_h, int32_t in_w, int32_t size);
+int hirest_preprocess_plan(int32_t in_h, int32_t in_w, int32_t size, void* host_plan, int64_t plan_bytes);
+int64_t hirest_preprocess_workspace_bytes(int32_t in_h, int32_t in_w, int32_t size, int32_t B);
+int hirest_preprocess_u8(const uint8_t* frames, int32_t B, int32_t in_h, int32_t in_w, int32_t size,
+                         const void* plan_dev, void* out, int32_t out_kind, const float* mean3, const float* std3,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Optional per-launch timing (bench.py's live roofline measurement).  When enabled, every
  * GEMM / attention / LayerNorm launch is bracketed by hipEventRecord on ITS launch stream;
  * hirest_profile_collect synchronises those events and returns one record per launch.

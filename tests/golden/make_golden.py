@@ -361,6 +361,44 @@ def gen_caption():
         json.dump(out, f)
 
 
+PREPROCESS_CASES = [  # (name, H, W, size): 360p/720p/1080p video, portrait, 4:3, odd sizes, up-sampling, no-op axes
+    ("360p", 360, 640, 224), ("720p", 720, 1280, 224), ("1080p", 1080, 1920, 224), ("portrait", 640, 360, 224),
+    ("vga", 480, 640, 224), ("odd", 333, 500, 224), ("odd2", 501, 334, 224), ("up", 120, 160, 224),
+    ("same", 224, 224, 224), ("short_ok", 224, 398, 224), ("square", 225, 225, 224), ("tiny28", 37, 53, 28),
+]
+
+
+def gen_preprocess():
+    """image_transform(size) of eva_clip.py:125-153 executed with the real Pillow resampler and torchvision's
+    Resize/CenterCrop/ToTensor/Normalize rules (torchvision itself is not installed; its size bookkeeping is restated
+    in the four lines below).  Stores SHA-256 digests of the uint8 crops and of the fp32 tensors, plus a few rows."""
+    import hashlib
+    from PIL import Image
+    import PIL
+    mean = np.asarray((0.48145466, 0.4578275, 0.40821073), dtype=np.float32).reshape(3, 1, 1)
+    std = np.asarray((0.26862954, 0.26130258, 0.27577711), dtype=np.float32).reshape(3, 1, 1)
+    out = {"pillow": PIL.__version__, "cases": {}}
+    for name, H, W, S in PREPROCESS_CASES:
+        arr = synth.rgb_frames("preprocess." + name, (H, W, 3), 5)
+        img = Image.fromarray(arr)
+        w, h = img.size
+        if not ((w <= h and w == S) or (h <= w and h == S)):       # torchvision Resize(int)
+            nw, nh = (S, int(S * h / w)) if w < h else (int(S * w / h), S)
+            img = img.resize((nw, nh), Image.BICUBIC)
+        w, h = img.size
+        left, top = int(round((w - S) / 2.0)), int(round((h - S) / 2.0))   # torchvision CenterCrop
+        img = img.crop((left, top, left + S, top + S)).convert("RGB")
+        u8 = np.asarray(img, dtype=np.uint8)
+        f32 = (u8.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0) - mean) / std
+        out["cases"][name] = {"H": H, "W": W, "size": S, "resized": [w, h], "crop": [left, top],
+                              "sha256_u8": hashlib.sha256(np.ascontiguousarray(u8).tobytes()).hexdigest(),
+                              "sha256_f32": hashlib.sha256(np.ascontiguousarray(f32).tobytes()).hexdigest(),
+                              "row0_u8": u8[0, :8].tolist(), "mid_u8": u8[S // 2, S // 2 - 4:S // 2 + 4].tolist()}
+        print(name, out["cases"][name]["resized"], out["cases"][name]["sha256_u8"][:16])
+    with open(os.path.join(HERE, "preprocess.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -380,6 +418,7 @@ def main():
         "eva_g14": lambda: gen_eva("eva_g14", synth.EVA_CLIP_G_14, 3, 2, 8),
         "joint": gen_joint,
         "caption": gen_caption,
+        "preprocess": gen_preprocess,
     }
     for name, fn in jobs.items():
         if args.only and name not in args.only:
