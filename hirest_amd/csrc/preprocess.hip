@@ -88,47 +88,131 @@ inline int64_t plan_words(const Geometry& g, int size) {
     return 16 + (int64_t)size * 2 + (int64_t)g.ksh * size + (int64_t)size * 2 + (int64_t)size * g.ksv;
 }
 
-// ---- pass 1: horizontal.  One block per (input row, frame); lanes = output columns. ----
+// ---- pass 1: horizontal.  One block per (band of H_ROWS input rows, frame); lanes = output columns.
+// The weight table is staged in LDS once per block; input rows are double-buffered (row i+1 is in flight in
+// registers while row i is resampled), so a block's global latency is paid once, not once per tap.
+constexpr int H_ROWS = 8;
+constexpr int H_MAXW = 12;                       // row dwords per thread: rows up to 256*12*4 = 12288 B (4096 px)
+
+__device__ __forceinline__ uint32_t row_word(const uint8_t* rowp, const uint32_t* ap, int i, int nd, int mis, int nbytes) {
+    if (i == 0 || i == nd - 1) {                 // edge words: never touch bytes outside this row's span
+        uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) {
+            int idx = i * 4 + k - mis;
+            if (idx >= 0 && idx < nbytes) v |= (uint32_t)rowp[idx] << (8 * k);
+        }
+        return v;
+    }
+    return ap[i];
+}
+
 __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ frames, int in_h, int in_w, int size,
                                                          int row0, int nrows, int col0, int ncols, int ksh,
                                                          const int32_t* __restrict__ hb, const int32_t* __restrict__ hk,
-                                                         uint8_t* __restrict__ tmp) {
+                                                         uint8_t* __restrict__ tmp, int row_words) {
     extern __shared__ uint32_t lds32[];
-    const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const uint8_t* rowp = frames + (((size_t)b * in_h + row0 + r) * in_w + col0) * 3;
+    int32_t* coef = (int32_t*)lds32;                                   // [ksh][size]
+    uint32_t* rowbuf = lds32 + ksh * size;                             // [2][row_words]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int r_begin = blockIdx.x * H_ROWS, r_end = min(r_begin + H_ROWS, nrows);
     const int nbytes = ncols * 3;
-    const int mis = (int)((uintptr_t)rowp & 3);
-    const uint32_t* ap = (const uint32_t*)(rowp - mis);
-    const int nd = (mis + nbytes + 3) >> 2;
-    for (int i = tid; i < nd; i += 256) {
-        uint32_t v;
-        if (i == 0 || i == nd - 1) {            // edge words: never touch bytes outside this row's span
-            v = 0;
-            for (int k = 0; k < 4; ++k) {
-                int idx = i * 4 + k - mis;
-                if (idx >= 0 && idx < nbytes) v |= (uint32_t)rowp[idx] << (8 * k);
-            }
-        } else v = ap[i];
-        lds32[i] = v;
-    }
-    __syncthreads();
-    const uint8_t* row = (const uint8_t*)lds32 + mis;
-    for (int x = tid; x < size; x += 256) {
-        const int lo = hb[2 * x] - col0, n = hb[2 * x + 1];
-        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-        const uint8_t* p = row + lo * 3;
-        for (int t = 0; t < n; ++t) {
-            const int k = hk[t * size + x];
-            a0 += (int)p[3 * t] * k; a1 += (int)p[3 * t + 1] * k; a2 += (int)p[3 * t + 2] * k;
+    for (int i = tid; i < ksh * size; i += 256) coef[i] = hk[i];
+
+    uint32_t v[H_MAXW] = {};
+    auto fetch = [&](int r) {
+        const uint8_t* rowp = frames + (((size_t)b * in_h + row0 + r) * in_w + col0) * 3;
+        const int mis = (int)((uintptr_t)rowp & 3);
+        const uint32_t* ap = (const uint32_t*)(rowp - mis);
+        const int nd = (mis + nbytes + 3) >> 2;
+#pragma unroll
+        for (int j = 0; j < H_MAXW; ++j) {
+            const int i = tid + j * 256;
+            if (i < nd) v[j] = row_word(rowp, ap, i, nd, mis, nbytes);
         }
-        uint8_t* o = tmp + (((size_t)b * nrows + r) * size + x) * 3;
-        o[0] = (uint8_t)min(max(a0 >> PRECISION_BITS, 0), 255);
-        o[1] = (uint8_t)min(max(a1 >> PRECISION_BITS, 0), 255);
-        o[2] = (uint8_t)min(max(a2 >> PRECISION_BITS, 0), 255);
+        return mis;
+    };
+    auto stash = [&](uint32_t* dst) {
+#pragma unroll
+        for (int j = 0; j < H_MAXW; ++j) {
+            const int i = tid + j * 256;
+            if (i < row_words) dst[i] = v[j];
+        }
+    };
+    int mis = fetch(r_begin);
+    stash(rowbuf);
+    __syncthreads();
+    for (int r = r_begin; r < r_end; ++r) {
+        const int cur = (r - r_begin) & 1;
+        int mis_next = 0;
+        if (r + 1 < r_end) mis_next = fetch(r + 1);
+        const uint8_t* row = (const uint8_t*)(rowbuf + cur * row_words) + mis;
+        for (int x = tid; x < size; x += 256) {
+            const int lo = hb[2 * x] - col0, n = hb[2 * x + 1];
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+            const uint8_t* p = row + lo * 3;
+#pragma unroll 4
+            for (int t = 0; t < n; ++t) {
+                const int k = coef[t * size + x];
+                a0 += (int)p[3 * t] * k; a1 += (int)p[3 * t + 1] * k; a2 += (int)p[3 * t + 2] * k;
+            }
+            uint8_t* o = tmp + (((size_t)b * nrows + r) * size + x) * 3;
+            o[0] = (uint8_t)min(max(a0 >> PRECISION_BITS, 0), 255);
+            o[1] = (uint8_t)min(max(a1 >> PRECISION_BITS, 0), 255);
+            o[2] = (uint8_t)min(max(a2 >> PRECISION_BITS, 0), 255);
+        }
+        if (r + 1 < r_end) stash(rowbuf + (cur ^ 1) * row_words);
+        mis = mis_next;
+        __syncthreads();
     }
 }
 
-// ---- pass 2: vertical.  One block per (output row, frame); lanes = bytes of the row (x, c). ----
+// ---- pass 2: vertical.  One block per (band of V_ROWS output rows, frame). ----
+constexpr int V_ROWS = 8;
+
+template <int KIND>
+__device__ __forceinline__ void emit(void* out, int b, int y, int j, int size, int v, const float* mean3, const float* std3) {
+    if (KIND == 0) {
+        ((uint8_t*)out)[((size_t)b * size + y) * size * 3 + j] = (uint8_t)v;
+    } else {
+        const int x = j / 3, c = j - 3 * x;
+        ((float*)out)[(((size_t)b * 3 + c) * size + y) * size + x] = ((float)v / 255.0f - mean3[c]) / std3[c];
+    }
+}
+
+// word path: lanes = 4 consecutive bytes of a resampled row (row bytes % 4 == 0, workspace 4-byte aligned)
+template <int KIND>
+__global__ __launch_bounds__(256) void resample_v_kernel_w(const uint32_t* __restrict__ tmp, int size, int row0, int nrows, int ksv,
+                                                           const int32_t* __restrict__ vb, const int32_t* __restrict__ vk,
+                                                           void* __restrict__ out, const float* __restrict__ mean3,
+                                                           const float* __restrict__ std3) {
+    const int b = blockIdx.y;
+    const int wpr = size * 3 / 4;
+    const int y_begin = blockIdx.x * V_ROWS, ny = min(V_ROWS, size - y_begin);
+    for (int item = threadIdx.x; item < ny * wpr; item += 256) {
+        const int y = y_begin + item / wpr, j = item % wpr;
+        const int lo = vb[2 * y] - row0, n = vb[2 * y + 1];
+        const uint32_t* src = tmp + ((size_t)b * nrows + lo) * wpr + j;
+        const int32_t* k = vk + (size_t)y * ksv;
+        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll 4
+        for (int t = 0; t < n; ++t) {
+            const uint32_t w = src[(size_t)t * wpr];
+            const int kt = k[t];
+            a0 += (int)(w & 255) * kt; a1 += (int)((w >> 8) & 255) * kt;
+            a2 += (int)((w >> 16) & 255) * kt; a3 += (int)(w >> 24) * kt;
+        }
+        const int v0 = min(max(a0 >> PRECISION_BITS, 0), 255), v1 = min(max(a1 >> PRECISION_BITS, 0), 255);
+        const int v2 = min(max(a2 >> PRECISION_BITS, 0), 255), v3 = min(max(a3 >> PRECISION_BITS, 0), 255);
+        if (KIND == 0) {
+            ((uint32_t*)out)[((size_t)b * size + y) * wpr + j] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+        } else {
+            emit<1>(out, b, y, 4 * j, size, v0, mean3, std3); emit<1>(out, b, y, 4 * j + 1, size, v1, mean3, std3);
+            emit<1>(out, b, y, 4 * j + 2, size, v2, mean3, std3); emit<1>(out, b, y, 4 * j + 3, size, v3, mean3, std3);
+        }
+    }
+}
+
+// byte path for sizes whose rows are not whole words
 template <int KIND>
 __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restrict__ tmp, int size, int row0, int nrows, int ksv,
                                                          const int32_t* __restrict__ vb, const int32_t* __restrict__ vk,
@@ -142,13 +226,7 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restri
     for (int j = threadIdx.x; j < rb; j += 256) {
         int acc = 1 << (PRECISION_BITS - 1);
         for (int t = 0; t < n; ++t) acc += (int)src[(size_t)t * rb + j] * k[t];
-        const int v = min(max(acc >> PRECISION_BITS, 0), 255);
-        if (KIND == 0) {
-            ((uint8_t*)out)[((size_t)b * size + y) * rb + j] = (uint8_t)v;
-        } else {
-            const int x = j / 3, c = j - 3 * x;
-            ((float*)out)[(((size_t)b * 3 + c) * size + y) * size + x] = ((float)v / 255.0f - mean3[c]) / std3[c];
-        }
+        emit<KIND>(out, b, y, j, size, min(max(acc >> PRECISION_BITS, 0), 255), mean3, std3);
     }
 }
 
@@ -207,15 +285,27 @@ extern "C" int hirest_preprocess_u8(const uint8_t* frames, int32_t B, int32_t in
     const int32_t* vb = hk + (int64_t)g.ksh * size;
     const int32_t* vk = vb + 2 * size;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = ((size_t)g.ncols * 3 + 3 + 3) / 4 * 4 + 4;
-    if (lds > 64 * 1024) return HIREST_E_BADARG;
-    hipLaunchKernelGGL(resample_h_kernel, dim3(g.nrows, B), dim3(256), lds, s, frames, in_h, in_w, size, g.row0, g.nrows,
-                       g.col0, g.ncols, g.ksh, hb, hk, (uint8_t*)workspace);
-    if (out_kind == 0)
+    const int row_words = (g.ncols * 3 + 3 + 3) / 4 + 1;
+    if (row_words > 256 * H_MAXW) return HIREST_E_SHAPE;                     // frames wider than 4096 px
+    const size_t lds = ((size_t)g.ksh * size + 2 * (size_t)row_words) * 4;
+    if (lds > 64 * 1024) return HIREST_E_SHAPE;
+    hipLaunchKernelGGL(resample_h_kernel, dim3((g.nrows + H_ROWS - 1) / H_ROWS, B), dim3(256), lds, s, frames, in_h, in_w, size,
+                       g.row0, g.nrows, g.col0, g.ncols, g.ksh, hb, hk, (uint8_t*)workspace, row_words);
+    const bool words = (size * 3) % 4 == 0 && ((uintptr_t)workspace & 3) == 0 && ((uintptr_t)out & 3) == 0;
+    if (words) {
+        const dim3 grid((size + V_ROWS - 1) / V_ROWS, B);
+        if (out_kind == 0)
+            hipLaunchKernelGGL(resample_v_kernel_w<0>, grid, dim3(256), 0, s, (const uint32_t*)workspace, size, g.row0, g.nrows,
+                               g.ksv, vb, vk, out, mean3, std3);
+        else
+            hipLaunchKernelGGL(resample_v_kernel_w<1>, grid, dim3(256), 0, s, (const uint32_t*)workspace, size, g.row0, g.nrows,
+                               g.ksv, vb, vk, out, mean3, std3);
+    } else if (out_kind == 0) {
         hipLaunchKernelGGL(resample_v_kernel<0>, dim3(size, B), dim3(256), 0, s, (const uint8_t*)workspace, size, g.row0,
                            g.nrows, g.ksv, vb, vk, out, mean3, std3);
-    else
+    } else {
         hipLaunchKernelGGL(resample_v_kernel<1>, dim3(size, B), dim3(256), 0, s, (const uint8_t*)workspace, size, g.row0,
                            g.nrows, g.ksv, vb, vk, out, mean3, std3);
+    }
     return hirest_launch_status();
 }

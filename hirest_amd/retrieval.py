@@ -36,8 +36,17 @@ def subsample_ids(n_frames: int, n_model_frames: int) -> np.ndarray:
 def encode_videos(model, frames: torch.Tensor, normalize_frames_first: bool = False,
                   return_frame_embeds: bool = False):
     """frames [V,F,3,S,S] (or uint8 [V,F,S,S,3]) -> pooled, L2-normalised [V,E] fp32
-    (inference_video_retrieval.py:266-285)."""
+    (inference_video_retrieval.py:266-285).  Raw decoded uint8 frames [V,F,H,W,3] of any resolution are resized and
+    cropped on the device first (the ``preprocess(Image.open(...))`` of :267-269 / extract_features.py:46-50)."""
     V, F = frames.shape[0], frames.shape[1]
+    size = getattr(getattr(model, "visual", None), "image_size", None)
+    if frames.dtype == torch.uint8 and size is not None and tuple(frames.shape[2:4]) != (size, size):
+        from .preprocess import FramePreprocessor
+        pre = getattr(model, "_frame_preprocessor", None)
+        if pre is None:
+            pre = FramePreprocessor(size, getattr(model.visual, "image_mean", None), getattr(model.visual, "image_std", None))
+            object.__setattr__(model, "_frame_preprocessor", pre)
+        frames = pre(frames.reshape((V * F,) + tuple(frames.shape[2:]))).reshape(V, F, size, size, 3)
     fe = model.encode_image(frames.reshape((V * F,) + tuple(frames.shape[2:]))).float().reshape(V, F, -1)
     pooled = ops.pool_l2norm(fe.contiguous(), normalize_frames_first)
     return (pooled, fe) if return_frame_embeds else pooled

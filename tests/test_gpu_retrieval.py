@@ -57,3 +57,26 @@ def test_retrieval_matched_recall_and_shard_invariance():
     assert torch.equal(both, pooled)
     _, _, idx2 = retrieval.retrieve(texts, both, 10)
     assert torch.equal(idx2.cpu().long(), idx)
+
+
+def test_raw_uint8_videos_are_preprocessed_on_device():
+    """encode_videos on raw decoded frames [V,F,H,W,3] uint8 == preprocess on the CPU oracle (Pillow-exact resize +
+    crop), then the oracle encoder: the extract_features.py:46-60 flow end to end."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import hirest_amd
+    from hirest_amd import retrieval
+    from oracle import preprocess_cpu as P
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    cfg, seed = synth.EVA_CLIP_TINY, 11
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}")
+    model = model.to(dev).eval()
+    sd = synth.eva_clip_state_dict(cfg, seed)
+    V, F = 3, 2
+    raw = synth.rgb_frames("ret.raw", (V, F, 270, 480, 3), 8)
+    pooled = retrieval.encode_videos(model, torch.from_numpy(raw).to(dev)).cpu()
+    x = np.stack([P.image_transform(raw[v, f], 224) for v in range(V) for f in range(F)])
+    ref = O.pool_video(O.eva_encode_image(sd, torch.from_numpy(x), cfg).reshape(V, F, -1))
+    cos = torch.nn.functional.cosine_similarity(pooled, ref, dim=-1)
+    assert cos.min().item() > 0.999, cos

@@ -150,6 +150,13 @@ def test_gpu_preprocess_unaligned_views_and_properties():
         out = pre(x[1:4]).cpu().numpy()                        # sliced view: base pointer offset by one odd-sized frame
         for i in range(3):
             assert np.array_equal(out[i], P.transform_u8(arr[1 + i], 224))
+    pre30 = FramePreprocessor(30)                              # 90-byte rows: the byte-wise vertical kernel
+    arr = synth.rgb_frames("preprocess.s30", (2, 77, 131, 3), 4)
+    out = pre30(torch.from_numpy(arr).to(dev)).cpu().numpy()
+    f32 = pre30(torch.from_numpy(arr).to(dev), normalized=True).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(out[i], P.transform_u8(arr[i], 30))
+        assert np.array_equal(f32[i], P.to_tensor_normalize(out[i]))
     const = torch.full((2, 360, 640, 3), 201, dtype=torch.uint8, device=dev)
     assert (pre(const) == 201).all()
     same = torch.from_numpy(synth.rgb_frames("preprocess.same", (2, 224, 224, 3), 1)).to(dev)
