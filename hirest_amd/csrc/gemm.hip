@@ -756,6 +756,327 @@ __global__ __launch_bounds__(512) void gemm_t256q(GemmP p) {
     epilogue_256<EPI>(p, acc, smem + wave * STG_BYTES, M0 + wr * 128, N0 + wc * 64, lane);
 }
 
+
+// =================================================================================================
+// Kernel "p256": PERSISTENT version of t256q.  One workgroup per CU walks its XCD's tile list; the LDS-DMA
+// stream is continuous across tiles (while the last two K steps of tile i are multiplied, the first two steps
+// of tile i+1 are already landing in the ring), so there is no per-tile prologue, no dummy refetch at the end
+// of a tile and no workgroup launch / drain per tile.  Other changes against t256q:
+//   * one barrier per 64-deep step (the barrier in front of the first half-step protected nothing);
+//   * the epilogue stages through a wave-private 4-KiB XOR-swizzled area BEHIND the ring (ring 128 KiB +
+//     staging = 160 KiB for 8 waves), so the ring keeps receiving the next tile during the epilogue;
+//   * DMA addresses are (uniform tile base + k) in SGPRs + one 32-bit per-lane offset per piece;
+//   * 8-wave form: the two waves of a SIMD (w, w+4) own different column halves, so in a ragged N edge tile
+//     (N = 1408 = 5.5 tiles) every SIMD keeps one active wave and the tile takes half the time;
+//   * WN = 128 gives the 4-wave form (2x2 waves of 128x128, accumulators in AGPRs): 2/3 of the LDS fragment
+//     reads per FLOP.
+// Comparison that motivated it (rocprofv3 PMC, fc1 shape, same clocks ~1.6 GHz): hipBLASLt's 256x256x64
+// stream-K kernel keeps the matrix pipe 72 % busy, t256q 58 %.
+// =================================================================================================
+constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128 B
+
+// Epilogue of p256: accumulators are 16x16 MFMA tiles, acc[mi][ni][e] = C[mi*16 + (lane&15)][ni*16 + 4*(lane>>4) + e]
+// (operands swapped, so a lane owns 4 consecutive columns of one row).  16 rows at a time go through a wave-private
+// XOR-swizzled staging area so that HBM sees whole 128-B lines.
+template <int EPI, int NI>
+__device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
+    constexpr bool OUT_BF16 = (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_QGELU_BF16);
+    const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;   // sw = srow & 7
+    const int rr = lane >> 3, rc = lane & 7;                     // read-back: row (it*8 + rr), 16-B chunk rc
+    if constexpr (OUT_BF16) {
+        bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+        for (int jp = 0; jp < NI; jp += 4) {                     // 64-column groups
+            f32x4 bv[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int col = Nw + (jp + n) * 16 + 4 * kg;
+                bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    f32x4 v = acc[mi][jp + n] + bv[n];
+                    if constexpr (EPI == HIREST_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if constexpr (EPI == HIREST_EPI_BIAS_QGELU_BF16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((n * 2 + (kg >> 1)) ^ sw) << 4) + (kg & 1) * 8) = o;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const int mb = Mw + mi * 16;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int r = it * 8 + rr;
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
+                    const int m = mb + r, n = Nw + jp * 16 + rc * 8;
+                    if (m < p.M) {
+                        bf16_t* dst = outp + (int64_t)m * p.ldo + n;
+                        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+                        else if (n + 4 <= p.N) *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    } else {
+        float* outp = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int jp = 0; jp < NI; jp += 2) {                     // 32-column groups
+            f32x4 bv[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = Nw + (jp + n) * 16 + 4 * kg;
+                bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int mq = 0; mq < 8; mq += 2) {                  // two 16-row passes share one batch of operand loads
+                f32x4 o[4];
+                int64_t off[4];
+                bool ok[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = Mw + mq * 16 + it * 8 + rr, n = Nw + jp * 16 + rc * 4;
+                    ok[it] = m < p.M && n < p.N;
+                    if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
+                        const int mm = ok[it] ? m : 0;
+                        const int b = mm / p.P, pp = mm - b * p.P;
+                        off[it] = ((int64_t)b * (p.P + 1) + 1 + pp) * p.ldo + n;
+                        o[it] = ok[it] ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else {
+                        off[it] = (int64_t)m * p.ldo + n;
+                        if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32)
+                            o[it] = ok[it] ? *reinterpret_cast<const f32x4*>(outp + off[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f32x4 v = acc[mq + sp][jp + n] + bv[n];
+                        *reinterpret_cast<f32x4*>(stg + srow * 128 + (((n * 4 + kg) ^ sw) << 4)) = v;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int r = it * 8 + rr;
+                        f32x4 w = *reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
+                        if constexpr (EPI != HIREST_EPI_BIAS_F32) w += o[sp * 2 + it];
+                        if (ok[sp * 2 + it]) *reinterpret_cast<f32x4*>(outp + off[sp * 2 + it]) = w;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int WN>
+__global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
+    constexpr int NW = 512 / WN;        // 8 or 4 waves: 2 (M) x NW/2 (N)
+    constexpr int NI = WN / 16;         // 16-column MFMA tiles per wave (4 or 8); 8 16-row tiles
+    constexpr int PPW = 32 / NW;        // LDS-DMA pieces per operand per wave per step
+    constexpr int NR = 8 + NI;          // fragment reads per 32-deep half-step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wr, wc;
+    if constexpr (NW == 8) { wr = (wave >> 1) & 1; wc = (wave & 1) + 2 * (wave >> 2); }
+    else { wr = wave >> 1; wc = wave & 1; }
+
+    // ---- this block's tile list: XCD (bid & 7) owns M panels [p_lo, p_lo+np); its CUs take every nslot-th tile
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3, nslot = gridDim.x >> 3;
+    const int p_lo = xcd * p.ppx;
+    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    if (np <= 0) return;
+    const int ntile = np * p.nbn;
+    if (slot >= ntile) return;
+    // Tile order inside the XCD.  The ~32 tiles in flight should form a near-square patch (a panels x b column tiles,
+    // a + b minimal) so that every operand line is shared by several CUs through the XCD's L2.  Few column tiles
+    // (N = 1408: 6): panel-major, all column tiles of a panel together -> the long-K A panel (3 MB at K = 6144) comes
+    // from HBM once instead of once per column group.  Many column tiles: GROUP_M panels x 4 column tiles.
+    const bool panel_major = p.nbn <= 8;
+    auto tile_origin = [&](int j, int& M0, int& N0) {
+        if (panel_major) {
+            const int mt_i = j / p.nbn;
+            M0 = (p_lo + mt_i) * T_BM; N0 = (j - mt_i * p.nbn) * T_BN;
+            return;
+        }
+        const int grp = j / (GROUP_M * p.nbn);
+        const int r = j - grp * GROUP_M * p.nbn;
+        int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
+        const int nt_i = r / gcount, mt_i = p_lo + grp * GROUP_M + (r - nt_i * gcount);
+        M0 = mt_i * T_BM; N0 = nt_i * T_BN;
+    };
+
+    // ---- LDS-DMA stream state (runs up to two K steps ahead of the MFMAs, across tile boundaries)
+    const int nst = p.K / Q_BK;
+    uint32_t a_off[PPW], w_off[PPW];
+    const char* a_base; const char* w_base;
+    auto set_sources = [&](int M0, int N0) {
+        if (p.dbg & 4) { M0 = 0; N0 = 0; }      // timing experiment: every tile streams tile (0,0)'s operands (L2-resident)
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int row = (wave * PPW + q) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            int ra = p.M - 1 - M0; ra = row < ra ? row : ra;
+            int rn = p.N - 1 - N0; rn = row < rn ? row : rn;
+            a_off[q] = (uint32_t)(ra * (int)p.lda + chunk * 8) * 2u;
+            w_off[q] = (uint32_t)(rn * (int)p.ldw + chunk * 8) * 2u;
+        }
+        a_base = reinterpret_cast<const char*>(p.A + (int64_t)M0 * p.lda);
+        w_base = reinterpret_cast<const char*>(p.W + (int64_t)N0 * p.ldw);
+    };
+    int dma_j = slot, dma_k = 0, dma_g = 0;
+    bool dma_live = true;
+    auto stage = [&]() {   // issue the next step of the stream into ring slot dma_g & 1
+        if (p.dbg & 1) return;                  // timing experiment: no LDS-DMA in the loop
+        char* buf = smem + (dma_g & 1) * Q_STEP + wave * (PPW * 1024);
+        const char* ab = a_base + (int64_t)dma_k * (Q_BK * 2);
+        const char* wb = w_base + (int64_t)dma_k * (Q_BK * 2);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) glds16(ab + a_off[q], buf + q * 1024);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) glds16(wb + w_off[q], buf + Q_WOFF + q * 1024);
+    };
+    auto advance = [&]() {   // wave-uniform; past the last tile the stream refetches its last step (never consumed)
+        ++dma_g;
+        if (dma_live && ++dma_k == nst) {
+            dma_j += nslot;
+            if (dma_j < ntile) { int m0, n0; tile_origin(dma_j, m0, n0); set_sources(m0, n0); dma_k = 0; }
+            else { dma_live = false; dma_k = nst - 1; }
+        }
+    };
+
+    // ---- fragments of v_mfma_f32_16x16x32_bf16: lane -> row (lane & 15), 8 consecutive k at 8 * (lane >> 4)
+    const int frow = lane & 15, fsw = (frow >> 1) & 7, kg = lane >> 4;
+    const int a_frag = (wr * 128 + frow) * (Q_BK * 2);
+    const int w_frag = Q_WOFF + (wc * WN + frow) * (Q_BK * 2);
+    int koff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) koff[h] = ((4 * h + kg) ^ fsw) << 4;
+
+    struct Frags { bf16x8 w[NI]; bf16x8 a[8]; };
+    Frags f0, f1;
+    auto load_frags = [&](const char* buf, int h, Frags& f) {
+#pragma unroll
+        for (int n = 0; n < NI; ++n) f.w[n] = *reinterpret_cast<const bf16x8*>(buf + w_frag + n * 16 * 128 + koff[h]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f.a[m] = *reinterpret_cast<const bf16x8*>(buf + a_frag + m * 16 * 128 + koff[h]);
+    };
+    f32x4 acc[8][NI];
+    auto mfma_half = [&](Frags& fc) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < NI; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc.w[n], fc.a[m], acc[m][n], 0, 0, 0);
+    };
+
+    // ---- prologue of the stream: steps 0 and 1
+    {
+        int m0, n0;
+        tile_origin(slot, m0, n0);
+        set_sources(m0, n0);
+    }
+    stage(); advance();
+    HX_WAIT_VM(0);                       // step 0 landed
+    stage(); advance();
+    __builtin_amdgcn_s_barrier();
+
+    char* stg = smem + 2 * Q_STEP + wave * P_STG;
+    int g = 0;   // global step index of the MFMA side: step g lives in ring slot g & 1
+    for (int j = slot; j < ntile; j += nslot) {
+        int M0, N0;
+        tile_origin(j, M0, N0);
+        const bool active = (N0 + wc * WN < p.N) && (M0 + wr * 128 < p.M);
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            load_frags(smem + (g & 1) * Q_STEP, 0, f0);
+            for (int t = 0; t < nst; ++t, ++g) {
+                const char* cur = smem + (g & 1) * Q_STEP;
+                const char* nxt = smem + ((g + 1) & 1) * Q_STEP;
+                // ---- first half: k 0..31 of step g | read the second half's fragments
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(cur, 1, f1);
+                mfma_half(f0);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- second half: step g+1 has landed everywhere and nobody reads slot g&1 any more after the
+                // barrier -> read step g+1's first fragments, refill slot g&1 with step g+2, k 32..63 of step g
+                HX_WAIT_VM(0);
+                HX_WAIT_LGKM0();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(nxt, 0, f0);          // (at the end of a tile: the next tile's step 0 — reloaded below)
+                stage();
+                mfma_half(f1);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * PPW; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                advance();
+            }
+            epilogue_p<EPI, NI>(p, acc, stg, M0 + wr * 128, N0 + wc * WN, lane);
+        } else {
+            for (int t = 0; t < nst; ++t, ++g) {
+                HX_WAIT_VM(0);
+                __builtin_amdgcn_s_barrier();
+                stage();
+                advance();
+            }
+        }
+    }
+    HX_WAIT_VM(0);
+}
+
+template <int EPI, int WN>
+int launch_p256(GemmP p, hipStream_t s) {
+    static bool configured = false;
+    static int cus = 0;
+    auto kern = gemm_p256<EPI, WN>;
+    constexpr int NW = 512 / WN;
+    constexpr int LDS = 2 * Q_STEP + NW * P_STG;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        int dev = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+        configured = true;
+    }
+    p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
+    p.ppx = (p.nbm + 7) / 8;
+    int nslot = cus / 8; nslot = nslot < 1 ? 1 : nslot;
+    const int per_xcd = p.ppx * p.nbn;
+    if (nslot > per_xcd) nslot = per_xcd;
+    hipLaunchKernelGGL(kern, dim3(8 * nslot), dim3(64 * NW), LDS, s, p);
+    return hirest_launch_status();
+}
+
 template <int EPI>
 int launch256q(GemmP p, hipStream_t s) {
     static bool configured = false;
@@ -812,7 +1133,9 @@ int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 w
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
-    if (g_force_kernel == 5 || (g_force_kernel == 0 && big)) return launch256q<EPI>(p, s);
+    if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);
+    if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
+    if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
     if (g_force_kernel == 3) return launch256<EPI, 5>(p, s);
@@ -827,7 +1150,7 @@ int g_gemm_dbg = 0;
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    if (which < 0 || which > 5) return HIREST_E_BADARG;
+    if (which < 0 || which > 7) return HIREST_E_BADARG;
     g_force_kernel = which;
     return 0;
 }

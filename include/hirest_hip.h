@@ -71,11 +71,13 @@ typedef struct hirest_gemm_args {
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
 /* Kernel selection for tests / A-B timing: 0 = automatic (default), 1 = force the 128x128 kernel,
- * 2 / 3 = force the 256x256 ping-pong kernel with a 4- / 5-slot LDS ring.  Results are identical
+ * 2 / 3 = the 256x256 ping-pong kernel with a 4- / 5-slot LDS ring, 4 = t256p (32-deep slabs), 5 = t256q
+ * (64-deep steps), 6 / 7 = the persistent 256x256 kernel with 8 / 4 waves.  Results are identical
  * (same k order per output element). */
 int hirest_gemm_select_kernel(int32_t which);
 /* TIMING EXPERIMENTS ONLY (results become wrong): bit0 = skip the main-loop LDS-DMA, bit1 = skip the
- * main-loop barrier and waits of the t256p kernel.  0 restores normal operation. */
+ * main-loop barrier and waits of the t256p kernel, bit2 = the persistent kernel streams tile (0,0)'s operands for
+ * every tile (L2-resident operands).  0 restores normal operation. */
 int hirest_gemm_debug_mode(int32_t bits);
 
 /* ------------------------------------------------------------------------------------

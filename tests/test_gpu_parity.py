@@ -53,7 +53,7 @@ def cos_rows(a, b):
 # ----------------------------------------------------------------------------------------
 # kernels
 # ----------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["t128", "t256x4", "t256x5", "t256p", "t256q"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7], ids=["t128", "t256x4", "t256x5", "t256p", "t256q", "p256w8", "p256w4"])
 def gemm_kernel(request, ops):
     ops.gemm_select_kernel(request.param)
     yield request.param
@@ -61,7 +61,8 @@ def gemm_kernel(request, ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 132, 128), (257, 1408, 1408), (1000, 4224, 1408), (77, 768, 3072),
-                                   (513, 260, 64), (2056, 1408, 6144)])
+                                   (513, 260, 64), (2056, 1408, 6144),
+                                   (6151, 2100, 192)])   # > 32 tiles per XCD, odd step count: persistent blocks walk several tiles
 def test_gemm_epilogues(dev, ops, gemm_kernel, M, N, K):
     from hirest_amd import _lib
     a = synth.tensor("g.a", (M, K), 1.0, 7)

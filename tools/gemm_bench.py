@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--shapes", nargs="*", default=["qkv", "proj", "fc1", "fc2", "fc1_nogelu"])
     ap.add_argument("--alias", action="store_true", help="lda=ldw=0: every row aliases row 0 (operands stay cache-resident): "
                     "kernel-structure ceiling without the memory system")
+    ap.add_argument("--hipblaslt", action="store_true", help="also time torch.mm (hipBLASLt, no epilogue) as a yardstick")
     ap.add_argument("--dbg", type=int, default=0, help="hirest_gemm_debug_mode bits (timing experiments)")
     a = ap.parse_args()
     _lib.load().hirest_gemm_debug_mode(a.dbg)
@@ -55,6 +56,18 @@ def main():
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             print(f"{'[alias] ' if a.alias else ''}{'[dbg%d] ' % a.dbg if a.dbg else ''}{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+        if a.hipblaslt:
+            Wt = W.t()
+            for _ in range(2):
+                torch.mm(A, Wt)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                torch.mm(A, Wt)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print(f"{name:11s} M={M} N={N} K={K} torch.mm (hipBLASLt, plain bf16 out): {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
         ops.gemm_select_kernel(0)
         del A, W, out
 
