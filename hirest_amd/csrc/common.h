@@ -30,22 +30,42 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// nn.GELU() default (erf form) and CLIP's QuickGELU.
-// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-rounding class, far below the
-// bf16 ulp of every consumer of this value): branch-free, 1 rcp + 1 exp, ~1/3 the VALU work of
-// ocml's erff in the GEMM epilogue.  This is still the exact-erf GELU, not the tanh approximation.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __expf(-ax * ax);
-    const float r = fmaf(-poly * t, e, 1.0f);
-    return copysignf(r, x);
+// nn.GELU() default (exact erf form, vit_model.py:49) and CLIP's QuickGELU.
+//   gelu(x) = x * Phi(x) = max(x, 0) - |x| * Phi(-|x|),   Phi(-a) = 0.5 * erfc(a / sqrt 2) = exp2(Q(a))
+// Q = degree-8 polynomial fit of log2(0.5 * erfcx(a / sqrt 2)) on [0, 9.4] with the -a^2/2 * log2(e) term folded into
+// its quadratic coefficient.  One v_exp_f32 and 8 FMAs per element (packed two-wide), no division; the older
+// Abramowitz-Stegun 7.1.26 form needed v_rcp + v_exp + 10 more ops and cost 12 % of the fc1 GEMM.  Checked against
+// x * ndtr(x) in float64 on 2M points of [-12, 12] (tools/gelu_fit.py): max abs error 1.1e-6, relative error <= 2e-5
+// everywhere on |x| <= 9.4 (i.e. <= 0.005 bf16 ulp of the value this feeds, tails included).  Beyond 9.4 the
+// correction term is clamped (|error| < 3e-20).  This is still the exact-erf GELU, not the tanh approximation.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fminf(fabsf(x), 9.4f);
+    float q = 6.909084504513885e-08f;
+    q = fmaf(q, a, -3.464947212705738e-06f);
+    q = fmaf(q, a, 7.678331166971475e-05f);
+    q = fmaf(q, a, -0.0010009667603299022f);
+    q = fmaf(q, a, 0.008675649762153625f);
+    q = fmaf(q, a, -0.05414620041847229f);
+    q = fmaf(q, a, -0.45840057730674744f);
+    q = fmaf(q, a, -1.1512391567230225f);
+    q = fmaf(q, a, -0.9999977350234985f);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// two-wide form: the Horner chain compiles to v_pk_fma_f32
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 a = {fminf(fabsf(x[0]), 9.4f), fminf(fabsf(x[1]), 9.4f)};
+    f32x2 q = f32x2{6.909084504513885e-08f, 6.909084504513885e-08f} * a + -3.464947212705738e-06f;
+    q = q * a + 7.678331166971475e-05f;
+    q = q * a + -0.0010009667603299022f;
+    q = q * a + 0.008675649762153625f;
+    q = q * a + -0.05414620041847229f;
+    q = q * a + -0.45840057730674744f;
+    q = q * a + -1.1512391567230225f;
+    q = q * a + -0.9999977350234985f;
+    const f32x2 phi = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f32x2 pos = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return pos - a * phi;
+}
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
 // Async global -> LDS copy of 16 bytes per lane (LDS-DMA).  `lds_wave_base` must be

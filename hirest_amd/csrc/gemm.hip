@@ -799,8 +799,8 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                 for (int n = 0; n < 4; ++n) {
                     f32x4 v = acc[mi][jp + n] + bv[n];
                     if constexpr (EPI == HIREST_EPI_BIAS_GELU_BF16) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
                     }
                     if constexpr (EPI == HIREST_EPI_BIAS_QGELU_BF16) {
 #pragma unroll
@@ -837,40 +837,49 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                 const int col = Nw + (jp + n) * 16 + 4 * kg;
                 bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            // the 8 operand loads of each 64x32 block (residual / pos rows) are issued before the first pass: the
+            // residual stream lives in HBM and a load-per-pass schedule left the epilogue latency-bound
+            // (proj: 1.23 ms with the residual read vs 0.92 ms without).
+            const int n = Nw + jp * 16 + rc * 4;
 #pragma unroll
-            for (int mq = 0; mq < 8; mq += 2) {                  // two 16-row passes share one batch of operand loads
-                f32x4 o[4];
-                int64_t off[4];
-                bool ok[4];
+            for (int mh = 0; mh < 8; mh += 4) {                  // 64 rows per batch
+                f32x4 o[8];
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int m = Mw + mq * 16 + it * 8 + rr, n = Nw + jp * 16 + rc * 4;
-                    ok[it] = m < p.M && n < p.N;
+                for (int it = 0; it < 8; ++it) {
+                    const int m = Mw + mh * 16 + it * 8 + rr;
+                    const bool ok = m < p.M && n < p.N;
                     if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
-                        const int mm = ok[it] ? m : 0;
-                        const int b = mm / p.P, pp = mm - b * p.P;
-                        off[it] = ((int64_t)b * (p.P + 1) + 1 + pp) * p.ldo + n;
-                        o[it] = ok[it] ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    } else {
-                        off[it] = (int64_t)m * p.ldo + n;
-                        if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32)
-                            o[it] = ok[it] ? *reinterpret_cast<const f32x4*>(outp + off[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const int mm = ok ? m : 0;
+                        const int pp = mm % p.P;
+                        o[it] = ok ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32) {
+                        o[it] = ok ? *reinterpret_cast<const f32x4*>(outp + (int64_t)m * p.ldo + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
+                for (int mi = mh; mi < mh + 4; ++mi) {
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const f32x4 v = acc[mq + sp][jp + n] + bv[n];
-                        *reinterpret_cast<f32x4*>(stg + srow * 128 + (((n * 4 + kg) ^ sw) << 4)) = v;
+                    for (int nn = 0; nn < 2; ++nn) {
+                        const f32x4 v = acc[mi][jp + nn] + bv[nn];
+                        *reinterpret_cast<f32x4*>(stg + srow * 128 + (((nn * 4 + kg) ^ sw) << 4)) = v;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
                         const int r = it * 8 + rr;
                         f32x4 w = *reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
-                        if constexpr (EPI != HIREST_EPI_BIAS_F32) w += o[sp * 2 + it];
-                        if (ok[sp * 2 + it]) *reinterpret_cast<f32x4*>(outp + off[sp * 2 + it]) = w;
+                        if constexpr (EPI != HIREST_EPI_BIAS_F32) w += o[(mi - mh) * 2 + it];
+                        const int m = Mw + mi * 16 + r;
+                        if (m < p.M && n < p.N) {
+                            int64_t off;
+                            if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
+                                const int b = m / p.P, pp = m - b * p.P;
+                                off = ((int64_t)b * (p.P + 1) + 1 + pp) * p.ldo + n;
+                            } else {
+                                off = (int64_t)m * p.ldo + n;
+                            }
+                            *reinterpret_cast<f32x4*>(outp + off) = w;
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     // a + b minimal) so that every operand line is shared by several CUs through the XCD's L2.  Few column tiles
     // (N = 1408: 6): panel-major, all column tiles of a panel together -> the long-K A panel (3 MB at K = 6144) comes
     // from HBM once instead of once per column group.  Many column tiles: GROUP_M panels x 4 column tiles.
-    const bool panel_major = p.nbn <= 8;
+    const bool panel_major = (p.dbg & 8) ? false : (p.dbg & 16) ? true : p.nbn <= 8;   // dbg bits: A/B timing of the order
     auto tile_origin = [&](int j, int& M0, int& N0) {
         if (panel_major) {
             const int mt_i = j / p.nbn;

@@ -12,7 +12,8 @@ from hirest_amd import _lib, ops  # noqa: E402
 
 SHAPES = {"qkv": (4224, 1408, _lib.EPI_BIAS_BF16), "proj": (1408, 1408, _lib.EPI_BIAS_RESID_F32),
           "fc1": (6144, 1408, _lib.EPI_BIAS_GELU_BF16), "fc2": (1408, 6144, _lib.EPI_BIAS_RESID_F32),
-          "fc1_nogelu": (6144, 1408, _lib.EPI_BIAS_BF16)}
+          "fc1_nogelu": (6144, 1408, _lib.EPI_BIAS_BF16), "fc2_plain": (1408, 6144, _lib.EPI_BIAS_BF16),
+          "proj_plain": (1408, 1408, _lib.EPI_BIAS_BF16), "fc2_f32": (1408, 6144, _lib.EPI_BIAS_F32)}
 
 
 def main():
@@ -20,6 +21,7 @@ def main():
     ap.add_argument("--variants", type=int, nargs="*", default=[1, 2, 4])
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=15, help="untimed launches per measurement (clocks / power state settle)")
     ap.add_argument("--shapes", nargs="*", default=["qkv", "proj", "fc1", "fc2", "fc1_nogelu"])
     ap.add_argument("--alias", action="store_true", help="lda=ldw=0: every row aliases row 0 (operands stay cache-resident): "
                     "kernel-structure ceiling without the memory system")
@@ -46,7 +48,7 @@ def main():
             _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "gemm")
         for v in a.variants:
             ops.gemm_select_kernel(v)
-            for _ in range(2):
+            for _ in range(a.warmup):
                 run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
