@@ -15,13 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhirest_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "score.hip", "tower.hip", "profile.hip", "joint.hip", "preprocess.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "score.hip", "tower.hip", "profile.hip", "joint.hip", "preprocess.hip", "eval.hip"]
 ARCH = "gfx950"
 # attention's softmax only ever sees finite values (masked scores are -3e38, not -inf): dropping NaN handling removes
 # the canonicalising v_max the compiler otherwise puts in front of every fmaxf on an MFMA result
 EXTRA_FLAGS = {"attention.hip": ["-ffinite-math-only"],
                # Pillow-exact weight tables (host doubles) and the reference's (x/255-mean)/std: no fused multiply-adds
-               "preprocess.hip": ["-ffp-contract=off"]}
+               "preprocess.hip": ["-ffp-contract=off"],
+               # evaluate.py's double-precision interval arithmetic, operation for operation
+               "eval.hip": ["-ffp-contract=off"]}
 
 
 def hipcc_path() -> str:

@@ -270,6 +270,24 @@ int hirest_preprocess_u8(const uint8_t* frames, int32_t B, int32_t in_h, int32_t
                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Moment-task evaluation on device (evaluate.py), double precision with Python's operation order:
+ *   hirest_interval_iou_f64     compute_iou (evaluate.py:24-31) of n interval pairs a[i] (= interval_1), b[i];
+ *                               R@tIoU of evaluate_moment_retrieval (:83-121) is !(iou < tIoU).
+ *   hirest_step_bound_pr        per-video recall / precision of compute_step_bound_scores (:123-188): refs / preds
+ *                               are ragged [sum,2] interval lists with CSR offsets [V+1]; a pair matches when
+ *                               compute_iou(pred, ref) > tiou (strict).  best_iou (optional) [sum preds] = max over refs.
+ *   hirest_preprocess_moment_bounds   preprocess_moment_bounds + NMS (:300-412): per video, predictions strictly inside
+ *                               gt_minmax[v] = (first gt start, last gt end) -> greedy NMS from the last index ->
+ *                               sorted by start, all gaps filled.  out [V,max_out,2]; out_count[v] may exceed max_out
+ *                               (then the list was truncated: enlarge and rerun).  At most 128 predictions per video.
+ * ------------------------------------------------------------------------------------ */
+int hirest_interval_iou_f64(const double* a, const double* b, int64_t n, double* iou, void* stream);
+int hirest_step_bound_pr(const double* refs, const int32_t* ref_off, const double* preds, const int32_t* pred_off,
+                         int32_t V, double tiou, double* recall, double* precision, double* best_iou, void* stream);
+int hirest_preprocess_moment_bounds(const double* preds, const int32_t* pred_off, const double* gt_minmax, int32_t V,
+                                    double* out, int32_t* out_count, int32_t max_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Optional per-launch timing (bench.py's live roofline measurement).  When enabled, every
  * GEMM / attention / LayerNorm launch is bracketed by hipEventRecord on ITS launch stream;
  * hirest_profile_collect synchronises those events and returns one record per launch.

@@ -200,6 +200,33 @@ def subsample_ids(n_frames: int, n_model_frames: int) -> np.ndarray:
     return np.linspace(0, n_frames - 1, n_model_frames).astype(int)
 
 
+def dataset_fit_frames(video_features: torch.Tensor, n_model_frames: int) -> torch.Tensor:
+    """hirest_dataset.py:333-356, loop for loop: linspace subsample when longer, bucket up-sample otherwise."""
+    if n_model_frames <= 0:
+        return video_features
+    n_frames = video_features.shape[0]
+    if n_frames > n_model_frames:
+        ids = torch.from_numpy(np.linspace(0, n_frames - 1, n_model_frames).astype(int))
+        return video_features[ids]
+    x = torch.zeros((n_model_frames, video_features.shape[1]))
+    slots = [0] * n_model_frames
+    buckets = [slots[(j * n_model_frames) // n_frames:((j + 1) * n_model_frames) // n_frames] for j in range(n_frames)]
+    j = 0
+    for k in range(len(buckets)):
+        for _ in buckets[k]:
+            x[j] = video_features[k]
+            j += 1
+    return x
+
+
+def dataset_asr_feats(asr_features: torch.Tensor, sub_spans, fitted_len: int, n_model_frames: int) -> torch.Tensor:
+    """hirest_dataset.py:358-402: per-second warping on the FITTED video length, then the same frame-count rule."""
+    warped = torch.zeros(fitted_len, asr_features.shape[1]).float()
+    for i, (start, end) in enumerate(sub_spans):
+        warped[start:end] = asr_features[i]
+    return dataset_fit_frames(warped, n_model_frames)
+
+
 def pool_video(frame_embeds: torch.Tensor, normalize_frames_first: bool = False) -> torch.Tensor:
     """[V,F,E] -> [V,E]: mean over frames then L2 (inference_video_retrieval.py:283-285, 323-327).
     ``normalize_frames_first`` reproduces extract_features.py:64 features (hazard H2)."""

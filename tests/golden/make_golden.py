@@ -399,6 +399,138 @@ def gen_preprocess():
         json.dump(out, f, indent=1)
 
 
+FEATURE_CASES = [(300, 32), (32, 32), (10, 32), (33, 32), (1, 32), (31, 32), (64, 32), (571, 300), (120, 300), (299, 300),
+                 (300, 300), (7, 20), (1855, 300), (45, 0)]
+
+
+def gen_features():
+    """Frame-count rules of the real MomentDataset.__getitem__ (hirest_dataset.py:323-404): the method is run on an
+    instance created without __init__ (which needs the whole dataset) over throw-away .pt files whose row k holds the
+    value k, so the returned rows spell out the index map; plus one ASR-warping case."""
+    import datetime
+    import tempfile
+    from pathlib import Path
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import hirest_dataset as ref_ds
+    out = {"vis": {}, "asr": {}}
+    with tempfile.TemporaryDirectory() as d:
+        for n, F in FEATURE_CASES:
+            feats = torch.arange(n, dtype=torch.float32)[:, None] + torch.tensor([0.0, 0.25, 0.5])[None]
+            torch.save(feats, f"{d}/v{n}_{F}.pt")
+            ds = ref_ds.MomentDataset.__new__(ref_ds.MomentDataset)
+            ds.data = [{"fname": f"v{n}_{F}"}]
+            ds.video_feature_dir = Path(d)
+            ds.n_model_frames = F
+            ds.videoid2asr = {}
+            vf = ds[0]["vis_feats"]
+            assert torch.equal(vf[:, 1] - vf[:, 0], torch.full((vf.shape[0],), 0.25))
+            out["vis"][f"{n},{F}"] = {"ids": [int(v) for v in vf[:, 0].tolist()], "dtype": str(vf.dtype)}
+        # ASR warping (hirest_dataset.py:358-402): subtitle i's embedding fills seconds [start, end)
+        for n, F, subs in [(40, 16, [(0, 3), (5, 9), (9, 12), (30, 45)]), (12, 32, [(1, 2), (4, 4), (6, 11)]), (50, 0, [(10, 20)])]:
+            name = f"a{n}_{F}"
+            torch.save(torch.zeros((n, 3)), f"{d}/{name}.pt")
+            asr = torch.arange(len(subs), dtype=torch.float32)[:, None] + 1.0 + torch.tensor([0.0, 0.5])[None]
+            torch.save(asr, f"{d}/{name}_asr.pt")
+
+            class Sub:
+                def __init__(self, a, b):
+                    self.start, self.end = datetime.timedelta(seconds=a), datetime.timedelta(seconds=b)
+            ds = ref_ds.MomentDataset.__new__(ref_ds.MomentDataset)
+            ds.data = [{"fname": name}]
+            ds.video_feature_dir = Path(d)
+            ds.n_model_frames = F
+            ds.videoid2asr = {name: [Sub(a, b) for a, b in subs]}
+
+            class _Dir:
+                def __truediv__(self, other):
+                    return Path(d) / other.replace(".pt", "_asr.pt")
+            ds.asr_feature_dir = _Dir()
+            af = ds[0]["asr_feats"]
+            out["asr"][name] = {"n": n, "F": F, "subs": subs, "col0": af[:, 0].tolist(), "col1": af[:, 1].tolist()}
+    with open(os.path.join(HERE, "feature_rules.json"), "w") as f:
+        json.dump(out, f)
+    print({k: len(v) for k, v in out.items()})
+
+
+def moment_eval_inputs():
+    """Seeded synthetic gt / predictions in evaluate.py's JSON layouts (shared with tests/test_evaluation.py)."""
+    cats = ["Food", "Hobbies", "Home"]
+    u = synth.uniform_pm1("moment_eval", 20000, 17)
+    it = iter(((u + 1.0) * 0.5).tolist())
+    rnd = lambda lo, hi: lo + (hi - lo) * next(it)
+    prompt_to_cat, video_to_cat = {}, {}
+    mr_gt, mr_pred, sb_gt, sb_pred = {}, {}, {}, {}
+    for pi in range(24):
+        prompt = f"prompt {pi}"
+        prompt_to_cat[prompt] = cats[pi % 3]
+        mr_gt[prompt], mr_pred[prompt] = {}, {}
+        for vi in range(1 + pi % 3):
+            video = f"vid_{pi}_{vi}.mp4"
+            video_to_cat[video] = cats[(pi + vi) % 3]
+            dur = int(rnd(40, 600))
+            a = int(rnd(0, dur * 0.6)); b = a + 1 + int(rnd(2, dur * 0.4))
+            clip = (pi + vi) % 5 != 0
+            mr_gt[prompt][video] = {"clip": clip, "bounds": [a, b], "v_duration": dur}
+            mode = (pi + 2 * vi) % 6
+            if mode == 0:
+                pb = [a, b]                                            # exact
+            elif mode == 1:
+                pb = [b + 3, b + 9]                                    # disjoint
+            elif mode == 2:
+                pb = [a, a + (b - a) // 2]                             # IoU near 0.5
+            else:
+                pb = [max(0, a + int(rnd(-15, 15))), b + int(rnd(-15, 15))]
+                if pb[1] <= pb[0]:
+                    pb[1] = pb[0] + 1
+            mr_pred[prompt][video] = {"bounds": pb}
+            if clip:
+                n_steps = 2 + int(rnd(0, 7))
+                cuts = sorted(set([a, b] + [int(rnd(a + 1, b - 1)) for _ in range(n_steps)]))
+                refs = [[cuts[i], cuts[i + 1]] for i in range(len(cuts) - 1)]
+                sb_gt[video] = {"bounds": refs}
+                preds = []
+                for r in refs:                                         # jittered, duplicated, nested and outside boxes
+                    if next(it) < 0.8:
+                        preds.append([r[0] + int(rnd(-3, 4)), r[1] + int(rnd(-3, 4))])
+                    if next(it) < 0.3:
+                        preds.append([r[0] + 1, r[1] - 1] if r[1] - r[0] > 3 else [r[0], r[1]])
+                if next(it) < 0.5:
+                    preds.append([a - 5, a + 2])
+                if next(it) < 0.3:
+                    preds.append([rnd(a, b), rnd(a, b) + 2.5])         # float bounds
+                preds = [p if p[1] > p[0] else [p[0], p[0] + 1] for p in preds]
+                sb_pred[video] = {"bounds": preds}
+    return {"prompt_to_cat": prompt_to_cat, "video_to_cat": video_to_cat, "mr_gt": mr_gt, "mr_pred": mr_pred,
+            "sb_gt": sb_gt, "sb_pred": sb_pred}
+
+
+def gen_moment_eval():
+    """evaluate.py's moment metrics run for real: compute_iou, evaluate_moment_retrieval, preprocess_moment_bounds (+NMS)
+    and compute_step_bound_scores, with the category globals that its __main__ would set (:444-466)."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import evaluate as ref_eval
+    inp = moment_eval_inputs()
+    cats = sorted(set(inp["prompt_to_cat"].values()) | set(inp["video_to_cat"].values())) + ["all"]
+    ref_eval.PROMPT_CATEGORIES = cats
+    ref_eval.PROMPT_TO_CAT = inp["prompt_to_cat"]
+    ref_eval.VIDEOS_TO_CAT = inp["video_to_cat"]
+    import copy
+    out = {"iou_samples": []}
+    for a, b in [([0, 10], [5, 15]), ([0, 10], [10, 20]), ([3, 7], [3, 7]), ([0, 100], [40, 60]), ([1.5, 2.25], [2.0, 9.75]),
+                 ([5, 5], [5, 5]), ([0, 3], [7, 9])]:
+        out["iou_samples"].append({"a": a, "b": b, "iou": ref_eval.compute_iou(a, b)})
+    out["moment_retrieval"] = ref_eval.evaluate_moment_retrieval(copy.deepcopy(inp["mr_gt"]), copy.deepcopy(inp["mr_pred"]))
+    pre = ref_eval.preprocess_moment_bounds(copy.deepcopy(inp["sb_gt"]), copy.deepcopy(inp["sb_pred"]))
+    out["preprocessed"] = {v: [[float(x) for x in b] for b in pre[v]["bounds"]] for v in pre}
+    out["step_bounds_raw"] = ref_eval.compute_step_bound_scores(copy.deepcopy(inp["sb_gt"]), copy.deepcopy(inp["sb_pred"]))
+    out["step_bounds_preprocessed"] = ref_eval.compute_step_bound_scores(copy.deepcopy(inp["sb_gt"]), pre)
+    with open(os.path.join(HERE, "moment_eval.json"), "w") as f:
+        json.dump(out, f)
+    print(out["moment_retrieval"]["all"], out["step_bounds_preprocessed"]["all"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -419,6 +551,8 @@ def main():
         "joint": gen_joint,
         "caption": gen_caption,
         "preprocess": gen_preprocess,
+        "features": gen_features,
+        "moment_eval": gen_moment_eval,
     }
     for name, fn in jobs.items():
         if args.only and name not in args.only:
