@@ -54,6 +54,7 @@ class ProfRecord(C.Structure):
 
 _SIGNATURES = {
     "hirest_profile_enable": (C.c_int, [C.c_int32]),
+    "hirest_attention_debug_mode": (C.c_int, [C.c_int32]),
     "hirest_profile_collect": (C.c_int, [C.POINTER(ProfRecord), C.c_int32]),
     "hirest_abi_version": (C.c_int, []),
     "hirest_build_info": (C.c_char_p, []),

@@ -341,9 +341,10 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 //              DMA V(h), DMA K(h+1) | S^T + softmax of the first tile | vmcnt(#K pieces) BARRIER B (V(h) landed)
 //              P.V ... remaining tiles
 // =================================================================================================
-template <int DH, int DP, int NT, bool FAST>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
+template <int DH, int DP, int NT, bool FAST, bool DBG>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
 __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                          int N, int H, float scale_log2e, int causal) {
+                                                          int N, int H, float scale_log2e, int causal, int dbg_bits) {
+    const int dbg = DBG ? dbg_bits : 0;   // timing-experiment switches fold away in the production instantiation
     using C = AttnCfg2<DH, DP, NT>;
     constexpr int NW = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -358,63 +359,68 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
     const int gk = g ^ ((-(c16 >> 2)) & 3);
     const int nqt = (N + 15) >> 4;
 
+    // LDS-DMA piece i of this wave covers 16-B chunks ci = i*64 + lane, i = wave, wave + 9, ...: 576 chunks = 48 rows
+    // further each time, same column -> one (row0, column) pair per lane.
+    const int ci0 = wave * 64 + lane;
+    const int row0 = ci0 / C::CPR, col0 = ci0 - row0 * C::CPR;
+    const int vc = col0 * 8 < DH ? col0 : DH / 8 - 1;
+    static_assert((NW * 64) % C::CPR == 0, "piece stride must be whole rows");
+    constexpr int ROWS_PER_PIECE = NW * 64 / C::CPR;
     auto dma_k = [&](int h, char* dst) -> int {
         int n = 0;
-        for (int i = wave; i < C::NK_INSTR; i += NW) {
-            const int ci = i * 64 + lane;
-            int row = ci / C::CPR, c = ci - row * C::CPR;
-            c = (c & ~3) | ((c & 3) ^ ((-(row >> 2)) & 3));
-            row = row < N ? row : N - 1;
-            c = c * 8 < DH ? c : DH / 8 - 1;
-            glds16(fbase + (int64_t)row * ld + D + h * DH + c * 8, dst + i * 1024);
+        const bf16_t* src = fbase + D + h * DH;
+        for (int i = wave, row = row0; i < C::NK_INSTR; i += NW, row += ROWS_PER_PIECE) {
+            int kc = (col0 & ~3) | ((col0 & 3) ^ ((-(row >> 2)) & 3));      // K image swizzle (see the fragment reads)
+            kc = kc * 8 < DH ? kc : DH / 8 - 1;
+            const int r = row < N ? row : N - 1;
+            glds16(src + (int64_t)r * ld + kc * 8, dst + i * 1024);
             ++n;
         }
         return n;
     };
     auto dma_v = [&](int h) {
-        for (int i = wave; i < C::NV_INSTR; i += NW) {
-            const int ci = i * 64 + lane;
-            int row = ci / C::CPR, c = ci - row * C::CPR;
-            row = row < N ? row : N - 1;
-            c = c * 8 < DH ? c : DH / 8 - 1;
-            glds16(fbase + (int64_t)row * ld + 2 * D + h * DH + c * 8, Vs + i * 1024);
+        const bf16_t* src = fbase + 2 * D + h * DH + vc * 8;
+        for (int i = wave, row = row0; i < C::NV_INSTR; i += NW, row += ROWS_PER_PIECE) {
+            const int r = row < N ? row : N - 1;
+            glds16(src + (int64_t)r * ld, Vs + i * 1024);
+        }
+    };
+    // Q fragments: lane (c16, g) holds query row qtile*16 + c16, dims 8*(4kk + g)..+7
+    auto load_q = [&](int h, int qtile, bf16x8 (&dst)[DP / 32]) {
+        const int q = qtile * 16 + c16;
+        const bf16_t* base = fbase + h * DH;
+#pragma unroll
+        for (int kk = 0; kk < DP / 32; ++kk) {
+            const int d = (kk * 4 + g) * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qtile < nqt && q < N && d < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * ld + d);
+            dst[kk] = v;
         }
     };
 
-    dma_k(0, smem);
+    // A wave owns query tiles `wave` and `wave + 9` (nqt <= 18 on this path).  Their Q fragments for head h+1 are
+    // loaded as soon as head h's S^T has consumed the registers, so the global latency never sits in front of a barrier.
+    bf16x8 qa[DP / 32], qb[DP / 32];
+    load_q(0, wave, qa);
+    load_q(0, wave + NW, qb);
+    if (!(dbg & 8)) dma_k(0, smem);
     for (int h = 0; h < H; ++h) {
-        const bf16_t* base = fbase + h * DH;
         const char* Ks = smem + (h & 1) * (C::NPAD * C::RS);
-        // Q fragments of this wave's first tile: loaded and retired BEFORE any new DMA is issued, so the
-        // compiler's wait for them cannot drain the V / K(h+1) transfers that are about to start
-        int qt = wave;
-        bf16x8 qf[DP / 32];
-        auto load_q = [&](int qtile) {
-            const int q = qtile * 16 + c16;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K(h) pieces and this head's Q fragments (issued a head ago)
 #pragma unroll
-            for (int kk = 0; kk < DP / 32; ++kk) {
-                const int d = (kk * 4 + g) * 8;
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (q < N && d < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * ld + d);
-                qf[kk] = v;
-            }
-        };
-        if (qt < nqt) load_q(qt);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K(h) pieces (issued one head ago) + the Q loads
-#pragma unroll
-        for (int kk = 0; kk < DP / 32; ++kk) asm volatile("" : "+v"(qf[kk]));
+        for (int kk = 0; kk < DP / 32; ++kk) { asm volatile("" : "+v"(qa[kk])); asm volatile("" : "+v"(qb[kk])); }
         __builtin_amdgcn_s_barrier();                          // A: K(h) everywhere, head h-1 done everywhere
-        dma_v(h);
-        const int nk_next = h + 1 < H ? dma_k(h + 1, smem + ((h + 1) & 1) * (C::NPAD * C::RS)) : 0;
+        if (!(dbg & 8)) dma_v(h);
+        const int nk_next = (h + 1 < H && !(dbg & 8)) ? dma_k(h + 1, smem + ((h + 1) & 1) * (C::NPAD * C::RS)) : 0;
         bool v_ready = false;
-        for (; qt < nqt; qt += NW) {
+        auto tile = [&](int qt, bf16x8 (&qf)[DP / 32]) {
             const int q = qt * 16 + c16;
             const bool qvalid = q < N;
-            if (qt != wave) load_q(qt);
             f32x4 st[NT];
 #pragma unroll
             for (int t = 0; t < NT; t += 2) {   // two key tiles at a time: independent accumulators hide the MFMA latency
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                if (!(dbg & 1))
 #pragma unroll
                 for (int kk = 0; kk < DP / 32; ++kk) {
                     const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c16) * C::RS + (kk * 4 + gk) * 16);
@@ -426,8 +432,9 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
                 }
                 st[t] = a0;
                 if (t + 1 < NT) st[t + 1] = a1;
-                __builtin_amdgcn_sched_barrier(0);
+                if ((t & 2) || !FAST) __builtin_amdgcn_sched_barrier(0);   // FAST: regions of 4 key tiles (12 reads in flight)
             }
+            if (h + 1 < H) load_q(h + 1, qt, qf);            // registers are free: next head's fragments start travelling
             // mask (only tiles that can contain masked keys pay for it), row max
             const int klimit = causal ? (q < N - 1 ? q : N - 1) : N - 1;
             float mx = -3.0e38f;
@@ -449,11 +456,13 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
             for (int s2 = 0; s2 < C::KS; ++s2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(st[2 * s2][i], scale_log2e, nmc));
+                    const float e0 = fmaf(st[2 * s2][i], scale_log2e, nmc);
+                    const float p0 = (dbg & 2) ? e0 : __builtin_amdgcn_exp2f(e0);
                     sum += p0;
                     pf[s2][i] = (bf16_t)p0;
                     if (2 * s2 + 1 < NT) {
-                        const float p1 = __builtin_amdgcn_exp2f(fmaf(st[2 * s2 + 1][i], scale_log2e, nmc));
+                        const float e1 = fmaf(st[2 * s2 + 1][i], scale_log2e, nmc);
+                        const float p1 = (dbg & 2) ? e1 : __builtin_amdgcn_exp2f(e1);
                         sum += p1;
                         pf[s2][4 + i] = (bf16_t)p1;
                     } else {
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
             if (!v_ready) {
-                wait_vm_le(nk_next);                 // V(h) pieces were issued before the K(h+1) pieces
+                wait_vm_le(nk_next);                 // V(h) pieces are older than the K(h+1) pieces (and the new Q loads)
                 __builtin_amdgcn_s_barrier();        // B: V(h) everywhere
                 v_ready = true;
             }
@@ -473,6 +482,7 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
             f32x4 oacc[DP / 16];
 #pragma unroll
             for (int dt = 0; dt < DP / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 4))
 #pragma unroll
             for (int s2 = 0; s2 < C::KS; ++s2) {
 #pragma unroll
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if ((s2 & 1) || !FAST) __builtin_amdgcn_sched_barrier(0);   // FAST: regions of 2 key steps (24 reads in flight)
             }
 #pragma unroll
             for (int dt = 0; dt < DP / 16; ++dt) {
@@ -495,7 +505,9 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
                     *reinterpret_cast<bf16x4*>(out + ((int64_t)b * N + q) * D + h * DH + d) = o;
                 }
             }
-        }
+        };
+        if (wave < nqt) tile(wave, qa);
+        if (wave + NW < nqt) tile(wave + NW, qb);
         if (!v_ready) {
             wait_vm_le(nk_next);
             __builtin_amdgcn_s_barrier();
@@ -504,20 +516,28 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DH, int DP, int NT, bool FAST>
-int launch3(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
+int g_attn_dbg = 0;   // timing experiments only (hirest_attention_debug_mode)
+
+template <int DH, int DP, int NT, bool FAST, bool DBG>
+int launch3_impl(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
     using C = AttnCfg2<DH, DP, NT>;
     constexpr int LDS = (2 * C::NPAD + C::KP) * C::RS;
     static_assert(LDS <= 163840, "K x2 + V must fit the CU's LDS");
     static bool configured = false;
-    auto kern = attention_kernel_v3<DH, DP, NT, FAST>;
+    auto kern = attention_kernel_v3<DH, DP, NT, FAST, DBG>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(576), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(576), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg);
     return hirest_launch_status();
+}
+
+template <int DH, int DP, int NT, bool FAST>
+int launch3(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
+    if (g_attn_dbg && FAST) return launch3_impl<DH, DP, NT, FAST, true>(qkv, out, B, N, H, scale, causal, s);
+    return launch3_impl<DH, DP, NT, FAST, false>(qkv, out, B, N, H, scale, causal, s);
 }
 
 int g_attn_variant = 3;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame; default for N > 80)
@@ -539,6 +559,8 @@ int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, in
 }
 
 }  // namespace
+
+extern "C" int hirest_attention_debug_mode(int32_t bits) { g_attn_dbg = bits; return 0; }
 
 extern "C" int hirest_attention_select_kernel(int32_t which) {
     if (which < 1 || which > 3) return HIREST_E_BADARG;

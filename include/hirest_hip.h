@@ -105,6 +105,9 @@ int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out,
 /* 1 = register-staged kernel with a transposed V image, 2 (default) = LDS-DMA staging + hardware
  * transpose reads.  For tests / A-B timing. */
 int hirest_attention_select_kernel(int32_t which);
+/* TIMING EXPERIMENTS ONLY (results become wrong), persistent kernel: bit0 skip the S^T MFMAs, bit1 skip the softmax
+ * exponentials, bit2 skip P.V, bit3 skip the K/V LDS-DMA.  0 restores normal operation. */
+int hirest_attention_debug_mode(int32_t bits);
 
 /* ------------------------------------------------------------------------------------
  * Patch extraction (im2col for Conv2d with kernel == stride == P, vit_model.py:198,205):
