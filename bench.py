@@ -132,10 +132,29 @@ def main():
             breakdown.append(ent)
         dom = next((e for e in breakdown if e["kernel"] == "gemm"), None)
         roofline = None
+        traffic = None
+        if dom:
+            # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC profile (FETCH_SIZE + WRITE_SIZE,
+            # separate passes, gfx950 correction; tools/pmc_traffic.sh).  bench.py cannot sample counters on itself.
+            try:
+                prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")))
+                same_tag = [e for e in breakdown if e["kernel"] == "gemm" and e["tag"] == dom["tag"]
+                            and e["launches"] == dom["launches"]]
+                same_tag.sort(key=lambda e: -e["dims"][0] * e["dims"][2])            # more operand bytes first
+                cands = [k for k in prof["kernels"] if f"gemm_p256<{dom['tag']}," in k["kernel"]
+                         and k["launches"] * args.steps in (dom["launches"], dom["launches"] - args.steps)]
+                cands.sort(key=lambda k: -k["fetch_bytes_per_launch"])
+                idx = same_tag.index(dom)
+                if idx < len(cands):
+                    traffic = cands[idx]["traffic_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                traffic = None
         if dom:
             epi = {0: "bias", 1: "bias+gelu", 2: "bias+quickgelu", 3: "bias+residual", 4: "bias->f32", 5: "patch+pos"}
             roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                        "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_note": "bytes per launch through the L2's memory side (Infinity-Cache hits included), from "
+                                        "profiles/r01/pmc_traffic.json; null if no matching profile",
                         "kernel": f"gemm<{epi.get(dom['tag'], dom['tag'])}> M={dom['dims'][0]} N={dom['dims'][1]} K={dom['dims'][2]}",
                         "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                         "algorithmic_flops_per_launch": 2.0 * dom["dims"][0] * dom["dims"][1] * dom["dims"][2],

@@ -907,24 +907,50 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     const int p_lo = xcd * p.ppx;
     int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
     if (np <= 0) return;
-    const int ntile = np * p.nbn;
-    if (slot >= ntile) return;
-    // Tile order inside the XCD.  The ~32 tiles in flight should form a near-square patch (a panels x b column tiles,
-    // a + b minimal) so that every operand line is shared by several CUs through the XCD's L2.  Few column tiles
-    // (N = 1408: 6): panel-major, all column tiles of a panel together -> the long-K A panel (3 MB at K = 6144) comes
-    // from HBM once instead of once per column group.  Many column tiles: GROUP_M panels x 4 column tiles.
+    // Work list of the XCD = units, unit j goes to CU slot j % nslot.  The ~32 tiles in flight form a patch (a panels x
+    // b column tiles) whose operand lines are shared through the XCD's L2:
+    //   * few column tiles (N = 1408: 6): panel-major, all column tiles of a panel together;
+    //   * many column tiles: groups of GROUP_M panels, column-major inside a group (8 panels x 4 columns per round).
+    // A unit is one 256x256 tile.  Experiment kept behind debug bit 5: when N % 256 <= 128 the ragged last column tile
+    // keeps one wave per SIMD busy and takes half the time; pairing two of them into one unit makes all units equal so
+    // the CUs move in lock-step.  FETCH_SIZE did not drop (fc2: 25 GB per launch either way — what the schedule must
+    // pull through a 4-MB L2: 5.3 A panels + 6 W tiles of 3 MB per round) and time did not improve, so it is off.
+    const bool half_edge = (p.dbg & 32) && (p.N % T_BN) != 0 && (p.N % T_BN) <= T_BN / 2;
+    const int ncf = half_edge ? p.nbn - 1 : p.nbn;                       // column tiles that take full time
     const bool panel_major = (p.dbg & 8) ? false : (p.dbg & 16) ? true : p.nbn <= 8;   // dbg bits: A/B timing of the order
-    auto tile_origin = [&](int j, int& M0, int& N0) {
+    const int upp = 2 * ncf + (half_edge ? 1 : 0);                       // units per panel pair (panel-major)
+    const int ugf = GROUP_M * ncf + (half_edge ? GROUP_M / 2 : 0);       // units per full panel group (grouped)
+    int nunit;
+    if (panel_major) nunit = (np >> 1) * upp + ((np & 1) ? ncf + (half_edge ? 1 : 0) : 0);
+    else { const int rem = np % GROUP_M; nunit = (np / GROUP_M) * ugf + (rem ? rem * ncf + (half_edge ? (rem + 1) / 2 : 0) : 0); }
+    if (slot >= nunit) return;
+    // tile `sub` of unit j -> origin; returns the number of tiles in the unit (1 or 2)
+    auto unit_tile = [&](int j, int sub, int& M0, int& N0) -> int {
+        int panel, col, cnt = 1;
         if (panel_major) {
-            const int mt_i = j / p.nbn;
-            M0 = (p_lo + mt_i) * T_BM; N0 = (j - mt_i * p.nbn) * T_BN;
-            return;
+            const int full_pairs = np >> 1;
+            if (j >= full_pairs * upp) {                                 // the odd last panel
+                const int r = j - full_pairs * upp;
+                panel = np - 1; col = r;                                 // r == ncf is its (single) edge tile
+            } else {
+                const int pair = j / upp, r = j - pair * upp;
+                if (r < ncf) { panel = 2 * pair; col = r; }
+                else if (r < 2 * ncf) { panel = 2 * pair + 1; col = r - ncf; }
+                else { panel = 2 * pair + sub; col = ncf; cnt = 2; }
+            }
+        } else {
+            int grp = j / ugf, r = j - grp * ugf, gcount = GROUP_M;
+            if (grp >= np / GROUP_M) { grp = np / GROUP_M; r = j - grp * ugf; gcount = np - grp * GROUP_M; }
+            if (r < gcount * ncf) {
+                col = r / gcount; panel = grp * GROUP_M + (r - col * gcount);
+            } else {
+                const int e = r - gcount * ncf;
+                col = ncf; panel = grp * GROUP_M + 2 * e + sub;
+                cnt = (2 * e + 1 < gcount) ? 2 : 1;
+            }
         }
-        const int grp = j / (GROUP_M * p.nbn);
-        const int r = j - grp * GROUP_M * p.nbn;
-        int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
-        const int nt_i = r / gcount, mt_i = p_lo + grp * GROUP_M + (r - nt_i * gcount);
-        M0 = mt_i * T_BM; N0 = nt_i * T_BN;
+        M0 = (p_lo + panel) * T_BM; N0 = col * T_BN;
+        return cnt;
     };
 
     // ---- LDS-DMA stream state (runs up to two K steps ahead of the MFMAs, across tile boundaries)
@@ -945,7 +971,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
         a_base = reinterpret_cast<const char*>(p.A + (int64_t)M0 * p.lda);
         w_base = reinterpret_cast<const char*>(p.W + (int64_t)N0 * p.ldw);
     };
-    int dma_j = slot, dma_k = 0, dma_g = 0;
+    int dma_j = slot, dma_sub = 0, dma_cnt = 1, dma_k = 0, dma_g = 0;
     bool dma_live = true;
     auto stage = [&]() {   // issue the next step of the stream into ring slot dma_g & 1
         if (p.dbg & 1) return;                  // timing experiment: no LDS-DMA in the loop
@@ -960,8 +986,8 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     auto advance = [&]() {   // wave-uniform; past the last tile the stream refetches its last step (never consumed)
         ++dma_g;
         if (dma_live && ++dma_k == nst) {
-            dma_j += nslot;
-            if (dma_j < ntile) { int m0, n0; tile_origin(dma_j, m0, n0); set_sources(m0, n0); dma_k = 0; }
+            if (dma_sub + 1 < dma_cnt) ++dma_sub; else { dma_j += nslot; dma_sub = 0; }
+            if (dma_j < nunit) { int m0, n0; dma_cnt = unit_tile(dma_j, dma_sub, m0, n0); set_sources(m0, n0); dma_k = 0; }
             else { dma_live = false; dma_k = nst - 1; }
         }
     };
@@ -994,7 +1020,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     // ---- prologue of the stream: steps 0 and 1
     {
         int m0, n0;
-        tile_origin(slot, m0, n0);
+        dma_cnt = unit_tile(slot, 0, m0, n0);
         set_sources(m0, n0);
     }
     stage(); advance();
@@ -1004,9 +1030,10 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
 
     char* stg = smem + 2 * Q_STEP + wave * P_STG;
     int g = 0;   // global step index of the MFMA side: step g lives in ring slot g & 1
-    for (int j = slot; j < ntile; j += nslot) {
+    for (int j = slot, sub = 0; j < nunit;) {
         int M0, N0;
-        tile_origin(j, M0, N0);
+        const int cnt = unit_tile(j, sub, M0, N0);
+        if (sub + 1 < cnt) ++sub; else { j += nslot; sub = 0; }           // cursor now points at the next tile
         const bool active = (N0 + wc * WN < p.N) && (M0 + wr * 128 < p.M);
         if (active) {
 #pragma unroll

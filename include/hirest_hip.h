@@ -77,7 +77,9 @@ int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
 int hirest_gemm_select_kernel(int32_t which);
 /* TIMING EXPERIMENTS ONLY (results become wrong): bit0 = skip the main-loop LDS-DMA, bit1 = skip the
  * main-loop barrier and waits of the t256p kernel, bit2 = the persistent kernel streams tile (0,0)'s operands for
- * every tile (L2-resident operands).  0 restores normal operation. */
+ * every tile (L2-resident operands).  Bits 3-5 only reorder the persistent kernel's tile walk (results stay correct):
+ * bit3 force the grouped order, bit4 force panel-major, bit5 pair ragged edge tiles into equal-duration units.
+ * 0 restores normal operation. */
 int hirest_gemm_debug_mode(int32_t bits);
 
 /* ------------------------------------------------------------------------------------

@@ -62,7 +62,7 @@ def gemm_kernel(request, ops):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 132, 128), (257, 1408, 1408), (1000, 4224, 1408), (77, 768, 3072),
                                    (513, 260, 64), (2056, 1408, 6144),
-                                   (6151, 2100, 192)])   # > 32 tiles per XCD, odd step count: persistent blocks walk several tiles
+                                   (6151, 2100, 192), (6151, 1408, 192), (5000, 300, 64)])   # > 32 tiles per XCD, odd step count: persistent blocks walk several tiles
 def test_gemm_epilogues(dev, ops, gemm_kernel, M, N, K):
     from hirest_amd import _lib
     a = synth.tensor("g.a", (M, K), 1.0, 7)
@@ -88,6 +88,30 @@ def test_gemm_epilogues(dev, ops, gemm_kernel, M, N, K):
     x = resid.to(dev).clone()
     ops.gemm(ad, wd, bd, x, _lib.EPI_BIAS_RESID_F32)
     assert (x.cpu().double() - (resid.double() + ref)).abs().max().item() <= scale * 1e-5
+
+
+@pytest.mark.parametrize("order_bits", [8, 16, 32, 48])
+def test_gemm_persistent_tile_orders(dev, ops, order_bits):
+    """The persistent kernel's alternative tile walks (debug bits 3-5: grouped / panel-major / paired edge units) visit
+    every tile exactly once: results equal the default order's."""
+    from hirest_amd import _lib
+    lib = _lib.load()
+    ops.gemm_select_kernel(6)
+    try:
+        for (M, N, K) in [(6151, 1408, 192), (6151, 2100, 128), (4400, 4224, 64)]:
+            a = synth.tensor("go.a", (M, K), 1.0, 9).to(torch.bfloat16).to(dev)
+            w = synth.tensor("go.w", (N, K), 0.05, 9).to(torch.bfloat16).to(dev)
+            bias = synth.tensor("go.b", (N,), 0.5, 9).to(dev)
+            ref = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm(a, w, bias, ref, _lib.EPI_BIAS_BF16)
+            lib.hirest_gemm_debug_mode(order_bits)
+            out = torch.full((M, N), 5.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm(a, w, bias, out, _lib.EPI_BIAS_BF16)
+            lib.hirest_gemm_debug_mode(0)
+            assert torch.equal(out, ref), (M, N, K, order_bits)
+    finally:
+        lib.hirest_gemm_debug_mode(0)
+        ops.gemm_select_kernel(0)
 
 
 def test_gemm_detects_transpose(dev, ops, gemm_kernel):

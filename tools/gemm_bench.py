@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--alias", action="store_true", help="lda=ldw=0: every row aliases row 0 (operands stay cache-resident): "
                     "kernel-structure ceiling without the memory system")
     ap.add_argument("--hipblaslt", action="store_true", help="also time torch.mm (hipBLASLt, no epilogue) as a yardstick")
+    ap.add_argument("--lda-pad", type=int, default=0, help="extra elements in A's row stride (L2 set-conflict experiment)")
     ap.add_argument("--dbg", type=int, default=0, help="hirest_gemm_debug_mode bits (timing experiments)")
     a = ap.parse_args()
     _lib.load().hirest_gemm_debug_mode(a.dbg)
@@ -34,7 +35,7 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(0)
     for name in a.shapes:
         N, K, epi = SHAPES[name]
-        A = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
+        A = torch.randn((M, K + a.lda_pad), device=dev, generator=g).to(torch.bfloat16)
         W = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.bfloat16)
         bias = torch.randn((N,), device=dev, generator=g)
         out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32) else torch.bfloat16)
@@ -42,9 +43,10 @@ def main():
         lib = _lib.load()
 
         def run():
-            if not a.alias:
+            if not a.alias and not a.lda_pad:
                 return ops.gemm(A, W, bias, out, epi)
-            args = _lib.GemmArgs(A.data_ptr(), 0, W.data_ptr(), 0, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
+            lda = 0 if a.alias else K + a.lda_pad
+            args = _lib.GemmArgs(A.data_ptr(), lda, W.data_ptr(), 0 if a.alias else K, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
             _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "gemm")
         for v in a.variants:
             ops.gemm_select_kernel(v)
@@ -57,7 +59,7 @@ def main():
                 run()
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
-            print(f"{'[alias] ' if a.alias else ''}{'[dbg%d] ' % a.dbg if a.dbg else ''}{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+            print(f"{'[alias] ' if a.alias else ''}{'[dbg%d] ' % a.dbg if a.dbg else ''}{'[lda+%d] ' % a.lda_pad if a.lda_pad else ''}{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
         if a.hipblaslt:
             Wt = W.t()
             for _ in range(2):
