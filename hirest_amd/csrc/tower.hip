@@ -68,7 +68,7 @@ int run_block(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf
 extern "C" int hirest_abi_version(void) { return HIREST_ABI_VERSION; }
 
 extern "C" const char* hirest_build_info(void) {
-    return "hirest_hip gfx950 (CDNA4) | gemm t256q/t128 32x32x16 bf16 MFMA + LDS-DMA | attention 16x16x32 bf16 MFMA + tr16 reads | " __VERSION__;
+    return "hirest_hip gfx950 (CDNA4) | gemm p256 (persistent, 16x16x32 bf16 MFMA) / t128 + LDS-DMA | attention 16x16x32 bf16 MFMA + tr16 reads | " __VERSION__;
 }
 
 extern "C" size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B) {
