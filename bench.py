@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 force t128, 2 force t256 (A/B timing)")
+    ap.add_argument("--gemm-dbg", type=int, default=0, help="hirest_gemm_debug_mode bits: TIMING EXPERIMENTS ONLY, the line is not a valid result")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,6 +65,7 @@ def main():
     from hirest_amd import _lib, retrieval, synth
     lib = _lib.load()
     lib.hirest_gemm_select_kernel(args.gemm_kernel)
+    lib.hirest_gemm_debug_mode(args.gemm_dbg)
 
     cfg = synth.EVA_CLIP_G_14
     model = hirest_amd.EVA_CLIP(**cfg).to(dev).eval()
@@ -171,6 +173,8 @@ def main():
                           "frames_per_gpu_per_step": args.frames, "global_batch": args.frames * world,
                           "micro_batch": args.chunk, "parallelism": f"dp{world}"},
                "roofline": roofline}
+        if args.gemm_dbg:
+            out["INVALID"] = f"timing experiment: hirest_gemm_debug_mode({args.gemm_dbg})"
 
     # ---- CPU baseline: the fp32 oracle on this host's cores, bounded sample (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

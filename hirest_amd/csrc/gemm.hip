@@ -888,8 +888,11 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
     }
 }
 
-template <int EPI, int WN>
+template <int EPI, int WN, bool DBG>
 __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
+    // timing-experiment switches (hirest_gemm_debug_mode) exist only in the DBG instantiation: a branch inside the K loop
+    // splits the scheduling region and destroys the MFMA / ds_read / LDS-DMA interleave
+    const int dbg = DBG ? p.dbg : 0;
     constexpr int NW = 512 / WN;        // 8 or 4 waves: 2 (M) x NW/2 (N)
     constexpr int NI = WN / 16;         // 16-column MFMA tiles per wave (4 or 8); 8 16-row tiles
     constexpr int PPW = 32 / NW;        // LDS-DMA pieces per operand per wave per step
@@ -915,9 +918,9 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     // keeps one wave per SIMD busy and takes half the time; pairing two of them into one unit makes all units equal so
     // the CUs move in lock-step.  FETCH_SIZE did not drop (fc2: 25 GB per launch either way — what the schedule must
     // pull through a 4-MB L2: 5.3 A panels + 6 W tiles of 3 MB per round) and time did not improve, so it is off.
-    const bool half_edge = (p.dbg & 32) && (p.N % T_BN) != 0 && (p.N % T_BN) <= T_BN / 2;
+    const bool half_edge = (dbg & 32) && (p.N % T_BN) != 0 && (p.N % T_BN) <= T_BN / 2;
     const int ncf = half_edge ? p.nbn - 1 : p.nbn;                       // column tiles that take full time
-    const bool panel_major = (p.dbg & 8) ? false : (p.dbg & 16) ? true : p.nbn <= 8;   // dbg bits: A/B timing of the order
+    const bool panel_major = (dbg & 8) ? false : (dbg & 16) ? true : p.nbn <= 8;   // dbg bits: A/B timing of the order
     const int upp = 2 * ncf + (half_edge ? 1 : 0);                       // units per panel pair (panel-major)
     const int ugf = GROUP_M * ncf + (half_edge ? GROUP_M / 2 : 0);       // units per full panel group (grouped)
     int nunit;
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     uint32_t a_off[PPW], w_off[PPW];
     const char* a_base; const char* w_base;
     auto set_sources = [&](int M0, int N0) {
-        if (p.dbg & 4) { M0 = 0; N0 = 0; }      // timing experiment: every tile streams tile (0,0)'s operands (L2-resident)
+        if (dbg & 4) { M0 = 0; N0 = 0; }      // timing experiment: every tile streams tile (0,0)'s operands (L2-resident)
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
             const int row = (wave * PPW + q) * 8 + (lane >> 3);
@@ -974,12 +977,13 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     int dma_j = slot, dma_sub = 0, dma_cnt = 1, dma_k = 0, dma_g = 0;
     bool dma_live = true;
     auto stage = [&]() {   // issue the next step of the stream into ring slot dma_g & 1
-        if (p.dbg & 1) return;                  // timing experiment: no LDS-DMA in the loop
+        if (dbg & 1) return;                  // timing experiment: no LDS-DMA in the loop
         char* buf = smem + (dma_g & 1) * Q_STEP + wave * (PPW * 1024);
         const char* ab = a_base + (int64_t)dma_k * (Q_BK * 2);
         const char* wb = w_base + (int64_t)dma_k * (Q_BK * 2);
 #pragma unroll
         for (int q = 0; q < PPW; ++q) glds16(ab + a_off[q], buf + q * 1024);
+        if (dbg & 128) return;                // timing experiment: A operand only (half the LDS-DMA traffic)
 #pragma unroll
         for (int q = 0; q < PPW; ++q) glds16(wb + w_off[q], buf + Q_WOFF + q * 1024);
     };
@@ -1046,7 +1050,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
                 const char* nxt = smem + ((g + 1) & 1) * Q_STEP;
                 // ---- first half: k 0..31 of step g | read the second half's fragments
                 __builtin_amdgcn_sched_barrier(0);
-                load_frags(cur, 1, f1);
+                if (!(dbg & 256)) load_frags(cur, 1, f1);   // (bit8, timing experiment: half the fragment reads)
                 mfma_half(f0);
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
@@ -1056,22 +1060,21 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- second half: step g+1 has landed everywhere and nobody reads slot g&1 any more after the
                 // barrier -> read step g+1's first fragments, refill slot g&1 with step g+2, k 32..63 of step g
-                HX_WAIT_VM(0);
+                if (!(dbg & 64)) HX_WAIT_VM(0);   // (bit6, timing experiment: do not wait for the LDS-DMA)
                 HX_WAIT_LGKM0();
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                load_frags(nxt, 0, f0);          // (at the end of a tile: the next tile's step 0 — reloaded below)
+                // The refill goes out FIRST: its round trip (L2 / Infinity Cache / HBM) is the longest latency of the step
+                // and it has exactly one step to land (fc2, whose A panels stream from HBM: 4.5 -> 4.2 ms).  It targets
+                // slot g&1; the fragment reads below are from the other slot.
                 stage();
+                load_frags(nxt, 0, f0);          // (at the end of a tile: the next tile's step 0 — reloaded below)
                 mfma_half(f1);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2 * PPW, 0);
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 2 * PPW; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 advance();
@@ -1089,11 +1092,11 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     HX_WAIT_VM(0);
 }
 
-template <int EPI, int WN>
-int launch_p256(GemmP p, hipStream_t s) {
+template <int EPI, int WN, bool DBG>
+int launch_p256_impl(GemmP p, hipStream_t s) {
     static bool configured = false;
     static int cus = 0;
-    auto kern = gemm_p256<EPI, WN>;
+    auto kern = gemm_p256<EPI, WN, DBG>;
     constexpr int NW = 512 / WN;
     constexpr int LDS = 2 * Q_STEP + NW * P_STG;
     if (!configured) {
@@ -1111,6 +1114,15 @@ int launch_p256(GemmP p, hipStream_t s) {
     if (nslot > per_xcd) nslot = per_xcd;
     hipLaunchKernelGGL(kern, dim3(8 * nslot), dim3(64 * NW), LDS, s, p);
     return hirest_launch_status();
+}
+
+template <int EPI, int WN>
+int launch_p256(GemmP p, hipStream_t s) {
+    if constexpr (WN == 64 && (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_RESID_F32)) {
+        if (p.dbg) return launch_p256_impl<EPI, WN, true>(p, s);       // experiment kernel: the three tower epilogues only
+    }
+    p.dbg = 0;
+    return launch_p256_impl<EPI, WN, false>(p, s);
 }
 
 template <int EPI>

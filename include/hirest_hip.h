@@ -79,7 +79,8 @@ int hirest_gemm_select_kernel(int32_t which);
  * main-loop barrier and waits of the t256p kernel, bit2 = the persistent kernel streams tile (0,0)'s operands for
  * every tile (L2-resident operands).  Bits 3-5 only reorder the persistent kernel's tile walk (results stay correct):
  * bit3 force the grouped order, bit4 force panel-major, bit5 pair ragged edge tiles into equal-duration units.
- * 0 restores normal operation. */
+ * Persistent kernel, results wrong: bit6 no wait for the LDS-DMA, bit7 DMA of the A operand only, bit8 half the fragment
+ * reads.  Any non-zero value selects a separate (slower-scheduled) instantiation.  0 restores normal operation. */
 int hirest_gemm_debug_mode(int32_t bits);
 
 /* ------------------------------------------------------------------------------------

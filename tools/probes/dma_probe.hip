@@ -75,8 +75,9 @@ __global__ __launch_bounds__(NWAVES * 64) void vgpr_stream(const char* __restric
     if (threadIdx.x == 0) sink[blockIdx.x] = smem[ksteps & 1023];
 }
 
-int main() {
-    const int rows = 65536; const int64_t row_bytes = 2816;   // K=1408 bf16
+int main(int argc, char** argv) {
+    const int rows = argc > 1 ? atoi(argv[1]) : 65536;        // 65536 rows = 184 MB (Infinity-Cache resident); 4096 = 11.5 MB (L2)
+    const int64_t row_bytes = 2816;   // K=1408 bf16
     char* A; CK(hipMalloc(&A, rows * row_bytes)); CK(hipMemset(A, 1, rows * row_bytes));
     int* sink; CK(hipMalloc(&sink, 4096 * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
