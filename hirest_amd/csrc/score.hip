@@ -137,6 +137,97 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sco
     }
 }
 
+// Long rows (beam search: 5 rows x beams*vocab = 152 620 scores) as two passes: every 4096-element chunk of a row yields
+// its own top-k candidates (score, tie key, index) in parallel, then one block per row selects among the candidates.
+// Same strict order, so the result equals topk_kernel's.
+constexpr int TOPK_CHUNK = 4096;
+__global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ scores, const int32_t* __restrict__ tie_rank,
+                                                        int V, int k, int nchunk, float* __restrict__ cs, int32_t* __restrict__ ct,
+                                                        int32_t* __restrict__ ci) {
+    __shared__ float rs[4];
+    __shared__ int rt[4];
+    __shared__ int ri[4];
+    __shared__ float ps; __shared__ int pt;
+    const int q = blockIdx.y, c = blockIdx.x;
+    const float* row = scores + (int64_t)q * V;
+    const int v0 = c * TOPK_CHUNK, v1 = min(V, v0 + TOPK_CHUNK);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float prev_s = INFINITY; int prev_t = 0x7fffffff;
+    const int64_t ob = ((int64_t)q * nchunk + c) * k;
+    for (int j = 0; j < k; ++j) {
+        float bs = -INFINITY; int bt = -0x7fffffff - 1; int bi = -1;
+        for (int v = v0 + tid; v < v1; v += 256) {
+            const float s = row[v];
+            const int t = tie_rank ? tie_rank[v] : v;
+            if (better(prev_s, prev_t, s, t) && (bi < 0 || better(s, t, bs, bt))) { bs = s; bt = t; bi = v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const int ot = __shfl_xor(bt, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi >= 0 && (bi < 0 || better(os, ot, bs, bt))) { bs = os; bt = ot; bi = oi; }
+        }
+        if (lane == 0) { rs[wave] = bs; rt[wave] = bt; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float s = rs[0]; int t = rt[0]; int i = ri[0];
+            for (int w = 1; w < 4; ++w)
+                if (ri[w] >= 0 && (i < 0 || better(rs[w], rt[w], s, t))) { s = rs[w]; t = rt[w]; i = ri[w]; }
+            cs[ob + j] = s; ct[ob + j] = t; ci[ob + j] = i;          // i < 0: the chunk has fewer than j+1 elements
+            ps = s; pt = t;
+        }
+        __syncthreads();
+        prev_s = ps; prev_t = pt;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ct,
+                                                        const int32_t* __restrict__ ci, int ncand, int k,
+                                                        int32_t* __restrict__ out_index, float* __restrict__ out_score) {
+    __shared__ float rs[4];
+    __shared__ int rt[4];
+    __shared__ int ri[4];
+    __shared__ float ps; __shared__ int pt;
+    const int q = blockIdx.x;
+    const float* s_ = cs + (int64_t)q * ncand;
+    const int32_t* t_ = ct + (int64_t)q * ncand;
+    const int32_t* i_ = ci + (int64_t)q * ncand;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float prev_s = INFINITY; int prev_t = 0x7fffffff;
+    for (int j = 0; j < k; ++j) {
+        float bs = -INFINITY; int bt = -0x7fffffff - 1; int bi = -1;
+        for (int v = tid; v < ncand; v += 256) {
+            const int idx = i_[v];
+            if (idx < 0) continue;
+            const float s = s_[v];
+            const int t = t_[v];
+            if (better(prev_s, prev_t, s, t) && (bi < 0 || better(s, t, bs, bt))) { bs = s; bt = t; bi = idx; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const int ot = __shfl_xor(bt, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi >= 0 && (bi < 0 || better(os, ot, bs, bt))) { bs = os; bt = ot; bi = oi; }
+        }
+        if (lane == 0) { rs[wave] = bs; rt[wave] = bt; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float s = rs[0]; int t = rt[0]; int i = ri[0];
+            for (int w = 1; w < 4; ++w)
+                if (ri[w] >= 0 && (i < 0 || better(rs[w], rt[w], s, t))) { s = rs[w]; t = rt[w]; i = ri[w]; }
+            out_index[(int64_t)q * k + j] = i;
+            if (out_score) out_score[(int64_t)q * k + j] = s;
+            ps = s; pt = t;
+        }
+        __syncthreads();
+        prev_s = ps; prev_t = pt;
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int hirest_pool_l2norm(const float* frame_embeds, float* out, int32_t V, int32_t F, int32_t E,
@@ -162,5 +253,30 @@ extern "C" int hirest_topk_f32(const float* scores, const int32_t* tie_rank, int
     if (!scores || !out_index || Q <= 0 || V <= 0 || k <= 0 || k > V) return HIREST_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(topk_kernel, dim3(Q), dim3(256), 0, s, scores, tie_rank, V, k, out_index, out_score);
+    return hirest_launch_status();
+}
+
+extern "C" int64_t hirest_topk_workspace_bytes(int32_t Q, int32_t V, int32_t k) {
+    if (Q <= 0 || V <= 0 || k <= 0) return HIREST_E_BADARG;
+    const int64_t nchunk = (V + TOPK_CHUNK - 1) / TOPK_CHUNK;
+    return Q * nchunk * k * 12;
+}
+
+extern "C" int hirest_topk_f32_ws(const float* scores, const int32_t* tie_rank, int32_t Q, int32_t V, int32_t k,
+                                  int32_t* out_index, float* out_score, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!scores || !out_index || Q <= 0 || V <= 0 || k <= 0 || k > V) return HIREST_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nchunk = (V + TOPK_CHUNK - 1) / TOPK_CHUNK;
+    if (nchunk < 4 || Q > 65535) {                                         // short rows: one pass is enough
+        hipLaunchKernelGGL(topk_kernel, dim3(Q), dim3(256), 0, s, scores, tie_rank, V, k, out_index, out_score);
+        return hirest_launch_status();
+    }
+    const int64_t n = (int64_t)Q * nchunk * k;
+    if (!workspace || workspace_bytes < n * 12) return HIREST_E_WORKSPACE;
+    float* cs = reinterpret_cast<float*>(workspace);
+    int32_t* ct = reinterpret_cast<int32_t*>(cs + n);
+    int32_t* ci = ct + n;
+    hipLaunchKernelGGL(topk_chunk_kernel, dim3(nchunk, Q), dim3(256), 0, s, scores, tie_rank, V, k, nchunk, cs, ct, ci);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(Q), dim3(256), 0, s, cs, ct, ci, nchunk * k, k, out_index, out_score);
     return hirest_launch_status();
 }

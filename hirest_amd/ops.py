@@ -156,6 +156,13 @@ def topk(scores: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
     Q, V = scores.shape
     idx = torch.empty((Q, k), dtype=torch.int32, device=scores.device)
     val = torch.empty((Q, k), dtype=torch.float32, device=scores.device)
+    if V >= 16384:                                   # long rows (beam search over beams * vocab): chunked two-pass selection
+        need = lib.hirest_topk_workspace_bytes(Q, V, k)
+        ws = torch.empty(need, dtype=torch.uint8, device=scores.device)
+        _lib.check(lib.hirest_topk_f32_ws(_dev(scores, torch.float32, "topk.scores"), _opt(tie_rank, torch.int32, "topk.tie_rank"),
+                                          Q, V, k, idx.data_ptr(), val.data_ptr(), ws.data_ptr(), need, stream_ptr()),
+                   "hirest_topk_f32_ws")
+        return val, idx
     _lib.check(lib.hirest_topk_f32(_dev(scores, torch.float32, "topk.scores"), _opt(tie_rank, torch.int32, "topk.tie_rank"),
                                    Q, V, k, idx.data_ptr(), val.data_ptr(), stream_ptr()), "hirest_topk_f32")
     return val, idx

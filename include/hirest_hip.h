@@ -151,6 +151,11 @@ int hirest_similarity_f32(const float* text_n, const float* video_n, float* scor
  * = the reference's sorted(zip(scores, names))[::-1] when tie_rank[v] = rank of names[v]. */
 int hirest_topk_f32(const float* scores, const int32_t* tie_rank, int32_t Q, int32_t V, int32_t k,
                     int32_t* out_index, float* out_score, void* stream);
+/* The same selection for long rows (beam search over beams*vocab scores): per-chunk candidates in parallel, then a merge.
+ * workspace: hirest_topk_workspace_bytes; identical results. */
+int64_t hirest_topk_workspace_bytes(int32_t Q, int32_t V, int32_t k);
+int hirest_topk_f32_ws(const float* scores, const int32_t* tie_rank, int32_t Q, int32_t V, int32_t k,
+                       int32_t* out_index, float* out_score, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Whole-tower runners: one call = one forward of a transformer tower over a batch, all

@@ -222,6 +222,27 @@ def test_embed_tokens_exact(dev, ops):
     assert torch.equal(eot.cpu().long(), torch.arange(B) * L + tok.argmax(-1))
 
 
+@pytest.mark.parametrize("Q,V,k", [(5, 152620, 5), (3, 91572, 3), (7, 16384, 10), (2, 20001, 16)])
+def test_topk_long_rows_two_pass(dev, ops, Q, V, k):
+    """Chunked two-pass selection (beam search over beams*vocab) == the single-pass kernel == the oracle, ties included."""
+    from oracle import ref_cpu as O
+    from hirest_amd import _lib
+    s = synth.tensor("tk.long", (Q, V), 1.0, 5)
+    s = (s * 64).round() / 64                       # few distinct values: many exact ties
+    tie = torch.from_numpy(np.random.default_rng(1).permutation(V).astype(np.int32))
+    sd = s.to(dev)
+    for tr in (None, tie):
+        trd = None if tr is None else tr.to(dev)
+        val, idx = ops.topk(sd, k, trd)
+        ref = O.topk_with_ties(s, tr if tr is not None else torch.arange(V, dtype=torch.int32), k)
+        assert torch.equal(idx.cpu().long(), ref.long())
+        assert torch.equal(val.cpu(), torch.gather(s, 1, ref.long()))
+        i1 = torch.empty((Q, k), dtype=torch.int32, device=dev)         # single-pass kernel through the plain entry point
+        _lib.check(_lib.load().hirest_topk_f32(sd.data_ptr(), None if trd is None else trd.data_ptr(), Q, V, k,
+                                              i1.data_ptr(), None, ops.stream_ptr()), "topk")
+        assert torch.equal(i1, idx)
+
+
 def test_pool_similarity_topk(dev, ops, golden_dir):
     from oracle import ref_cpu as O
     V, F, E, Q = 37, 32, 1024, 19
