@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
     ap.add_argument("--chunk", type=int, default=1024, help="frames per tower call (micro-batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the batch timed on the CPU oracle (~10-15 s)")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 force t128, 2 force t256 (A/B timing)")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="hirest_gemm_debug_mode bits: TIMING EXPERIMENTS ONLY, the line is not a valid result")
     args = ap.parse_args()
