@@ -25,7 +25,7 @@ struct GemmF {
     int M, N, K, act;   // act: 0 none, 1 gelu (erf), 2 tanh
 };
 
-constexpr int FK = 16, FLD = FK + 1;
+constexpr int FK = 32, FLD = FK + 1;      // K is staged 32 deep; K itself only has to be a multiple of 16 (zero fill)
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     __shared__ float As[64 * FLD];
@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int M0 = blockIdx.y * 64, N0 = blockIdx.x * 64;
-    // staging: thread -> (row = tid/4, 4 consecutive k = (tid%4)*4)
-    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    // staging: thread -> (row = tid/4, 8 consecutive k = (tid%4)*8); the next 32-deep slab is loaded into registers while
+    // the current one is multiplied — these GEMMs run as one or two waves of blocks (M = 25 ... 1500), so the global
+    // latency of a synchronous load per slab (44 us for K = 768) was the whole kernel time
+    const int srow = tid >> 2, sk = (tid & 3) * 8;
     int gm = M0 + srow; gm = gm < p.M ? gm : p.M - 1;
     int gn = N0 + srow; gn = gn < p.N ? gn : p.N - 1;
     const float* ap = p.A + (int64_t)gm * p.lda + sk;
@@ -44,13 +46,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int arow = (wm * 32 + (lane & 31)) * FLD + (lane >> 5);
     const int wrow = (wn * 32 + (lane & 31)) * FLD + (lane >> 5);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int k0, f32x4 (&av)[2], f32x4 (&wv)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool in = k0 + sk + 4 * h < p.K;            // K % 4 == 0: a 4-vector is inside or outside as a whole
+            av[h] = in ? *reinterpret_cast<const f32x4*>(ap + k0 + 4 * h) : zero;
+            wv[h] = in ? *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h) : zero;
+        }
+    };
+    f32x4 av[2], wv[2];
+    fetch(0, av, wv);
     for (int k0 = 0; k0 < p.K; k0 += FK) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k0);
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + k0);
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { As[srow * FLD + sk + e] = av[e]; Ws[srow * FLD + sk + e] = wv[e]; }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { As[srow * FLD + sk + 4 * h + e] = av[h][e]; Ws[srow * FLD + sk + 4 * h + e] = wv[h][e]; }
         __syncthreads();
+        if (k0 + FK < p.K) fetch(k0 + FK, av, wv);
 #pragma unroll
         for (int kk = 0; kk < FK; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + kk], As[arow + kk], acc, 0, 0, 0);
@@ -377,7 +391,7 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
                                const float* resid, int64_t ldr, const float* periodic, int32_t period,
                                float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return HIREST_E_BADARG;
-    if (K % FK != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
+    if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     return hirest_launch_status();
