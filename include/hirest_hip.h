@@ -12,7 +12,8 @@
  * sizes, no torch types.  Conventions for every entry point:
  *   - all pointers are DEVICE pointers unless the name says host;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing
- *     synchronises, nothing allocates device memory, there is no hidden global state;
+ *     synchronises, nothing allocates device memory, there is no hidden global state
+ *     (besides the test / timing switches hirest_*_select_kernel, hirest_*_debug_mode and the optional profiler);
  *   - return value: 0 on success, a negative HIREST_E_* for argument errors, or a
  *     positive hipError_t from the launch;
  *   - bf16 tensors are raw uint16 bit patterns (round-to-nearest-even from fp32);
@@ -105,8 +106,9 @@ int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_index,
 int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out,
                           int32_t B, int32_t N, int32_t H, int32_t dh,
                           float scale, int32_t causal, void* stream);
-/* 1 = register-staged kernel with a transposed V image, 2 (default) = LDS-DMA staging + hardware
- * transpose reads.  For tests / A-B timing. */
+/* 1 = register-staged kernel with a transposed V image, 2 = LDS-DMA staging + hardware transpose reads, one workgroup
+ * per (frame, head), 3 (default) = 2's arithmetic in one persistent workgroup per frame (used for 80 < N <= 272 tokens
+ * and >= 64 frames; other shapes fall back to 2).  For tests / A-B timing. */
 int hirest_attention_select_kernel(int32_t which);
 /* TIMING EXPERIMENTS ONLY (results become wrong), persistent kernel: bit0 skip the S^T MFMAs, bit1 skip the softmax
  * exponentials, bit2 skip P.V, bit3 skip the K/V LDS-DMA.  0 restores normal operation. */
