@@ -1092,6 +1092,267 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     HX_WAIT_VM(0);
 }
 
+
+// =================================================================================================
+// Kernel "pp256": persistent 256x256 tile, PING-PONG wave groups.  Waves 0-3 (group 0) and 4-7 (group 1, the same
+// SIMDs) run the same phase sequence one barrier apart, so that while one wave of a SIMD executes its 16 MFMAs the
+// other one reads fragments, issues LDS-DMA and waits — the matrix pipe always has exactly one feeder.
+// A 64-deep K step is four phases over the wave's 128x64 output, one 64x32 quadrant each over the FULL K step:
+//     P1 (a0,b0)   P2 (a0,b1)   P3 (a1,b1)   P4 (a1,b0)      a = 64-row half of the wave's A block, b = 32-column half of its W block
+//     phase = [ LOAD: vmcnt | ds_read | LDS-DMA ]  barrier  lgkmcnt(0)  [ 16 MFMA ]  barrier
+// Each 128-row group of a ring slot is read in ONE LOAD (a0,b0: P1; b1: P2; a1: P3) and refilled two phases later
+// (a0,b0: P3; b1: P4; a1: next P1) with the data of step +2; a group is waited for (counted vmcnt: "all but the 8
+// newest pieces") in the LOAD one phase BEFORE the LOAD that reads it (a0,b0: P4; b1: P1; a1: P2).
+// Why that is race-free with the one-barrier skew (hardware barrier k pairs group 0's k-th with group 1's (k-1)-th):
+//   RAW  a wave's wait in LOAD(p-1) precedes its next barrier; every reader passes one more barrier before its
+//        LOAD(p), and by then the other group has arrived at (= executed everything before) the paired barrier, which
+//        lies after its own LOAD(p-1).
+//   WAR  reads issued in LOAD(p) retire at the lgkmcnt(0) right after the phase's first barrier; a refill in LOAD(p+2)
+//        of either group comes after a barrier at which the other group had already passed that lgkmcnt(0).
+// Registers: one A sub-block (8 fragments) + both W sub-blocks (2 x 4): 64 VGPRs — nothing is prefetched across phases.
+// =================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
+    constexpr int NI = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                       // ping-pong group; waves w and w+4 share a SIMD
+    const int wr = grp, wc = wave & 3;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3, nslot = gridDim.x >> 3;
+    const int p_lo = xcd * p.ppx;
+    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    if (np <= 0) return;
+    const bool panel_major = p.nbn <= 8;
+    const int nunit = np * p.nbn;
+    if (slot >= nunit) return;
+    auto tile_origin = [&](int j, int& M0, int& N0) {        // same walk as p256 (see there)
+        if (panel_major) {
+            const int mt_i = j / p.nbn;
+            M0 = (p_lo + mt_i) * T_BM; N0 = (j - mt_i * p.nbn) * T_BN;
+            return;
+        }
+        const int g_ = j / (GROUP_M * p.nbn);
+        const int r = j - g_ * GROUP_M * p.nbn;
+        int gcount = np - g_ * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
+        const int nt_i = r / gcount, mt_i = p_lo + g_ * GROUP_M + (r - nt_i * gcount);
+        M0 = mt_i * T_BM; N0 = nt_i * T_BN;
+    };
+
+    // ---- LDS-DMA stream.  Row group -> 16 pieces of 8 rows, two per wave: piece j = 2*wave + q.
+    //   A groups: j < 8 -> rows a*64 + 8j of the wr = 0 block, j >= 8 -> of the wr = 1 block (+128)
+    //   W groups: run j/4 = wc block, rows wc*64 + b*32 + 8*(j%4)
+    const int nst = p.K / Q_BK;
+    uint32_t a_off[2][2], w_off[2][2];
+    int a_lds[2][2], w_lds[2][2];
+    const char* a_base; const char* w_base;
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = 2 * wave + q;
+            a_lds[hsel][q] = ((j >> 3) * 128 + hsel * 64 + (j & 7) * 8) * 128;
+            w_lds[hsel][q] = Q_WOFF + ((j >> 2) * 64 + hsel * 32 + (j & 3) * 8) * 128;
+        }
+    auto set_sources = [&](int M0, int N0) {
+#pragma unroll
+        for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ra0 = (a_lds[hsel][q] >> 7) + (lane >> 3);
+                const int rw0 = ((w_lds[hsel][q] - Q_WOFF) >> 7) + (lane >> 3);
+                const int ca = (lane & 7) ^ ((ra0 >> 1) & 7), cw = (lane & 7) ^ ((rw0 >> 1) & 7);
+                int ra = p.M - 1 - M0; ra = ra0 < ra ? ra0 : ra;
+                int rn = p.N - 1 - N0; rn = rw0 < rn ? rw0 : rn;
+                a_off[hsel][q] = (uint32_t)(ra * (int)p.lda + ca * 8) * 2u;
+                w_off[hsel][q] = (uint32_t)(rn * (int)p.ldw + cw * 8) * 2u;
+            }
+        a_base = reinterpret_cast<const char*>(p.A + (int64_t)M0 * p.lda);
+        w_base = reinterpret_cast<const char*>(p.W + (int64_t)N0 * p.ldw);
+    };
+    // The refill stream is two steps ahead of the step being multiplied; its a1 group is issued one step later than its
+    // a0 / b0 / b1 groups (in the next step's P1), so the stream keeps the previous step's A source as well.
+    int dma_j = slot, dma_k = 0, dma_g = 0;
+    bool dma_live = true;
+    const char* a1_base; uint32_t a1_off[2]; int a1_k = 0, a1_g = 0;    // pending a1 group: source of the step issued last
+    auto issue_a0 = [&]() {
+        char* buf = smem + (dma_g & 1) * Q_STEP;
+        const char* ab = a_base + (int64_t)dma_k * (Q_BK * 2);
+        glds16(ab + a_off[0][0], buf + a_lds[0][0]);
+        glds16(ab + a_off[0][1], buf + a_lds[0][1]);
+    };
+    auto issue_w = [&](int hsel) {
+        char* buf = smem + (dma_g & 1) * Q_STEP;
+        const char* wb = w_base + (int64_t)dma_k * (Q_BK * 2);
+        glds16(wb + w_off[hsel][0], buf + w_lds[hsel][0]);
+        glds16(wb + w_off[hsel][1], buf + w_lds[hsel][1]);
+    };
+    auto issue_a1_pending = [&]() {
+        char* buf = smem + (a1_g & 1) * Q_STEP;
+        const char* ab = a1_base + (int64_t)a1_k * (Q_BK * 2);
+        glds16(ab + a1_off[0], buf + a_lds[1][0]);
+        glds16(ab + a1_off[1], buf + a_lds[1][1]);
+    };
+    auto advance = [&]() {   // after a step's a0, b0, b1 were issued: remember its a1 group, move to the next step
+        a1_base = a_base; a1_off[0] = a_off[1][0]; a1_off[1] = a_off[1][1]; a1_k = dma_k; a1_g = dma_g;
+        ++dma_g;
+        if (dma_live && ++dma_k == nst) {
+            dma_j += nslot;
+            if (dma_j < nunit) { int m0, n0; tile_origin(dma_j, m0, n0); set_sources(m0, n0); dma_k = 0; }
+            else { dma_live = false; dma_k = nst - 1; }        // past the end: refetch of the last step, never consumed
+        }
+    };
+
+    // ---- fragments of v_mfma_f32_16x16x32_bf16: lane -> row (lane & 15), 8 consecutive k at 8 * (lane >> 4)
+    const int frow = lane & 15, fsw = (frow >> 1) & 7, kg = lane >> 4;
+    const int a_frag = (wr * 128 + frow) * (Q_BK * 2);
+    const int w_frag = Q_WOFF + (wc * 64 + frow) * (Q_BK * 2);
+    int koff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) koff[h] = ((4 * h + kg) ^ fsw) << 4;
+    struct FA { bf16x8 v[4][2]; };
+    struct FW { bf16x8 v[2][2]; };
+    FA Af;
+    FW W0, W1;
+    auto read_a = [&](const char* buf, int a) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) Af.v[m][h] = *reinterpret_cast<const bf16x8*>(buf + a_frag + (a * 64 + m * 16) * 128 + koff[h]);
+    };
+    auto read_w = [&](const char* buf, int b, FW& f) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) f.v[n][h] = *reinterpret_cast<const bf16x8*>(buf + w_frag + (b * 32 + n * 16) * 128 + koff[h]);
+    };
+    f32x4 acc[8][NI];
+    auto mfma_q = [&](int a, int b, FW& fw) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.v[n][h], Af.v[m][h], acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+
+    // ---- prologue: steps 0 and 1 completely (their a1 groups included), everything drained; then the skew barrier
+    {
+        int m0, n0;
+        tile_origin(slot, m0, n0);
+        set_sources(m0, n0);
+    }
+    for (int i = 0; i < 2; ++i) { issue_a0(); issue_w(0); issue_w(1); advance(); issue_a1_pending(); }
+    // the stream's "pending a1" now belongs to step 1 and is already issued: the first in-loop P1 must not issue it again.
+    // Make the pending group the a1 group of step 2 instead by issuing step 2's early groups in the loop as usual:
+    // (P1 issues the pending a1 = step g+1's; see the loop) -> mark it consumed
+    bool a1_valid = false;
+    HX_WAIT_VM(0);
+    bar();
+    if (grp == 1) bar();                              // group 1 runs one barrier behind group 0 from here on
+
+    char* stg = smem + 2 * Q_STEP + wave * P_STG;
+    int g = 0;                                        // global step index of the MFMA side: step g lives in ring slot g & 1
+    for (int j = slot; j < nunit; j += nslot) {
+        int M0, N0;
+        tile_origin(j, M0, N0);
+        const bool active = (N0 + wc * 64 < p.N) && (M0 + wr * 128 < p.M);
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (active) {
+            for (int t = 0; t < nst; ++t, ++g) {
+                const char* cur = smem + (g & 1) * Q_STEP;
+                // ---- P1 (a0,b0): wait b1(g); read a0, b0; refill a1 of step g+1 (its rows were last read in P3 of step g-1)
+                HX_WAIT_VM(8);
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(cur, 0); read_w(cur, 0, W0);
+                if (a1_valid) issue_a1_pending();
+                bar();
+                HX_WAIT_LGKM0();
+                mfma_q(0, 0, W0);
+                bar();
+                // ---- P2 (a0,b1): wait a1(g); read b1
+                HX_WAIT_VM(8);
+                __builtin_amdgcn_sched_barrier(0);
+                read_w(cur, 1, W1);
+                bar();
+                HX_WAIT_LGKM0();
+                mfma_q(0, 1, W1);
+                bar();
+                // ---- P3 (a1,b1): read a1; refill a0, b0 with step g+2 (read in P1)
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(cur, 1);
+                issue_a0(); issue_w(0);
+                bar();
+                HX_WAIT_LGKM0();
+                mfma_q(1, 1, W1);
+                bar();
+                // ---- P4 (a1,b0): wait a0, b0 of step g+1; refill b1 with step g+2 (read in P2)
+                HX_WAIT_VM(8);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_w(1);
+                advance();
+                a1_valid = true;
+                bar();
+                mfma_q(1, 0, W0);
+                bar();
+            }
+            epilogue_p<EPI, NI>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
+        } else {
+            // the same wait / DMA / barrier skeleton for a wave whose output block lies in the padding of a ragged edge tile
+            for (int t = 0; t < nst; ++t, ++g) {
+                HX_WAIT_VM(8);
+                if (a1_valid) issue_a1_pending();
+                bar(); bar();
+                HX_WAIT_VM(8);
+                bar(); bar();
+                issue_a0(); issue_w(0);
+                bar(); bar();
+                HX_WAIT_VM(8);
+                issue_w(1);
+                advance();
+                a1_valid = true;
+                bar(); bar();
+            }
+        }
+    }
+    if (grp == 0) bar();                              // pair the skew barrier
+    HX_WAIT_VM(0);
+}
+
+template <int EPI>
+int launch_pp256(GemmP p, hipStream_t s) {
+    static bool configured = false;
+    static int cus = 0;
+    auto kern = gemm_pp256<EPI>;
+    constexpr int LDS = 2 * Q_STEP + 8 * P_STG;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        int dev = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+        configured = true;
+    }
+    p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
+    p.ppx = (p.nbm + 7) / 8;
+    int nslot = cus / 8; nslot = nslot < 1 ? 1 : nslot;
+    const int per_xcd = p.ppx * p.nbn;
+    if (nslot > per_xcd) nslot = per_xcd;
+    hipLaunchKernelGGL(kern, dim3(8 * nslot), dim3(512), LDS, s, p);
+    return hirest_launch_status();
+}
+
 template <int EPI, int WN, bool DBG>
 int launch_p256_impl(GemmP p, hipStream_t s) {
     static bool configured = false;
@@ -1181,8 +1442,11 @@ int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 w
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
+    // long-K shapes (fc2: K = 6144, A streaming from HBM) run 4-5 % faster on the ping-pong kernel, K = 1408 shapes do not
+    if (g_force_kernel == 0 && big && p.K >= 4096) return launch_pp256<EPI>(p, s);
     if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);
     if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
+    if (g_force_kernel == 8) return launch_pp256<EPI>(p, s);
     if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
@@ -1198,7 +1462,7 @@ int g_gemm_dbg = 0;
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    if (which < 0 || which > 7) return HIREST_E_BADARG;
+    if (which < 0 || which > 8) return HIREST_E_BADARG;
     g_force_kernel = which;
     return 0;
 }

@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=40)
 ap.add_argument("--repeats", type=int, default=5)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--variant", type=int, default=6, help="kernel under test (hirest_gemm_select_kernel)")
 ap.add_argument("--full", action="store_true", help="the four production shapes at M = 263168 instead of random shapes")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -35,7 +36,7 @@ for c in range(a.cases):
     ref = run(1)
     ok = True
     for r in range(a.repeats):
-        got = run(6)
+        got = run(a.variant)
         if not torch.equal(got, ref):
             ok = False
             d = (got.float() - ref.float()).abs()
