@@ -106,6 +106,8 @@ _SIGNATURES = {
     "hirest_interval_iou_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "hirest_step_bound_pr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hirest_frame_to_timestamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "hirest_timestamp_to_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "hirest_preprocess_moment_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                   C.c_int32, C.c_void_p]),
     "hirest_vision_workspace_bytes": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),

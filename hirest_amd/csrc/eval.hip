@@ -104,6 +104,55 @@ __global__ void preprocess_bounds_kernel(const double* __restrict__ preds, const
     out_count[v] = cnt;
 }
 
+// hirest_dataset.py:12-68: bins = np.linspace(0, int(duration) - 1, n).  numpy builds it as arange(n) * step with
+// step = (stop - start) / (n - 1) in double and overwrites the last element with `stop`; the bin value is recomputed
+// here on demand (one multiply) instead of materialising n doubles per conversion as the reference does.
+struct Bins {
+    int64_t n; double stop, step;
+    __device__ __forceinline__ double at(int64_t i) const { return (i == n - 1 && n > 1) ? stop : (n > 1 ? (double)i * step : 0.0); }
+};
+__device__ __forceinline__ bool make_bins(double duration, int32_t n_frames, Bins& b) {
+    const int64_t d = (int64_t)duration;                       // Python int(): truncation toward zero
+    b.n = n_frames < 0 ? d : n_frames;                         // n_frames < 0: one frame per second
+    b.stop = (double)(d - 1);
+    b.step = b.n > 1 ? b.stop / (double)(b.n - 1) : 0.0;
+    return d >= 1 && b.n >= 1;                                 // shorter than one second: the reference's bins are empty / decreasing
+}
+
+__global__ void frame_to_timestamp_kernel(const int64_t* __restrict__ frame, const double* __restrict__ duration,
+                                          const int32_t* __restrict__ n_frames, int32_t n_frames_all, int64_t per_video, int64_t n,
+                                          int64_t* __restrict__ ts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t v = i / per_video;
+    Bins b;
+    int64_t f = frame[i];
+    if (!make_bins(duration[v], n_frames ? n_frames[v] : n_frames_all, b)) { ts[i] = INT64_MIN; return; }
+    if (f < 0) f += b.n;                                       // numpy negative indexing
+    ts[i] = (f < 0 || f >= b.n) ? INT64_MIN : (int64_t)b.at(f);   // IndexError in the reference
+}
+
+// np.digitize(t, bins, right=True) = number of bins strictly below t, then min(., n - 1)
+__global__ void timestamp_to_frame_kernel(const double* __restrict__ t, const double* __restrict__ duration,
+                                          const int32_t* __restrict__ n_frames, int32_t n_frames_all, int64_t per_video, int64_t n,
+                                          int64_t* __restrict__ frame) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t v = i / per_video;
+    Bins b;
+    if (!make_bins(duration[v], n_frames ? n_frames[v] : n_frames_all, b)) { frame[i] = INT64_MIN; return; }
+    const double x = t[i];
+    if (x != x) { frame[i] = b.n - 1; return; }                // NaN sorts after every bin
+    int64_t k = 0;
+    if (b.step > 0.0 && x > 0.0) {                             // first guess from the spacing, then settle on the exact bin values
+        const double g = ceil(x / b.step);
+        k = g >= (double)b.n ? b.n : (int64_t)g;
+    }
+    while (k > 0 && !(b.at(k - 1) < x)) --k;
+    while (k < b.n && b.at(k) < x) ++k;
+    frame[i] = k < b.n - 1 ? k : b.n - 1;
+}
+
 }  // namespace
 
 extern "C" int hirest_interval_iou_f64(const double* a, const double* b, int64_t n, double* iou, void* stream) {
@@ -128,5 +177,23 @@ extern "C" int hirest_preprocess_moment_bounds(const double* preds, const int32_
     if (!preds || !pred_off || !gt_minmax || !out || !out_count || V < 0 || max_out < 1) return HIREST_E_BADARG;
     hipLaunchKernelGGL(preprocess_bounds_kernel, dim3((V + 63) / 64), dim3(64), 0, (hipStream_t)stream, preds, pred_off, gt_minmax,
                        V, out, out_count, max_out);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_frame_to_timestamp(const int64_t* frame, const double* duration, const int32_t* n_frames, int32_t n_frames_all,
+                                         int64_t per_video, int64_t n, int64_t* timestamp, void* stream) {
+    if (n == 0) return 0;
+    if (!frame || !duration || !timestamp || n < 0 || per_video < 1) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(frame_to_timestamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frame, duration,
+                       n_frames, n_frames_all, per_video, n, timestamp);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_timestamp_to_frame(const double* t, const double* duration, const int32_t* n_frames, int32_t n_frames_all,
+                                         int64_t per_video, int64_t n, int64_t* frame, void* stream) {
+    if (n == 0) return 0;
+    if (!t || !duration || !frame || n < 0 || per_video < 1) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(timestamp_to_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, duration,
+                       n_frames, n_frames_all, per_video, n, frame);
     return hirest_launch_status();
 }

@@ -778,6 +778,12 @@ constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128
 // Epilogue of p256: accumulators are 16x16 MFMA tiles, acc[mi][ni][e] = C[mi*16 + (lane&15)][ni*16 + 4*(lane>>4) + e]
 // (operands swapped, so a lane owns 4 consecutive columns of one row).  16 rows at a time go through a wave-private
 // XOR-swizzled staging area so that HBM sees whole 128-B lines.
+// Compiler-only ordering point for a wave-private LDS staging area: the LDS executes one wave's DS instructions in issue
+// order (a ds_read issued after a ds_write of the same bytes returns the new data, a ds_write issued after a ds_read
+// cannot overtake it), so no s_waitcnt is needed between the staging writes and the read-back — a wavefront-scope fence
+// would drain lgkmcnt twice per 16-row pass.
+#define HX_LDS_ORDER() asm volatile("" ::: "memory")
+
 template <int EPI, int NI>
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
     constexpr bool OUT_BF16 = (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_QGELU_BF16);
@@ -811,7 +817,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                     for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
                     *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((n * 2 + (kg >> 1)) ^ sw) << 4) + (kg & 1) * 8) = o;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                HX_LDS_ORDER();
                 const int mb = Mw + mi * 16;
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
@@ -824,7 +830,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         else if (n + 4 <= p.N) *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                HX_LDS_ORDER();
             }
         }
     } else {
@@ -863,7 +869,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         const f32x4 v = acc[mi][jp + nn] + bv[nn];
                         *reinterpret_cast<f32x4*>(stg + srow * 128 + (((nn * 4 + kg) ^ sw) << 4)) = v;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    HX_LDS_ORDER();
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
                         const int r = it * 8 + rr;
@@ -881,7 +887,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                             *reinterpret_cast<f32x4*>(outp + off) = w;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    HX_LDS_ORDER();
                 }
             }
         }

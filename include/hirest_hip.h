@@ -302,6 +302,20 @@ int hirest_preprocess_moment_bounds(const double* preds, const int32_t* pred_off
                                     double* out, int32_t* out_count, int32_t max_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Frame index <-> timestamp (hirest_dataset.py:12-68; run.py:731-732,769-770 turn predicted frame indices into the
+ * seconds that evaluate.py scores).  bins = np.linspace(0, int(duration) - 1, n), n = n_frames (< 0: int(duration)),
+ * evaluated in double exactly as numpy builds it (arange * step, last element = stop).  Element i belongs to video
+ * i / per_video (per_video = 2 for [V,2] moment bounds); n_frames is per video [V] or NULL (then n_frames_all).
+ *   hirest_frame_to_timestamp   timestamp[i] = int(bins[frame[i]]) (negative indices wrap like numpy); INT64_MIN where the
+ *                               reference raises IndexError (index outside the bins, or a video shorter than 1 s).
+ *   hirest_timestamp_to_frame   frame[i] = min(np.digitize(t[i], bins, right=True), n - 1); INT64_MIN for videos < 1 s.
+ * ------------------------------------------------------------------------------------ */
+int hirest_frame_to_timestamp(const int64_t* frame, const double* duration, const int32_t* n_frames, int32_t n_frames_all,
+                              int64_t per_video, int64_t n, int64_t* timestamp, void* stream);
+int hirest_timestamp_to_frame(const double* t, const double* duration, const int32_t* n_frames, int32_t n_frames_all,
+                              int64_t per_video, int64_t n, int64_t* frame, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Optional per-launch timing (bench.py's live roofline measurement).  When enabled, every
  * GEMM / attention / LayerNorm launch is bracketed by hipEventRecord on ITS launch stream;
  * hirest_profile_collect synchronises those events and returns one record per launch.

@@ -531,6 +531,41 @@ def gen_moment_eval():
     print(out["moment_retrieval"]["all"], out["step_bounds_preprocessed"]["all"])
 
 
+def timeline_cases():
+    """Inputs of the frame-index <-> timestamp fixture (pure numpy; shared with tests/test_timeline.py): per case the
+    frame indices 0..n-1 and a timestamp list holding a regular sweep past the end, every bin value exactly, and the
+    doubles just below / above every bin (the digitize(right=True) edge)."""
+    cases = []
+    for dur in (1.0, 1.9, 2.0, 3.7, 17.3, 59.9, 60.0, 199.99, 200.0, 367.8, 571.4, 1855.2, 2500.5):
+        for n in (-1, 1, 2, 3, 20, 32, 64, 300, 2048):
+            nn = int(dur) if n < 0 else n
+            bins = np.linspace(0, int(dur) - 1, nn)
+            t = np.concatenate([np.arange(-1.0, dur + 3.0, 0.37), bins, np.nextafter(bins, -np.inf), np.nextafter(bins, np.inf),
+                                np.arange(0, int(dur) + 2, dtype=np.float64)])
+            cases.append({"duration": dur, "n_frames": n, "frames": np.arange(nn, dtype=np.int64), "timestamps": t})
+    return cases
+
+
+def gen_timeline():
+    """hirest_dataset.py:12-68 run for real on timeline_cases(): digests of the int64 result arrays + their first values."""
+    import hashlib
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import hirest_dataset as ref_ds
+    out = []
+    for c in timeline_cases():
+        f2t = np.array([ref_ds.frame_index_to_timestamp(int(i), c["duration"], c["n_frames"]) for i in c["frames"]], dtype=np.int64)
+        t2f = np.array([ref_ds.timestamp_to_frame_index(float(t), c["duration"], c["n_frames"]) for t in c["timestamps"]], dtype=np.int64)
+        out.append({"duration": c["duration"], "n_frames": c["n_frames"],
+                    "frame_to_ts_sha256": hashlib.sha256(f2t.tobytes()).hexdigest(), "frame_to_ts_head": f2t[:6].tolist(),
+                    "frame_to_ts_tail": f2t[-3:].tolist(),
+                    "ts_to_frame_sha256": hashlib.sha256(t2f.tobytes()).hexdigest(), "ts_to_frame_head": t2f[:12].tolist(),
+                    "n_timestamps": int(len(t2f))})
+    with open(os.path.join(HERE, "timeline.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote timeline.json", len(out), "cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -553,6 +588,7 @@ def main():
         "preprocess": gen_preprocess,
         "features": gen_features,
         "moment_eval": gen_moment_eval,
+        "timeline": gen_timeline,
     }
     for name, fn in jobs.items():
         if args.only and name not in args.only:
