@@ -495,15 +495,21 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
                 }
                 if ((s2 & 1) || !FAST) __builtin_amdgcn_sched_barrier(0);   // FAST: regions of 2 key steps (24 reads in flight)
             }
+            // A lane holds 4 consecutive d of every 16-wide d tile (8-B stores, 32 B per query row and instruction).  Two
+            // v_permlane16_swap per d-tile pair (semantics: tools/probes/permlane_probe.hip) regroup them so the lane
+            // row g owns 8 consecutive d of tile (2*dp + (g&1)): 16-B stores, 64 contiguous bytes per query row.
+            static_assert((DP / 16) % 2 == 0 && DH % 8 == 0, "paired d tiles");
 #pragma unroll
-            for (int dt = 0; dt < DP / 16; ++dt) {
-                const int d = dt * 16 + 4 * g;
-                if (qvalid && d < DH) {
-                    bf16x4 o;
+            for (int dp = 0; dp < DP / 32; ++dp) {
+                union { bf16x4 v; unsigned u[2]; } e, o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(oacc[dt][i] * inv);
-                    *reinterpret_cast<bf16x4*>(out + ((int64_t)b * N + q) * D + h * DH + d) = o;
-                }
+                for (int i = 0; i < 4; ++i) { e.v[i] = (bf16_t)(oacc[2 * dp][i] * inv); o.v[i] = (bf16_t)(oacc[2 * dp + 1][i] * inv); }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(e.u[0], o.u[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(e.u[1], o.u[1], false, false);
+                union { bf16x8 v; unsigned u[4]; } w;
+                w.u[0] = s0[0]; w.u[1] = s1[0]; w.u[2] = s0[1]; w.u[3] = s1[1];
+                const int d = (2 * dp + (g & 1)) * 16 + (g >> 1) * 8;
+                if (qvalid && d < DH) *reinterpret_cast<bf16x8*>(out + ((int64_t)b * N + q) * D + h * DH + d) = w.v;
             }
         };
         if (wave < nqt) tile(wave, qa);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_bulk(const float* __restri
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = lane + 64 * i;
-                v[r][i] = c < nv ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[r][i] = c < nv ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_bulk(const float* __restri
                         bf16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[r][i][e] - mean) * rstd * g[i][e] + b[i][e]);
-                        *reinterpret_cast<bf16x4*>(orow + 4 * c) = o;
+                        __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(orow + 4 * c));
                     }
                 }
             }

@@ -434,7 +434,7 @@ __device__ __forceinline__ void epilogue_256(const GemmP& p, f32x16 (&acc)[4][2]
                 const int m = mb + r, n = Nw + c * 8;
                 if (m < p.M) {
                     bf16_t* dst = outp + (int64_t)m * p.ldo + n;
-                    if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+                    if (n + 8 <= p.N) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst));
                     else if (n + 4 <= p.N) *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
                 }
             }
@@ -826,7 +826,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                     const int m = mb + r, n = Nw + jp * 16 + rc * 8;
                     if (m < p.M) {
                         bf16_t* dst = outp + (int64_t)m * p.ldo + n;
-                        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+                        if (n + 8 <= p.N) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst));
                         else if (n + 4 <= p.N) *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
                     }
                 }
@@ -859,7 +859,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         const int pp = mm % p.P;
                         o[it] = ok ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                     } else if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32) {
-                        o[it] = ok ? *reinterpret_cast<const f32x4*>(outp + (int64_t)m * p.ldo + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        o[it] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(outp + (int64_t)m * p.ldo + n)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
 #pragma unroll
@@ -884,7 +884,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                             } else {
                                 off = (int64_t)m * p.ldo + n;
                             }
-                            *reinterpret_cast<f32x4*>(outp + off) = w;
+                            __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(outp + off));
                         }
                     }
                     HX_LDS_ORDER();

@@ -1,0 +1,8 @@
+run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bb.log 2>&1; python - <<PY
+import json
+x=json.loads(open("gpurun_out/bb.log").read().strip().splitlines()[-1])
+print("$1 frames/s %.0f"%x["value"], sorted([(e["tag"],e["dims"][1],e["dims"][2],round(e["avg_ms"],3)) for e in x["roofline"]["breakdown"][:5]]))
+PY
+}
+cp hirest_amd/lib/libhirest_hip.so /tmp/new.so
+run new; cp hirest_amd/lib/base.so.keep hirest_amd/lib/libhirest_hip.so; run base; cp /tmp/new.so hirest_amd/lib/libhirest_hip.so; run new; cp hirest_amd/lib/base.so.keep hirest_amd/lib/libhirest_hip.so; run base
