@@ -1,3 +1,6 @@
+#!/bin/bash
+# A/B of two builds inside ONE gpurun call (box-to-box variance is 5-8 %): copy the baseline library to
+# hirest_amd/lib/base.so.keep before rebuilding, then `gpurun -- bash tools/ab_lib.sh` alternates new / base twice.
 run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bb.log 2>&1; python - <<PY
 import json
 x=json.loads(open("gpurun_out/bb.log").read().strip().splitlines()[-1])

@@ -28,7 +28,12 @@ def main():
     ap.add_argument("--hipblaslt", action="store_true", help="also time torch.mm (hipBLASLt, no epilogue) as a yardstick")
     ap.add_argument("--lda-pad", type=int, default=0, help="extra elements in A's row stride (L2 set-conflict experiment)")
     ap.add_argument("--dbg", type=int, default=0, help="hirest_gemm_debug_mode bits (timing experiments)")
+    ap.add_argument("--nk", type=int, nargs=3, action="append", default=[], metavar=("N", "K", "EPI"),
+                    help="extra shape (repeatable), named n<N>k<K>e<EPI>")
     a = ap.parse_args()
+    for n, k, e in a.nk:
+        SHAPES[f"n{n}k{k}e{e}"] = (n, k, e)
+        a.shapes = [x for x in a.shapes] + [f"n{n}k{k}e{e}"]
     _lib.load().hirest_gemm_debug_mode(a.dbg)
     dev = torch.device("cuda:0")
     M = a.frames * 257
