@@ -317,6 +317,24 @@ def test_eva_g14_full_size_vs_reference(dev, golden_dir):
     # bf16 NCHW input = same result as f32 input holding bf16-representable values
     imb = img.to(torch.bfloat16)
     assert torch.equal(model.encode_image(imb), model.encode_image(imb.float()))
+    # BASELINE configs[1] at full size: one 1024-frame tower call (persistent p256 / pp256 GEMMs, 263168-row activations)
+    # with the golden frames planted among random ones; duplicates agree and chunking the big batch changes nothing
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    full = torch.randn((1024, 3, 224, 224), device=dev, generator=gen)
+    spots = [0, 517, 1023]
+    full[spots[0]], full[spots[1]], full[spots[2]] = img[0], img[1], img[0]
+    model.visual.max_frames_per_call = 1024
+    of = model.encode_image(full)
+    assert torch.isfinite(of).all() and torch.equal(of[0], of[1023])
+    # the reference's own outputs, now checked on rows of the full-size batch
+    _check_embed(of[spots[:2]].cpu(), torch.from_numpy(g["image_embed"]), "EVA-g/14 image, rows of a 1024-frame call")
+    # micro-batches of >= 64 frames all take the same kernels (below that the attention switches from the persistent
+    # per-frame form to one workgroup per head, equal within rounding only): a 64-frame call reproduces the rows exactly
+    assert torch.equal(model.encode_image(full[453:517 + 1])[-1], of[517])
+    assert (of[spots[:2]] - out).abs().max().item() < 2e-2 * out.abs().max().item()
+    model.visual.max_frames_per_call = 384                      # 384 + 384 + 256: ragged micro-batches
+    assert torch.equal(model.encode_image(full), of)
+    model.visual.max_frames_per_call = 256
 
 
 # ----------------------------------------------------------------------------------------
