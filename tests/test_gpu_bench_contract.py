@@ -1,0 +1,36 @@
+"""bench.py's output contract (one JSON line with the metric, the live roofline of the dominant kernel and the CPU
+baseline) on a reduced batch, so that a kernel or profile-format change cannot silently break what the driver parses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--frames", "256",
+                        "--chunk", "256", "--cpu-frames", "1"], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("encoded frames/sec") and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "bf16"
+    assert d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert d["value"] > 100 and abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    assert "traffic" in rf and rf["kernel"].startswith("gemm<") and rf["avg_launch_ms"] > 0
+    # achieved = algorithmic flops of the dominant kernel / its live average launch duration
+    assert abs(rf["achieved"] - rf["algorithmic_flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * rf["achieved"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert cb["min_cosine_gpu_vs_cpu_on_sample"] > 0.999
