@@ -23,7 +23,10 @@ import os
 import sys
 import time
 
-import torch
+# the host driver only supports dmabuf IPC: RCCL's intra-node transport needs this before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
