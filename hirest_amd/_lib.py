@@ -12,7 +12,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
 
-EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_POS_F32 = range(6)
+(EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_POS_F32,
+ EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16) = range(9)
 
 ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}
 
@@ -21,7 +22,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
                 ("bias", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
-                ("pos", C.c_void_p), ("patches_per_frame", C.c_int32)]
+                ("pos", C.c_void_p), ("patches_per_frame", C.c_int32), ("aux0", C.c_void_p), ("aux1", C.c_void_p)]
 
 
 class BlockWeights(C.Structure):
@@ -68,6 +69,8 @@ _SIGNATURES = {
                                         C.c_float, C.c_int32, C.c_void_p]),
     "hirest_patchify": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_void_p]),
+    "hirest_rowstats_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_ln_stats_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_write_cls_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_void_p]),
     "hirest_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -134,7 +137,7 @@ def load():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.hirest_abi_version() != 1:
+    if lib.hirest_abi_version() != 2:
         raise RuntimeError("libhirest_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -127,6 +127,59 @@ __global__ __launch_bounds__(256) void layernorm_rows_bulk(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs (HIREST_EPI_LNFOLD_*): the statistics side.
+//   rowstats_bf16_kernel   x f32 [M,D] -> xb = bf16(x) and (mean, rstd) of the ROUNDED row (start of a tower call; inside
+//                          the layer loop the residual GEMMs' epilogues produce both)
+//   ln_finalize_kernel     per-row (sum, sum of squares) of G 32-column groups -> (mean, rstd); 8 lanes per row, the G
+//                          partials are combined in double so the E[x^2] - mean^2 form loses nothing to their order
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void rowstats_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ xb,
+                                                            float* __restrict__ stats, float eps, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int nv = D >> 2;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (int64_t)row * ldx;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * c));
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v[e]; const float f = (float)o[e]; s += f; q = fmaf(f, f, q); }
+                *reinterpret_cast<bf16x4*>(xb + (int64_t)row * D + 4 * c) = o;
+            }
+        }
+        const double S = (double)wave_sum(s), Q = (double)wave_sum(q);
+        const double mean = S / D;
+        double var = Q / D - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (int64_t)row) = f32x2{(float)mean, (float)(1.0 / sqrt(var + (double)eps))};
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int G, float* __restrict__ stats,
+                                                          float eps, int rows, int D) {
+    const int sub = threadIdx.x & 7;
+    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    double S = 0.0, Q = 0.0;
+    if (row < rows) {
+        const f32x2* pr = reinterpret_cast<const f32x2*>(part) + row * G;
+        for (int g = sub; g < G; g += 8) { const f32x2 v = pr[g]; S += (double)v[0]; Q += (double)v[1]; }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { S += __shfl_xor(S, m); Q += __shfl_xor(Q, m); }
+    if (row < rows && sub == 0) {
+        const double mean = S / D;
+        double var = Q / D - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{(float)mean, (float)(1.0 / sqrt(var + (double)eps))};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Patch extraction.  One thread produces 8 consecutive k-columns (16 B of bf16) of one patch row.
 // Column k = c*P*P + ph*P + pw (conv weight flatten order, vit_model.py:198).
 // ---------------------------------------------------------------------------------------------
@@ -265,6 +318,28 @@ extern "C" int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_
     }
     if (out_is_f32) return launch_ln<true>(x, ldx, row_index, gamma, beta, eps, out, ldo, rows, D, s);
     return launch_ln<false>(x, ldx, row_index, gamma, beta, eps, out, ldo, rows, D, s);
+}
+
+extern "C" int hirest_rowstats_bf16(const float* x, int64_t ldx, hirest_bf16* xb, float* stats, float eps, int32_t rows, int32_t D,
+                                    void* stream) {
+    if (!x || !xb || !stats || rows <= 0) return HIREST_E_BADARG;
+    if (D <= 0 || D % 4 != 0 || D > 6 * 256 || ldx % 4 != 0) return HIREST_E_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    bf16_t* o = reinterpret_cast<bf16_t*>(xb);
+    const int nv = (D / 4 + 63) / 64;
+    const int grid = rows / 4 + 1 < 256 * 16 ? rows / 4 + 1 : 256 * 16;
+#define RS_CASE(NVV) case NVV: hipLaunchKernelGGL((rowstats_bf16_kernel<NVV>), dim3(grid), dim3(256), 0, s, x, ldx, o, stats, eps, rows, D); break;
+    switch (nv) { RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) default: return HIREST_E_SHAPE; }
+#undef RS_CASE
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_ln_stats_finalize(const float* partials, int32_t groups, float* stats, float eps, int32_t rows, int32_t D,
+                                        void* stream) {
+    if (!partials || !stats || rows <= 0 || groups <= 0 || D <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partials, groups,
+                       stats, eps, rows, D);
+    return hirest_launch_status();
 }
 
 extern "C" int hirest_patchify(const void* frames, int32_t in_dtype, int32_t B, int32_t S, int32_t P,

@@ -25,6 +25,7 @@ struct GemmP {
     void* out; int64_t ldo;
     int M, N, K;
     const float* pos; int P;
+    void* aux0; void* aux1;   // LN-fold epilogues (see hirest_hip.h): producer = bf16 copy / row partials, consumer = row stats / column sums
     int nbm, nbn, ppx;   // tile counts, M-panels per XCD
     int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
 };
@@ -774,6 +775,9 @@ __global__ __launch_bounds__(512) void gemm_t256q(GemmP p) {
 // stream-K kernel keeps the matrix pipe 72 % busy, t256q 58 %.
 // =================================================================================================
 constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128 B
+constexpr bool epi_is_lnfold(int epi) { return epi == HIREST_EPI_LNFOLD_BF16 || epi == HIREST_EPI_LNFOLD_GELU_BF16; }
+// the LN-fold consumers keep the (mean, rstd) pairs of the wave's 128 rows behind their staging area
+constexpr int p_stg_bytes(int epi) { return epi_is_lnfold(epi) ? P_STG + 1024 : P_STG; }
 
 // Epilogue of p256: accumulators are 16x16 MFMA tiles, acc[mi][ni][e] = C[mi*16 + (lane&15)][ni*16 + 4*(lane>>4) + e]
 // (operands swapped, so a lane owns 4 consecutive columns of one row).  16 rows at a time go through a wave-private
@@ -786,25 +790,44 @@ constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128
 
 template <int EPI, int NI>
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
-    constexpr bool OUT_BF16 = (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_QGELU_BF16);
+    constexpr bool FOLD = epi_is_lnfold(EPI);
+    constexpr bool OUT_BF16 = (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_QGELU_BF16 || FOLD);
     const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;   // sw = srow & 7
     const int rr = lane >> 3, rc = lane & 7;                     // read-back: row (it*8 + rr), 16-B chunk rc
     if constexpr (OUT_BF16) {
         bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+        if constexpr (FOLD) {   // (mean, rstd) of this wave's 128 rows -> LDS behind the staging area (one 16-B load per lane)
+            const float* st = reinterpret_cast<const float*>(p.aux0);
+            const int r0 = Mw + 2 * lane;
+            const f32x2 v0 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 < p.M ? r0 : p.M - 1));
+            const f32x2 v1 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 + 1 < p.M ? r0 + 1 : p.M - 1));
+            *reinterpret_cast<f32x4*>(stg + P_STG + 16 * lane) = f32x4{v0[0], v0[1], v1[0], v1[1]};
+            HX_LDS_ORDER();
+        }
 #pragma unroll
         for (int jp = 0; jp < NI; jp += 4) {                     // 64-column groups
-            f32x4 bv[4];
+            f32x4 bv[4], sv[FOLD ? 4 : 1];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int col = Nw + (jp + n) * 16 + 4 * kg;
                 bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (FOLD)
+                    sv[n] = col < p.N ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux1) + col) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
+                f32x2 mr = {0.f, 1.f};
+                if constexpr (FOLD) mr = *reinterpret_cast<const f32x2*>(stg + P_STG + (mi * 16 + srow) * 8);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    f32x4 v = acc[mi][jp + n] + bv[n];
-                    if constexpr (EPI == HIREST_EPI_BIAS_GELU_BF16) {
+                    f32x4 v;
+                    if constexpr (FOLD) {   // LayerNorm folded into the GEMM: rstd * (x~ W'^T - mean * rowsum(W')) + b'
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaf(-mr[0], sv[n][e], acc[mi][jp + n][e]), mr[1], bv[n][e]);
+                    } else {
+                        v = acc[mi][jp + n] + bv[n];
+                    }
+                    if constexpr (EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_LNFOLD_GELU_BF16) {
                         const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
                         v = f32x4{g0[0], g0[1], g1[0], g1[1]};
                     }
@@ -858,7 +881,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         const int mm = ok ? m : 0;
                         const int pp = mm % p.P;
                         o[it] = ok ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    } else if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32) {
+                    } else if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32 || EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
                         o[it] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(outp + (int64_t)m * p.ldo + n)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -876,6 +899,29 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         f32x4 w = *reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
                         if constexpr (EPI != HIREST_EPI_BIAS_F32) w += o[(mi - mh) * 2 + it];
                         const int m = Mw + mi * 16 + r;
+                        if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
+                            // bf16 copy of the new residual row (the next GEMM's A operand) and the sums of its 32-column
+                            // group over the ROUNDED values (the folded LayerNorm normalises exactly what the GEMM reads)
+                            const bool ok = m < p.M && n < p.N;
+                            bf16x4 wb;
+                            float ps = 0.f, pq = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                wb[e] = (bf16_t)w[e];
+                                const float f = ok ? (float)wb[e] : 0.f;
+                                ps += f; pq = fmaf(f, f, pq);
+                            }
+                            ps += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ps), 0xB1, 0xf, 0xf, true));
+                            pq += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pq), 0xB1, 0xf, 0xf, true));
+                            ps += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ps), 0x4E, 0xf, 0xf, true));
+                            pq += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pq), 0x4E, 0xf, 0xf, true));
+                            ps += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ps), 0x141, 0xf, 0xf, true));
+                            pq += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pq), 0x141, 0xf, 0xf, true));
+                            if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.aux0) + (int64_t)m * p.N + n) = wb;
+                            const int g32 = (Nw + jp * 16) >> 5;
+                            if (rc == 0 && m < p.M && Nw + jp * 16 < p.N)
+                                *reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.aux1) + ((int64_t)m * ((p.N + 31) >> 5) + g32) * 2) = f32x2{ps, pq};
+                        }
                         if (m < p.M && n < p.N) {
                             int64_t off;
                             if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
@@ -1038,7 +1084,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     stage(); advance();
     __builtin_amdgcn_s_barrier();
 
-    char* stg = smem + 2 * Q_STEP + wave * P_STG;
+    char* stg = smem + 2 * Q_STEP + wave * p_stg_bytes(EPI);
     int g = 0;   // global step index of the MFMA side: step g lives in ring slot g & 1
     for (int j = slot, sub = 0; j < nunit;) {
         int M0, N0;
@@ -1263,7 +1309,7 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
     bar();
     if (grp == 1) bar();                              // group 1 runs one barrier behind group 0 from here on
 
-    char* stg = smem + 2 * Q_STEP + wave * P_STG;
+    char* stg = smem + 2 * Q_STEP + wave * p_stg_bytes(EPI);
     int g = 0;                                        // global step index of the MFMA side: step g lives in ring slot g & 1
     for (int j = slot; j < nunit; j += nslot) {
         int M0, N0;
@@ -1341,7 +1387,7 @@ int launch_pp256(GemmP p, hipStream_t s) {
     static bool configured = false;
     static int cus = 0;
     auto kern = gemm_pp256<EPI>;
-    constexpr int LDS = 2 * Q_STEP + 8 * P_STG;
+    constexpr int LDS = 2 * Q_STEP + 8 * p_stg_bytes(EPI);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
@@ -1365,7 +1411,7 @@ int launch_p256_impl(GemmP p, hipStream_t s) {
     static int cus = 0;
     auto kern = gemm_p256<EPI, WN, DBG>;
     constexpr int NW = 512 / WN;
-    constexpr int LDS = 2 * Q_STEP + NW * P_STG;
+    constexpr int LDS = 2 * Q_STEP + NW * p_stg_bytes(EPI);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
@@ -1443,6 +1489,16 @@ int launch256(GemmP p, hipStream_t s) {
     return hirest_launch_status();
 }
 
+// LN-fold epilogues exist in the persistent kernels only
+template <int EPI>
+int launch_fused(const GemmP& p, hipStream_t s) {
+    const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
+    if (!big || !p.aux0 || !p.aux1) return !big ? HIREST_E_SHAPE : HIREST_E_BADARG;
+    GemmP q = p; q.dbg = 0;
+    if (p.K >= 4096) return launch_pp256<EPI>(q, s);
+    return launch_p256_impl<EPI, 64, false>(q, s);
+}
+
 int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
 
 template <int EPI>
@@ -1483,6 +1539,7 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.bias = a->bias; p.out = a->out; p.ldo = a->ldo;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.pos = a->pos; p.P = a->patches_per_frame;
+    p.aux0 = a->aux0; p.aux1 = a->aux1;
     p.dbg = g_gemm_dbg;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
     p.ppx = (p.nbm + 7) / 8;
@@ -1497,6 +1554,9 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
         case HIREST_EPI_PATCH_POS_F32:
             if (!a->pos || a->patches_per_frame <= 0) return HIREST_E_BADARG;
             return launch<HIREST_EPI_PATCH_POS_F32>(p, s);
+        case HIREST_EPI_BIAS_RESID_LNSTATS_F32: return launch_fused<HIREST_EPI_BIAS_RESID_LNSTATS_F32>(p, s);
+        case HIREST_EPI_LNFOLD_BF16: return launch_fused<HIREST_EPI_LNFOLD_BF16>(p, s);
+        case HIREST_EPI_LNFOLD_GELU_BF16: return launch_fused<HIREST_EPI_LNFOLD_GELU_BF16>(p, s);
         default: return HIREST_E_BADARG;
     }
 }

@@ -44,7 +44,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bi
     a.A = reinterpret_cast<const hirest_bf16*>(A); a.lda = lda;
     a.W = reinterpret_cast<const hirest_bf16*>(W); a.ldw = ldw;
     a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
-    a.pos = pos; a.patches_per_frame = P;
+    a.pos = pos; a.patches_per_frame = P; a.aux0 = nullptr; a.aux1 = nullptr;
     return hirest_gemm_bf16(&a, stream);
 }
 

@@ -38,17 +38,22 @@ def _opt(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epilogue: int,
-         pos: Optional[torch.Tensor] = None, patches_per_frame: int = 0) -> torch.Tensor:
-    """out <- epilogue(a @ w.T + bias); a [M,K] bf16, w [N,K] bf16, bias [N] f32."""
+         pos: Optional[torch.Tensor] = None, patches_per_frame: int = 0,
+         aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out <- epilogue(a @ w.T + bias); a [M,K] bf16, w [N,K] bf16, bias [N] f32.  aux0 / aux1: the LN-fold epilogues'
+    extra operands (include/hirest_hip.h)."""
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K:
         raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
-    out_dtype = torch.bfloat16 if epilogue in (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16) else torch.float32
+    out_dtype = torch.bfloat16 if epilogue in (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, _lib.EPI_LNFOLD_BF16,
+                                              _lib.EPI_LNFOLD_GELU_BF16) else torch.float32
     args = _lib.GemmArgs(_dev(a, torch.bfloat16, "gemm.a"), K, _dev(w, torch.bfloat16, "gemm.w"), K,
                          _opt(bias, torch.float32, "gemm.bias"), _dev(out, out_dtype, "gemm.out"), out.shape[-1],
-                         M, N, K, epilogue, _opt(pos, torch.float32, "gemm.pos"), patches_per_frame)
+                         M, N, K, epilogue, _opt(pos, torch.float32, "gemm.pos"), patches_per_frame,
+                         None if aux0 is None else _dev(aux0, aux0.dtype, "gemm.aux0"),
+                         None if aux1 is None else _dev(aux1, aux1.dtype, "gemm.aux1"))
     _lib.check(lib.hirest_gemm_bf16(C.byref(args), stream_ptr()), "hirest_gemm_bf16")
     return out
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HIREST_ABI_VERSION 1
+#define HIREST_ABI_VERSION 2
 
 #define HIREST_E_BADARG   (-1)
 #define HIREST_E_SHAPE    (-2)   /* unsupported shape (see each function) */
@@ -54,8 +54,19 @@ enum hirest_epilogue {
     HIREST_EPI_BIAS_QGELU_BF16 = 2,  /* out bf16          = quick_gelu(acc + bias) (model.py:175) */
     HIREST_EPI_BIAS_RESID_F32 = 3,   /* out f32 (in/out)  = out + acc + bias     (x += f(x)) */
     HIREST_EPI_BIAS_F32 = 4,         /* out f32           = acc + bias                        */
-    HIREST_EPI_PATCH_POS_F32 = 5     /* patch-embed: row m=b*P+p -> out row b*(P+1)+1+p;
+    HIREST_EPI_PATCH_POS_F32 = 5,    /* patch-embed: row m=b*P+p -> out row b*(P+1)+1+p;
                                         out f32 = acc + bias + pos[(1+p)*ldo' ...]; see below */
+    /* LayerNorm folded into the neighbouring GEMMs (large problems only: M*N >= 2^21, M >= 512, N >= 256;
+     * HIREST_E_SHAPE otherwise).  LN(x) W^T + b = rstd * (x W'^T - mean * s) + b' with W' = W * gamma (per input
+     * column), s[n] = sum_k W'[n][k], b' = b + W beta, so the GEMM reads the un-normalised stream and the LayerNorm
+     * pass (vit_model.py:177-178) disappears: */
+    HIREST_EPI_BIAS_RESID_LNSTATS_F32 = 6, /* producer: as BIAS_RESID_F32, plus aux0 = bf16 copy [M,N] of the new rows
+                                        and aux1 = f32 [M, ceil(N/32), 2] per-row (sum, sum of squares) of each 32-column
+                                        group of the bf16-ROUNDED values; hirest_ln_stats_finalize turns them into
+                                        (mean, rstd) rows */
+    HIREST_EPI_LNFOLD_BF16 = 7,      /* consumer: A = that bf16 copy, W = W', bias = b', aux0 = f32 [M,2] (mean, rstd),
+                                        aux1 = s [N];  out bf16 = rstd * (acc - mean * s) + b' */
+    HIREST_EPI_LNFOLD_GELU_BF16 = 8  /* same, then gelu_erf */
 };
 
 typedef struct hirest_gemm_args {
@@ -68,6 +79,9 @@ typedef struct hirest_gemm_args {
     /* HIREST_EPI_PATCH_POS_F32 only: */
     const float* pos;                     /* [(P+1), N] position embedding (row 0 = cls slot) */
     int32_t patches_per_frame;            /* P (256 for 224^2 / 14) */
+    /* LN-fold epilogues only (see enum): */
+    void* aux0;
+    void* aux1;
 } hirest_gemm_args;
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
@@ -129,6 +143,13 @@ int hirest_patchify(const void* frames, int32_t in_dtype, int32_t B, int32_t S, 
 /* x[b*(P+1)] = cls + pos[0]  for every frame (vit_model.py:330-333, the CLS row). */
 int hirest_write_cls_rows(float* x, int64_t ldx, const float* cls, const float* pos0,
                           int32_t B, int32_t tokens_per_frame, int32_t D, void* stream);
+
+/* Statistics side of the folded LayerNorm (HIREST_EPI_LNFOLD_*; vit_model.py:177-178):
+ *   hirest_rowstats_bf16       x f32 [rows, D] -> xb bf16 [rows, D] (the GEMM's A operand) and stats f32 [rows, 2] =
+ *                              (mean, 1/sqrt(var + eps)) of the ROUNDED row, biased variance.  D % 4 == 0, D <= 1536.
+ *   hirest_ln_stats_finalize   partials f32 [rows, groups, 2] written by HIREST_EPI_BIAS_RESID_LNSTATS_F32 -> stats. */
+int hirest_rowstats_bf16(const float* x, int64_t ldx, hirest_bf16* xb, float* stats, float eps, int32_t rows, int32_t D, void* stream);
+int hirest_ln_stats_finalize(const float* partials, int32_t groups, float* stats, float eps, int32_t rows, int32_t D, void* stream);
 
 /* Text prologue: x[b,t,:] = tok_emb[tok[b,t]] + pos[t]  (eva_model.py:233-235); also writes
  * eot_row[b] = b*L + argmax_t tok[b,t] (first maximum) for the EOT gather (eva_model.py:243). */

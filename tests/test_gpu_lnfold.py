@@ -1,0 +1,112 @@
+"""LayerNorm folded into the neighbouring GEMMs (HIREST_EPI_BIAS_RESID_LNSTATS_F32 -> hirest_ln_stats_finalize ->
+HIREST_EPI_LNFOLD_*): each piece against its definition, and the chain against LayerNorm + plain GEMM
+(vit_model.py:177-178: x = x + proj(...); h = norm2(x); fc1(h))."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _finalize(part, rows, D, eps, dev):
+    from hirest_amd import _lib, ops
+    stats = torch.empty((rows, 2), device=dev)
+    _lib.check(_lib.load().hirest_ln_stats_finalize(part.data_ptr(), part.shape[1], stats.data_ptr(), eps, rows, D, ops.stream_ptr()),
+               "hirest_ln_stats_finalize")
+    return stats
+
+
+@pytest.mark.parametrize("M,N,K", [(2570, 1408, 1408), (2056, 1408, 6144), (1999, 1056, 704)])
+def test_producer_writes_residual_copy_and_row_sums(dev, M, N, K):
+    from hirest_amd import _lib, ops
+    g = torch.Generator(device=dev); g.manual_seed(M + N)
+    A = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
+    W = (torch.randn((N, K), device=dev, generator=g) * 0.03).to(torch.bfloat16)
+    bias = torch.randn((N,), device=dev, generator=g)
+    x0 = torch.randn((M, N), device=dev, generator=g) * 3 + 0.7
+    ref = x0.clone()
+    ops.gemm(A, W, bias, ref, _lib.EPI_BIAS_RESID_F32)
+    out = x0.clone()
+    xb = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16)
+    G = (N + 31) // 32
+    part = torch.full((M, G, 2), float("nan"), device=dev)
+    ops.gemm(A, W, bias, out, _lib.EPI_BIAS_RESID_LNSTATS_F32, aux0=xb, aux1=part)
+    assert torch.equal(out, ref)                                   # the residual stream itself is untouched by the extras
+    assert torch.equal(xb, ref.to(torch.bfloat16))
+    f = xb.float()
+    pad = torch.zeros((M, G * 32), device=dev); pad[:, :N] = f
+    want = torch.stack([pad.reshape(M, G, 32).sum(-1), (pad * pad).reshape(M, G, 32).sum(-1)], dim=-1)
+    assert torch.isfinite(part).all()
+    assert (part - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    stats = _finalize(part, M, N, 1e-6, dev)
+    mean = f.double().mean(1)
+    rstd = 1.0 / torch.sqrt(f.double().var(1, unbiased=False) + 1e-6)
+    assert (stats[:, 0].double() - mean).abs().max().item() < 1e-5
+    assert ((stats[:, 1].double() - rstd) / rstd).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("M,N,K", [(2570, 4224, 1408), (2056, 6144, 1408), (1999, 2100, 704), (520, 4608, 4096)])
+def test_consumer_equals_layernorm_then_gemm(dev, M, N, K, gelu):
+    from hirest_amd import _lib, ops
+    g = torch.Generator(device=dev); g.manual_seed(M * 3 + N)
+    x = torch.randn((M, K), device=dev, generator=g) * 2.5 + 0.4
+    x[:, 5] *= 30.0                                                 # an outlier channel, as real ViT streams have
+    gamma = 1.0 + 0.2 * torch.randn((K,), device=dev, generator=g)
+    beta = 0.1 * torch.randn((K,), device=dev, generator=g)
+    W = torch.randn((N, K), device=dev, generator=g) * 0.03
+    b = torch.randn((N,), device=dev, generator=g)
+    eps = 1e-6
+    # statistics + bf16 copy (the tower's first step)
+    xb = torch.empty((M, K), device=dev, dtype=torch.bfloat16)
+    stats = torch.empty((M, 2), device=dev)
+    if K <= 1536:
+        _lib.check(_lib.load().hirest_rowstats_bf16(x.data_ptr(), K, xb.data_ptr(), stats.data_ptr(), eps, M, K, ops.stream_ptr()), "rowstats")
+    else:                                                           # wider than any LayerNorm on the path: statistics from torch
+        xb.copy_(x.to(torch.bfloat16))
+        fd = xb.double()
+        stats.copy_(torch.stack([fd.mean(1), 1.0 / torch.sqrt(fd.var(1, unbiased=False) + eps)], 1).float())
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    f = xb.double()
+    assert (stats[:, 0].double() - f.mean(1)).abs().max().item() < 1e-5
+    assert ((stats[:, 1].double() * torch.sqrt(f.var(1, unbiased=False) + eps)) - 1).abs().max().item() < 1e-4
+    # folded weights (what hirest_amd/eva_clip.py prepares once per checkpoint)
+    Wf = (W * gamma[None, :]).to(torch.bfloat16)
+    s = Wf.float().sum(1).contiguous()
+    bf = (b + W @ beta).contiguous()
+    out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    ops.gemm(xb, Wf, bf, out, _lib.EPI_LNFOLD_GELU_BF16 if gelu else _lib.EPI_LNFOLD_BF16, aux0=stats, aux1=s)
+    # definition in double on the same rounded operands: LN(x~) @ (W gamma)^T + b + W beta
+    ln = (f - f.mean(1, keepdim=True)) / torch.sqrt(f.var(1, unbiased=False, keepdim=True) + eps)
+    want = ln @ Wf.double().t() + bf.double()
+    if gelu:
+        want = torch.nn.functional.gelu(want)
+    err = (out.double() - want).abs()
+    tol = 2.0 ** -8 * want.abs() + 2e-2            # one bf16 ulp of the result + the fp32 accumulation of a K-long sum with an outlier channel
+    assert bool((err <= tol).all()), f"max excess {(err - tol).max().item():.3e}"
+    # and against the unfused path (LayerNorm kernel -> bf16 -> GEMM): same thing within the bf16 rounding of h
+    h = torch.empty((M, K), device=dev, dtype=torch.bfloat16)
+    ops.layernorm(x, gamma, beta, eps, h)
+    plain = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    ops.gemm(h, W.to(torch.bfloat16), b, plain, _lib.EPI_BIAS_GELU_BF16 if gelu else _lib.EPI_BIAS_BF16)
+    cos = torch.nn.functional.cosine_similarity(out.float(), plain.float(), dim=1).min().item()
+    assert cos > 0.9995, cos
+
+
+def test_fold_epilogues_reject_small_problems(dev):
+    from hirest_amd import _lib, ops
+    A = torch.zeros((64, 64), device=dev, dtype=torch.bfloat16)
+    W = torch.zeros((256, 64), device=dev, dtype=torch.bfloat16)
+    out = torch.zeros((64, 256), device=dev, dtype=torch.bfloat16)
+    st = torch.zeros((64, 2), device=dev)
+    s = torch.zeros((256,), device=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, W, None, out, _lib.EPI_LNFOLD_BF16, aux0=st, aux1=s)
