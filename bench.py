@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the batch timed on the CPU oracle (~10-15 s)")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 force t128, 2 force t256 (A/B timing)")
+    ap.add_argument("--no-ln-fold", action="store_true", help="A/B: run the LayerNorm passes instead of folding them into the GEMMs")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="hirest_gemm_debug_mode bits: TIMING EXPERIMENTS ONLY, the line is not a valid result")
     args = ap.parse_args()
 
@@ -74,6 +75,8 @@ def main():
     model = hirest_amd.EVA_CLIP(**cfg).to(dev).eval()
     model.init_random_(seed=1234)
     model.visual.max_frames_per_call = args.chunk
+    if args.no_ln_fold:
+        model.visual.fold_layernorm = False
 
     V_local = args.frames // FRAMES_PER_VIDEO
     gen = torch.Generator(device=dev)
@@ -155,7 +158,8 @@ def main():
             except (OSError, ValueError, KeyError):
                 traffic = None
         if dom:
-            epi = {0: "bias", 1: "bias+gelu", 2: "bias+quickgelu", 3: "bias+residual", 4: "bias->f32", 5: "patch+pos"}
+            epi = {0: "bias", 1: "bias+gelu", 2: "bias+quickgelu", 3: "bias+residual", 4: "bias->f32", 5: "patch+pos",
+                   6: "bias+residual+ln-stats", 7: "ln-fold+bias", 8: "ln-fold+bias+gelu"}
             roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_note": "bytes per launch through the L2's memory side (Infinity-Cache hits included), from "

@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
 
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-                                          "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                                          "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                          "qkv_wf", "qkv_bf", "qkv_s", "fc1_wf", "fc1_bf", "fc1_s")]
 
 
 class VisionTower(C.Structure):

@@ -788,8 +788,113 @@ constexpr int p_stg_bytes(int epi) { return epi_is_lnfold(epi) ? P_STG + 1024 : 
 // would drain lgkmcnt twice per 16-row pass.
 #define HX_LDS_ORDER() asm volatile("" ::: "memory")
 
-template <int EPI, int NI>
+// Epilogue of HIREST_EPI_BIAS_RESID_LNSTATS_F32 (64-column wave tiles): x += acc + bias as in the plain residual form, plus
+//   * the bf16 copy of the new rows (next GEMM's A operand): both 32-column halves of a pass are regrouped with one DPP
+//     exchange per value so that every lane stores 16 B and a row's 64 columns leave as one full 128-B line;
+//   * (sum, sum of squares) of the ROUNDED values per row and 64-column group -> aux1 [M, ceil(N/64), 2]
+//     (hirest_ln_stats_finalize folds the groups into (mean, rstd)).
+// The residual operands of pass mi + 1 are requested before pass mi is processed.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float v) {   // over the 8 lanes lane & ~7 .. | 7: quad xor 1, xor 2, then the mirrored quad
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8][4], char* stg, int Mw, int Nw, int lane) {
+    const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;
+    const int rr = lane >> 3, rc = lane & 7;
+    float* outp = reinterpret_cast<float*>(p.out);
+    bf16_t* xb = reinterpret_cast<bf16_t*>(p.aux0);
+    float* part = reinterpret_cast<float*>(p.aux1);
+    const int G = (p.N + 63) >> 6;
+    f32x4 bv[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int col = Nw + n * 16 + 4 * kg;
+        bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int n0 = Nw + rc * 4, n1 = Nw + 32 + rc * 4;               // this lane's columns in the two 32-column halves
+    auto load_res = [&](int mi, f32x4 (&o)[2][2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = Mw + mi * 16 + it * 8 + rr;
+            const float* row = outp + (int64_t)(m < p.M ? m : p.M - 1) * p.ldo;
+            o[0][it] = n0 < p.N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            o[1][it] = n1 < p.N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 oc[2][2], on[2][2];
+    load_res(0, oc);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        if (mi + 1 < 8) load_res(mi + 1, on);
+        f32x4 wv[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+                *reinterpret_cast<f32x4*>(stg + srow * 128 + (((nn * 4 + kg) ^ sw) << 4)) = acc[mi][h * 2 + nn] + bv[h * 2 + nn];
+            HX_LDS_ORDER();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 8 + rr;
+                wv[h][it] = *reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4)) + oc[h][it];
+            }
+            HX_LDS_ORDER();
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = Mw + mi * 16 + it * 8 + rr;
+            const bool okm = m < p.M, ok0 = okm && n0 < p.N, ok1 = okm && n1 < p.N;
+            if (ok0) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
+            if (ok1) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
+            union { bf16x4 v; float f[2]; } b0, b1, snd, rcv;
+            float ps = 0.f, pq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                b0.v[e] = (bf16_t)wv[0][it][e]; b1.v[e] = (bf16_t)wv[1][it][e];
+                const float f0 = ok0 ? (float)b0.v[e] : 0.f, f1 = ok1 ? (float)b1.v[e] : 0.f;
+                ps += f0 + f1; pq = fmaf(f0, f0, fmaf(f1, f1, pq));
+            }
+            snd.v = (rc & 1) ? b0.v : b1.v;                          // odd lanes hand over their left half, even lanes their right half
+            rcv.f[0] = dpp_xor1(snd.f[0]); rcv.f[1] = dpp_xor1(snd.f[1]);
+            union { bf16x8 v; float f[4]; } w8;
+            int col;
+            if (rc & 1) { w8.f[0] = rcv.f[0]; w8.f[1] = rcv.f[1]; w8.f[2] = b1.f[0]; w8.f[3] = b1.f[1]; col = n1 - 4; }
+            else        { w8.f[0] = b0.f[0]; w8.f[1] = b0.f[1]; w8.f[2] = rcv.f[0]; w8.f[3] = rcv.f[1]; col = n0; }
+            if (okm && col + 8 <= p.N) *reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col) = w8.v;
+            ps = sum8(ps); pq = sum8(pq);
+            if (rc == 0 && okm && Nw < p.N) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
+        }
+        if (mi + 1 < 8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) oc[h][it] = on[h][it];
+        }
+    }
+}
+
+// (mean, rstd) of rows Mw + 2*lane and Mw + 2*lane + 1 for the LN-fold consumers (gemm_p256 brings them in by LDS-DMA at
+// the start of a tile instead, so the latency hides behind the K loop)
+__device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane) {
+    const float* st = reinterpret_cast<const float*>(p.aux0);
+    const int r0 = Mw + 2 * lane;
+    const f32x2 v0 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 < p.M ? r0 : p.M - 1));
+    const f32x2 v1 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 + 1 < p.M ? r0 + 1 : p.M - 1));
+    return f32x4{v0[0], v0[1], v1[0], v1[1]};
+}
+
+template <int EPI, int NI, bool PRE = false>   // PRE: the caller has already brought the row statistics into LDS
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
+    if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
+        static_assert(NI == 4, "the statistics producer is written for 64-column wave tiles");
+        epilogue_lnstats(p, acc, stg, Mw, Nw, lane);
+        return;
+    }
     constexpr bool FOLD = epi_is_lnfold(EPI);
     constexpr bool OUT_BF16 = (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_QGELU_BF16 || FOLD);
     const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;   // sw = srow & 7
@@ -797,11 +902,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
     if constexpr (OUT_BF16) {
         bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
         if constexpr (FOLD) {   // (mean, rstd) of this wave's 128 rows -> LDS behind the staging area (one 16-B load per lane)
-            const float* st = reinterpret_cast<const float*>(p.aux0);
-            const int r0 = Mw + 2 * lane;
-            const f32x2 v0 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 < p.M ? r0 : p.M - 1));
-            const f32x2 v1 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 + 1 < p.M ? r0 + 1 : p.M - 1));
-            *reinterpret_cast<f32x4*>(stg + P_STG + 16 * lane) = f32x4{v0[0], v0[1], v1[0], v1[1]};
+            if constexpr (!PRE) *reinterpret_cast<f32x4*>(stg + P_STG + 16 * lane) = load_row_stats(p, Mw, lane);
             HX_LDS_ORDER();
         }
 #pragma unroll
@@ -881,7 +982,7 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         const int mm = ok ? m : 0;
                         const int pp = mm % p.P;
                         o[it] = ok ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    } else if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32 || EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
+                    } else if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32) {
                         o[it] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(outp + (int64_t)m * p.ldo + n)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -899,29 +1000,6 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         f32x4 w = *reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
                         if constexpr (EPI != HIREST_EPI_BIAS_F32) w += o[(mi - mh) * 2 + it];
                         const int m = Mw + mi * 16 + r;
-                        if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
-                            // bf16 copy of the new residual row (the next GEMM's A operand) and the sums of its 32-column
-                            // group over the ROUNDED values (the folded LayerNorm normalises exactly what the GEMM reads)
-                            const bool ok = m < p.M && n < p.N;
-                            bf16x4 wb;
-                            float ps = 0.f, pq = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                wb[e] = (bf16_t)w[e];
-                                const float f = ok ? (float)wb[e] : 0.f;
-                                ps += f; pq = fmaf(f, f, pq);
-                            }
-                            ps += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ps), 0xB1, 0xf, 0xf, true));
-                            pq += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pq), 0xB1, 0xf, 0xf, true));
-                            ps += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ps), 0x4E, 0xf, 0xf, true));
-                            pq += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pq), 0x4E, 0xf, 0xf, true));
-                            ps += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ps), 0x141, 0xf, 0xf, true));
-                            pq += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pq), 0x141, 0xf, 0xf, true));
-                            if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.aux0) + (int64_t)m * p.N + n) = wb;
-                            const int g32 = (Nw + jp * 16) >> 5;
-                            if (rc == 0 && m < p.M && Nw + jp * 16 < p.N)
-                                *reinterpret_cast<f32x2*>(reinterpret_cast<float*>(p.aux1) + ((int64_t)m * ((p.N + 31) >> 5) + g32) * 2) = f32x2{ps, pq};
-                        }
                         if (m < p.M && n < p.N) {
                             int64_t off;
                             if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
@@ -1092,6 +1170,12 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
         if (sub + 1 < cnt) ++sub; else { j += nslot; sub = 0; }           // cursor now points at the next tile
         const bool active = (N0 + wc * WN < p.N) && (M0 + wr * 128 < p.M);
         if (active) {
+            if constexpr (epi_is_lnfold(EPI)) {   // (mean, rstd) of this wave's 128 rows: global -> LDS by DMA, lands under the K loop
+                int r0 = M0 + wr * 128 + 2 * lane;
+                const int last = (p.M - 1) & ~1;   // the stats buffer is padded to an even number of rows
+                r0 = r0 < last ? r0 : last;
+                glds16(reinterpret_cast<const float*>(p.aux0) + 2 * (int64_t)r0, stg + P_STG);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1131,7 +1215,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 advance();
             }
-            epilogue_p<EPI, NI>(p, acc, stg, M0 + wr * 128, N0 + wc * WN, lane);
+            epilogue_p<EPI, NI, epi_is_lnfold(EPI)>(p, acc, stg, M0 + wr * 128, N0 + wc * WN, lane);
         } else {
             for (int t = 0; t < nst; ++t, ++g) {
                 HX_WAIT_VM(0);
@@ -1494,6 +1578,7 @@ template <int EPI>
 int launch_fused(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
     if (!big || !p.aux0 || !p.aux1) return !big ? HIREST_E_SHAPE : HIREST_E_BADARG;
+    if (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
     GemmP q = p; q.dbg = 0;
     if (p.K >= 4096) return launch_pp256<EPI>(q, s);
     return launch_p256_impl<EPI, 64, false>(q, s);

@@ -15,18 +15,35 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Regions {
-    size_t x, h, big, eot, total;
+    size_t x, h, big, eot, xb, part, stats, total;
 };
 
-Regions plan(int64_t M, int D, int wide, int B) {
+// lnfold: also the folded-LayerNorm buffers (vision): xb bf16 [M,D] = rounded copy of the residual stream (A operand of
+// qkv / fc1), part f32 [M, ceil(D/64), 2] row sums per 64-column group, stats f32 [M,2] (mean, rstd)
+Regions plan(int64_t M, int D, int wide, int B, bool lnfold = false) {
     Regions r;
     size_t off = 0;
     r.x = off; off += align256((size_t)M * D * 4);
     r.h = off; off += align256((size_t)M * D * 2);
     r.big = off; off += align256((size_t)M * wide * 2);
     r.eot = off; off += align256((size_t)B * 4);
+    r.xb = r.part = r.stats = off;
+    if (lnfold) {
+        r.xb = off; off += align256((size_t)M * D * 2);
+        r.part = off; off += align256((size_t)M * ((D + 63) / 64) * 8);
+        r.stats = off; off += align256((size_t)M * 8);
+    }
     r.total = off;
     return r;
+}
+
+// The folded path needs the persistent GEMM kernels (large problems) and the row-statistics kernel's width limit; below
+// 64 frames the attention also switches kernels, so 64 is the one boundary where results may differ within rounding.
+inline bool vision_lnfold(const hirest_vision_tower* t, int B) {
+    if (!t->blocks || !t->blocks[0].qkv_wf || t->act != 0 || t->ln_pre_g || B < 64) return false;
+    const int T = (t->image_size / t->patch) * (t->image_size / t->patch) + 1;
+    const int64_t M = (int64_t)B * T;
+    return t->width >= 256 && t->width <= 1536 && t->width % 8 == 0 && M * t->width >= (int64_t)2048 * 1024;
 }
 
 inline int vision_wide(const hirest_vision_tower* t) {
@@ -39,12 +56,12 @@ inline int vision_wide(const hirest_vision_tower* t) {
 #define CHECK(expr) do { int _e = (expr); if (_e != 0) return _e; } while (0)
 
 int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int M, int N,
-         int K, int epi, void* stream, const float* pos = nullptr, int P = 0) {
+         int K, int epi, void* stream, const float* pos = nullptr, int P = 0, void* aux0 = nullptr, void* aux1 = nullptr) {
     hirest_gemm_args a;
     a.A = reinterpret_cast<const hirest_bf16*>(A); a.lda = lda;
     a.W = reinterpret_cast<const hirest_bf16*>(W); a.ldw = ldw;
     a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
-    a.pos = pos; a.patches_per_frame = P; a.aux0 = nullptr; a.aux1 = nullptr;
+    a.pos = pos; a.patches_per_frame = P; a.aux0 = aux0; a.aux1 = aux1;
     return hirest_gemm_bf16(&a, stream);
 }
 
@@ -63,6 +80,23 @@ int run_block(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf
     return 0;
 }
 
+// the same block with both LayerNorms folded into the GEMMs around them (include/hirest_hip.h, HIREST_EPI_LNFOLD_*):
+// on entry xb / stats describe x; proj and fc2 refresh them in their epilogues
+int run_block_lnfold(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf16* big, hirest_bf16* xb, float* part,
+                     float* stats, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream) {
+    const int M = B * T, G = (D + 63) / 64;
+    CHECK(gemm(xb, D, w.qkv_wf, D, w.qkv_bf, big, 3 * D, M, 3 * D, D, HIREST_EPI_LNFOLD_BF16, stream, nullptr, 0, stats,
+               const_cast<float*>(w.qkv_s)));
+    CHECK(hirest_attention_bf16(big, h, B, T, heads, dh, 1.0f / sqrtf((float)dh), 0, stream));
+    CHECK(gemm(h, D, w.proj_w, D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
+    CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, stream));
+    CHECK(gemm(xb, D, w.fc1_wf, D, w.fc1_bf, big, Dm, M, Dm, D, HIREST_EPI_LNFOLD_GELU_BF16, stream, nullptr, 0, stats,
+               const_cast<float*>(w.fc1_s)));
+    CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
+    CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, stream));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int hirest_abi_version(void) { return HIREST_ABI_VERSION; }
@@ -74,7 +108,7 @@ extern "C" const char* hirest_build_info(void) {
 extern "C" size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B) {
     if (!t || B <= 0) return 0;
     const int T = (t->image_size / t->patch) * (t->image_size / t->patch) + 1;
-    return plan((int64_t)B * T, t->width, vision_wide(t), B).total;
+    return plan((int64_t)B * T, t->width, vision_wide(t), B, vision_lnfold(t, B)).total;
 }
 
 extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* frames, int32_t in_dtype, int32_t B,
@@ -82,7 +116,8 @@ extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* f
     if (!t || !frames || !out || !workspace || B <= 0 || !t->blocks) return HIREST_E_BADARG;
     if (t->width != t->heads * t->head_dim || t->image_size % t->patch != 0) return HIREST_E_SHAPE;
     const int G = t->image_size / t->patch, P = G * G, T = P + 1, D = t->width;
-    const Regions r = plan((int64_t)B * T, D, vision_wide(t), B);
+    const bool lnfold = vision_lnfold(t, B);
+    const Regions r = plan((int64_t)B * T, D, vision_wide(t), B, lnfold);
     if (workspace_bytes < r.total) return HIREST_E_WORKSPACE;
     char* ws = reinterpret_cast<char*>(workspace);
     float* x = reinterpret_cast<float*>(ws + r.x);
@@ -96,8 +131,18 @@ extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* f
     CHECK(hirest_write_cls_rows(x, D, t->cls, t->pos, B, T, D, stream));
     if (t->ln_pre_g)   // model.py:261 ln_pre, in place on the fp32 stream (row-local, so in place is safe)
         CHECK(hirest_layernorm(x, D, nullptr, t->ln_pre_g, t->ln_pre_b, t->ln_eps, x, D, 1, B * T, D, stream));
-    for (int l = 0; l < t->layers; ++l)
-        CHECK(run_block(t->blocks[l], x, h, big, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps, t->act, 0, stream));
+    if (lnfold) {
+        hirest_bf16* xb = reinterpret_cast<hirest_bf16*>(ws + r.xb);
+        float* part = reinterpret_cast<float*>(ws + r.part);
+        float* stats = reinterpret_cast<float*>(ws + r.stats);
+        CHECK(hirest_rowstats_bf16(x, D, xb, stats, t->ln_eps, B * T, D, stream));
+        for (int l = 0; l < t->layers; ++l)
+            CHECK(run_block_lnfold(t->blocks[l], x, h, big, xb, part, stats, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps,
+                                   stream));
+    } else {
+        for (int l = 0; l < t->layers; ++l)
+            CHECK(run_block(t->blocks[l], x, h, big, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps, t->act, 0, stream));
+    }
     if (t->out_all_tokens) {   // ln_post + proj on every token row; out is [B*T, embed_dim]
         CHECK(hirest_layernorm(x, D, nullptr, t->norm_g, t->norm_b, t->ln_eps, h, D, 0, B * T, D, stream));
         CHECK(gemm(h, D, t->head_w, D, t->head_b, out, t->embed_dim, B * T, t->embed_dim, D, HIREST_EPI_BIAS_F32, stream));

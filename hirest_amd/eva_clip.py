@@ -138,6 +138,7 @@ class VisionTower(_Tower):
         self.head = _linear(embed_dim, D)
         self.image_mean, self.image_std = OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
         self.max_frames_per_call = 1024  # micro-batch per tower call (workspace ~5.4 GB at 1024 frames)
+        self.fold_layernorm = True       # tower calls of >= 64 frames fold both LayerNorms of a block into its GEMMs
 
     def _prepare(self, device):
         if self._prepared is not None and self._prepared["device"] == device:
@@ -155,15 +156,25 @@ class VisionTower(_Tower):
         pw = torch.zeros((D, kpad), dtype=torch.float32, device=device)
         pw[:, :K] = self.patch_embed.proj.weight.detach().float().reshape(D, K)
         blocks = (_lib.BlockWeights * self.layers)()
+
+        def fold(weight, bias, norm):
+            """LayerNorm folded into the Linear that follows it (include/hirest_hip.h, HIREST_EPI_LNFOLD_*):
+            LN(x) W^T + b = rstd (x W'^T - mean s) + b',  W' = W gamma (bf16), s = row sums of the bf16 W', b' = b + W beta."""
+            w32 = weight.detach().float()
+            wf = ops.to_bf16((w32 * norm.weight.detach().float()[None, :]).contiguous())
+            return hold(wf), hold((bias + w32 @ norm.bias.detach().float()).contiguous()), hold(wf.float().sum(1).contiguous())
         for i, b in enumerate(self.blocks):
             qkv_b = torch.cat([b.attn.q_bias.detach().float(), torch.zeros(D, device=device), b.attn.v_bias.detach().float()])
+            folded = (None,) * 6
+            if self.fold_layernorm and not self.quick_gelu:
+                folded = fold(b.attn.qkv.weight, qkv_b, b.norm1) + fold(b.mlp.fc1.weight, b.mlp.fc1.bias.detach().float(), b.norm2)
             blocks[i] = _lib.BlockWeights(
                 hold(self._f32(b.norm1.weight)), hold(self._f32(b.norm1.bias)),
                 hold(self._bf16(b.attn.qkv.weight)), hold(qkv_b.contiguous()),
                 hold(self._bf16(b.attn.proj.weight)), hold(self._f32(b.attn.proj.bias)),
                 hold(self._f32(b.norm2.weight)), hold(self._f32(b.norm2.bias)),
                 hold(self._bf16(b.mlp.fc1.weight)), hold(self._f32(b.mlp.fc1.bias)),
-                hold(self._bf16(b.mlp.fc2.weight)), hold(self._f32(b.mlp.fc2.bias)))
+                hold(self._bf16(b.mlp.fc2.weight)), hold(self._f32(b.mlp.fc2.bias)), *folded)
         mean = torch.tensor(self.image_mean, dtype=torch.float32, device=device)
         std = torch.tensor(self.image_std, dtype=torch.float32, device=device)
         desc = _lib.VisionTower(

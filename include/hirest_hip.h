@@ -61,10 +61,11 @@ enum hirest_epilogue {
      * column), s[n] = sum_k W'[n][k], b' = b + W beta, so the GEMM reads the un-normalised stream and the LayerNorm
      * pass (vit_model.py:177-178) disappears: */
     HIREST_EPI_BIAS_RESID_LNSTATS_F32 = 6, /* producer: as BIAS_RESID_F32, plus aux0 = bf16 copy [M,N] of the new rows
-                                        and aux1 = f32 [M, ceil(N/32), 2] per-row (sum, sum of squares) of each 32-column
-                                        group of the bf16-ROUNDED values; hirest_ln_stats_finalize turns them into
+                                        and aux1 = f32 [M, ceil(N/64), 2] per-row (sum, sum of squares) of each 64-column
+                                        group of the bf16-ROUNDED values (N % 8 == 0); hirest_ln_stats_finalize turns them into
                                         (mean, rstd) rows */
-    HIREST_EPI_LNFOLD_BF16 = 7,      /* consumer: A = that bf16 copy, W = W', bias = b', aux0 = f32 [M,2] (mean, rstd),
+    HIREST_EPI_LNFOLD_BF16 = 7,      /* consumer: A = that bf16 copy, W = W', bias = b', aux0 = f32 [M,2] (mean, rstd; the buffer
+                                        must be readable up to an EVEN number of rows, i.e. M + 1 rows when M is odd),
                                         aux1 = s [N];  out bf16 = rstd * (acc - mean * s) + b' */
     HIREST_EPI_LNFOLD_GELU_BF16 = 8  /* same, then gelu_erf */
 };
@@ -192,6 +193,11 @@ typedef struct hirest_block_weights {      /* pre-LN transformer block */
     const float* ln2_g; const float* ln2_b;
     const hirest_bf16* fc1_w; const float* fc1_b;     /* [Dm,D] */
     const hirest_bf16* fc2_w; const float* fc2_b;     /* [D,Dm] */
+    /* Optional (all six or none; vision tower, gelu_erf only): LayerNorm-folded operands of the two GEMMs that follow a
+     * LayerNorm — W' = W * gamma (bf16), b' = b + W beta, s = row sums of the bf16 W' (see HIREST_EPI_LNFOLD_*).  When
+     * present, tower calls of >= 64 frames skip the LayerNorm passes of the block. */
+    const hirest_bf16* qkv_wf; const float* qkv_bf; const float* qkv_s;
+    const hirest_bf16* fc1_wf; const float* fc1_bf; const float* fc1_s;
 } hirest_block_weights;
 
 typedef struct hirest_vision_tower {       /* EVA ViT (vit_model.py:248-351) */

@@ -13,7 +13,10 @@ from hirest_amd import _lib, ops  # noqa: E402
 SHAPES = {"qkv": (4224, 1408, _lib.EPI_BIAS_BF16), "proj": (1408, 1408, _lib.EPI_BIAS_RESID_F32),
           "fc1": (6144, 1408, _lib.EPI_BIAS_GELU_BF16), "fc2": (1408, 6144, _lib.EPI_BIAS_RESID_F32),
           "fc1_nogelu": (6144, 1408, _lib.EPI_BIAS_BF16), "fc2_plain": (1408, 6144, _lib.EPI_BIAS_BF16),
-          "proj_plain": (1408, 1408, _lib.EPI_BIAS_BF16), "fc2_f32": (1408, 6144, _lib.EPI_BIAS_F32)}
+          "proj_plain": (1408, 1408, _lib.EPI_BIAS_BF16), "fc2_f32": (1408, 6144, _lib.EPI_BIAS_F32),
+          # LayerNorm-fold epilogues (same operands, so the difference to qkv / fc1 / proj / fc2 is the epilogue's cost)
+          "qkv_fold": (4224, 1408, _lib.EPI_LNFOLD_BF16), "fc1_fold": (6144, 1408, _lib.EPI_LNFOLD_GELU_BF16),
+          "proj_stats": (1408, 1408, _lib.EPI_BIAS_RESID_LNSTATS_F32), "fc2_stats": (1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32)}
 
 
 def main():
@@ -43,13 +46,21 @@ def main():
         A = torch.randn((M, K + a.lda_pad), device=dev, generator=g).to(torch.bfloat16)
         W = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.bfloat16)
         bias = torch.randn((N,), device=dev, generator=g)
-        out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32) else torch.bfloat16)
+        out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32, _lib.EPI_BIAS_RESID_LNSTATS_F32) else torch.bfloat16)
+        aux0 = aux1 = None
+        if epi in (_lib.EPI_LNFOLD_BF16, _lib.EPI_LNFOLD_GELU_BF16):
+            aux0 = torch.cat([torch.randn((M + 1, 1), device=dev, generator=g) * 0.1, torch.rand((M + 1, 1), device=dev, generator=g) + 0.5], 1)[:M].contiguous()
+            aux0 = torch.cat([aux0, aux0[:1]])[:M]
+            aux1 = torch.randn((N,), device=dev, generator=g)
+        elif epi == _lib.EPI_BIAS_RESID_LNSTATS_F32:
+            aux0 = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+            aux1 = torch.empty((M, (N + 63) // 64, 2), device=dev)
         import ctypes as C
         lib = _lib.load()
 
         def run():
             if not a.alias and not a.lda_pad:
-                return ops.gemm(A, W, bias, out, epi)
+                return ops.gemm(A, W, bias, out, epi, aux0=aux0, aux1=aux1)
             lda = 0 if a.alias else K + a.lda_pad
             args = _lib.GemmArgs(A.data_ptr(), lda, W.data_ptr(), 0 if a.alias else K, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
             _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "gemm")
