@@ -865,7 +865,7 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
             int col;
             if (rc & 1) { w8.f[0] = rcv.f[0]; w8.f[1] = rcv.f[1]; w8.f[2] = b1.f[0]; w8.f[3] = b1.f[1]; col = n1 - 4; }
             else        { w8.f[0] = b0.f[0]; w8.f[1] = b0.f[1]; w8.f[2] = rcv.f[0]; w8.f[3] = rcv.f[1]; col = n0; }
-            if (okm && col + 8 <= p.N) *reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col) = w8.v;
+            if (okm && col + 8 <= p.N) __builtin_nontemporal_store(w8.v, reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col));
             ps = sum8(ps); pq = sum8(pq);
             if (rc == 0 && okm && Nw < p.N) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
         }
@@ -915,16 +915,18 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                 if constexpr (FOLD)
                     sv[n] = col < p.N ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux1) + col) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            f32x2 mr_next = {0.f, 1.f};
+            if constexpr (FOLD) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + srow * 8);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
-                f32x2 mr = {0.f, 1.f};
-                if constexpr (FOLD) mr = *reinterpret_cast<const f32x2*>(stg + P_STG + (mi * 16 + srow) * 8);
+                const f32x2 mr = mr_next;                              // (mean, rstd) of row mi*16 + srow, read one pass ahead
+                if constexpr (FOLD) { if (mi + 1 < 8) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + ((mi + 1) * 16 + srow) * 8); }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     f32x4 v;
-                    if constexpr (FOLD) {   // LayerNorm folded into the GEMM: rstd * (x~ W'^T - mean * rowsum(W')) + b'
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaf(-mr[0], sv[n][e], acc[mi][jp + n][e]), mr[1], bv[n][e]);
+                    if constexpr (FOLD) {   // LayerNorm folded into the GEMM: rstd * x~ W'^T + (b' - rstd * mean * rowsum(W'))
+                        const float c = -mr[0] * mr[1];                // whole-vector forms: two v_pk_fma_f32 each
+                        v = acc[mi][jp + n] * f32x4{mr[1], mr[1], mr[1], mr[1]} + (sv[n] * f32x4{c, c, c, c} + bv[n]);
                     } else {
                         v = acc[mi][jp + n] + bv[n];
                     }

@@ -334,6 +334,17 @@ def test_eva_g14_full_size_vs_reference(dev, golden_dir):
     assert (of[spots[:2]] - out).abs().max().item() < 2e-2 * out.abs().max().item()
     model.visual.max_frames_per_call = 384                      # 384 + 384 + 256: ragged micro-batches
     assert torch.equal(model.encode_image(full), of)
+    # calls of >= 64 frames fold both LayerNorms of a block into its GEMMs (HIREST_EPI_LNFOLD_*); the plain path
+    # (LayerNorm kernel + plain epilogues) on the same batch agrees within the bf16 rounding of the LayerNorm output
+    # and meets the same bar against the reference's outputs; both are deterministic
+    assert torch.equal(model.encode_image(full[:128]), of[:128])
+    model.visual.fold_layernorm, model.visual._prepared = False, None
+    plain = model.encode_image(full[:128])
+    model.visual.fold_layernorm, model.visual._prepared = True, None
+    _check_embed(plain[:1].cpu(), torch.from_numpy(g["image_embed"])[:1], "EVA-g/14 image, LayerNorm passes not folded")
+    cos = torch.nn.functional.cosine_similarity(plain, of[:128], dim=1).min().item()
+    print(f"folded vs plain LayerNorm path, 128 frames: min cosine {cos:.6f}")
+    assert cos > 0.9998
     model.visual.max_frames_per_call = 256
 
 
