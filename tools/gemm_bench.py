@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--dbg", type=int, default=0, help="hirest_gemm_debug_mode bits (timing experiments)")
     ap.add_argument("--nk", type=int, nargs=3, action="append", default=[], metavar=("N", "K", "EPI"),
                     help="extra shape (repeatable), named n<N>k<K>e<EPI>")
+    ap.add_argument("--a-scale", type=float, default=1.0, help="A = randn * scale + offset (does operand distribution move the time?)")
+    ap.add_argument("--a-offset", type=float, default=0.0)
     a = ap.parse_args()
     for n, k, e in a.nk:
         SHAPES[f"n{n}k{k}e{e}"] = (n, k, e)
@@ -43,7 +45,7 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(0)
     for name in a.shapes:
         N, K, epi = SHAPES[name]
-        A = torch.randn((M, K + a.lda_pad), device=dev, generator=g).to(torch.bfloat16)
+        A = (torch.randn((M, K + a.lda_pad), device=dev, generator=g) * a.a_scale + a.a_offset).to(torch.bfloat16)
         W = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.bfloat16)
         bias = torch.randn((N,), device=dev, generator=g)
         out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32, _lib.EPI_BIAS_RESID_LNSTATS_F32) else torch.bfloat16)
