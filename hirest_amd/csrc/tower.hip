@@ -8,6 +8,7 @@
 //   h    bf16 [M, D]                     LN output / attention output (never live together)
 //   big  bf16 [M, max(3D, Dm, kpad*)]    qkv / MLP hidden / patches (never live together)
 //   eot  i32  [B]                        text only
+//   xb / part / stats                     vision calls of >= 64 frames with folded-LayerNorm weights: see plan()
 #include "common.h"
 
 namespace {
