@@ -198,7 +198,8 @@ def main():
             t0 = time.perf_counter()
             cpu_out = ref_cpu.eva_encode_image(sd, sample, cfg)
             dt = time.perf_counter() - t0
-        gpu_out = model.encode_image(frames.reshape(-1, 3, 224, 224)[:n]).float().cpu()
+        # same kernels as the timed path: tower calls of >= 64 frames fold the LayerNorms into the GEMMs, so encode 64+ and keep n
+        gpu_out = model.encode_image(frames.reshape(-1, 3, 224, 224)[:max(n, 64)])[:n].float().cpu()
         cos = torch.nn.functional.cosine_similarity(cpu_out, gpu_out, dim=-1).min().item()
         out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{n} frames of the same synthetic batch, full 40-layer EVA-CLIP-g/14 fp32 "
