@@ -294,6 +294,12 @@ def test_eva_tiny_towers_vs_reference(dev, golden_dir):
     _check_embed(ft.cpu(), torch.from_numpy(g["fwd_text"]), "tiny fwd text")
     assert abs(ls.item() - float(g["logit_scale_exp"])) < 1e-4
     assert torch.equal(model(None, tok), model.encode_text(tok))
+    # empty batches (the reference's modules return empty [0, E] tensors) and the reference's input checks
+    assert tuple(model.encode_image(img[:0]).shape) == (0, fi.shape[1]) and tuple(model.encode_text(tok[:0]).shape) == (0, ft.shape[1])
+    with pytest.raises(AssertionError):
+        model.encode_image(img[:, :, :200, :200].contiguous())           # vit_model.py:203
+    with pytest.raises(RuntimeError):
+        model.encode_image(img.cpu())                                    # no CPU fallback
 
 
 def test_eva_g14_full_size_vs_reference(dev, golden_dir):
