@@ -180,7 +180,7 @@ def main():
                           "frames_per_gpu_per_step": args.frames, "global_batch": args.frames * world,
                           "micro_batch": args.chunk, "parallelism": f"dp{world}"},
                "roofline": roofline}
-        if args.gemm_dbg:
+        if args.gemm_dbg & ~512:                       # bit 9 only switches the kernels' walk direction off (A/B), results unchanged
             out["INVALID"] = f"timing experiment: hirest_gemm_debug_mode({args.gemm_dbg})"
 
     # ---- CPU baseline: the fp32 oracle on this host's cores, bounded sample (rank 0, N=1 only)

@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
                 ("bias", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
-                ("pos", C.c_void_p), ("patches_per_frame", C.c_int32), ("aux0", C.c_void_p), ("aux1", C.c_void_p)]
+                ("pos", C.c_void_p), ("patches_per_frame", C.c_int32), ("aux0", C.c_void_p), ("aux1", C.c_void_p), ("flags", C.c_int32)]
 
 
 class BlockWeights(C.Structure):

@@ -25,6 +25,7 @@ struct GemmP {
     void* out; int64_t ldo;
     int M, N, K;
     const float* pos; int P;
+    int rev;                  // walk the tile list backwards (HIREST_GEMM_REVERSE)
     void* aux0; void* aux1;   // LN-fold epilogues (see hirest_hip.h): producer = bf16 copy / row partials, consumer = row stats / column sums
     int nbm, nbn, ppx;   // tile counts, M-panels per XCD
     int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
@@ -1061,6 +1062,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     if (slot >= nunit) return;
     // tile `sub` of unit j -> origin; returns the number of tiles in the unit (1 or 2)
     auto unit_tile = [&](int j, int sub, int& M0, int& N0) -> int {
+        if (p.rev) j = nunit - 1 - j;                                    // (not combined with the paired-edge experiment)
         int panel, col, cnt = 1;
         if (panel_major) {
             const int full_pairs = np >> 1;
@@ -1267,6 +1269,7 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
     const int nunit = np * p.nbn;
     if (slot >= nunit) return;
     auto tile_origin = [&](int j, int& M0, int& N0) {        // same walk as p256 (see there)
+        if (p.rev) j = nunit - 1 - j;
         if (panel_major) {
             const int mt_i = j / p.nbn;
             M0 = (p_lo + mt_i) * T_BM; N0 = (j - mt_i * p.nbn) * T_BN;
@@ -1627,7 +1630,8 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.pos = a->pos; p.P = a->patches_per_frame;
     p.aux0 = a->aux0; p.aux1 = a->aux1;
-    p.dbg = g_gemm_dbg;
+    p.rev = ((a->flags & HIREST_GEMM_REVERSE) && !(g_gemm_dbg & 512)) ? 1 : 0;   // debug bit 9: ignore the direction flags (A/B)
+    p.dbg = g_gemm_dbg & ~512;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
     p.ppx = (p.nbm + 7) / 8;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -57,12 +57,13 @@ inline int vision_wide(const hirest_vision_tower* t) {
 #define CHECK(expr) do { int _e = (expr); if (_e != 0) return _e; } while (0)
 
 int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int M, int N,
-         int K, int epi, void* stream, const float* pos = nullptr, int P = 0, void* aux0 = nullptr, void* aux1 = nullptr) {
+         int K, int epi, void* stream, const float* pos = nullptr, int P = 0, void* aux0 = nullptr, void* aux1 = nullptr,
+         int flags = 0) {
     hirest_gemm_args a;
     a.A = reinterpret_cast<const hirest_bf16*>(A); a.lda = lda;
     a.W = reinterpret_cast<const hirest_bf16*>(W); a.ldw = ldw;
     a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
-    a.pos = pos; a.patches_per_frame = P; a.aux0 = aux0; a.aux1 = aux1;
+    a.pos = pos; a.patches_per_frame = P; a.aux0 = aux0; a.aux1 = aux1; a.flags = flags;
     return hirest_gemm_bf16(&a, stream);
 }
 
@@ -93,7 +94,11 @@ int run_block_lnfold(const hirest_block_weights& w, float* x, hirest_bf16* h, hi
     CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, stream));
     CHECK(gemm(xb, D, w.fc1_wf, D, w.fc1_bf, big, Dm, M, Dm, D, HIREST_EPI_LNFOLD_GELU_BF16, stream, nullptr, 0, stats,
                const_cast<float*>(w.fc1_s)));
-    CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
+    // fc2 walks its rows backwards: it starts on the part of the hidden activation fc1 wrote last, and the next block's qkv
+    // (forwards) starts on the rows of xb fc2 wrote last — both still in the 256-MB Infinity Cache.  (Alternating every
+    // kernel of the chain, attention included, measured less: the grouped tile order of qkv / fc1 runs slower backwards.)
+    CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part,
+               HIREST_GEMM_REVERSE));
     CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, stream));
     return 0;
 }

@@ -39,7 +39,7 @@ def _opt(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epilogue: int,
          pos: Optional[torch.Tensor] = None, patches_per_frame: int = 0,
-         aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None) -> torch.Tensor:
+         aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
     """out <- epilogue(a @ w.T + bias); a [M,K] bf16, w [N,K] bf16, bias [N] f32.  aux0 / aux1: the LN-fold epilogues'
     extra operands (include/hirest_hip.h)."""
     lib = _lib.load()
@@ -53,7 +53,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
                          _opt(bias, torch.float32, "gemm.bias"), _dev(out, out_dtype, "gemm.out"), out.shape[-1],
                          M, N, K, epilogue, _opt(pos, torch.float32, "gemm.pos"), patches_per_frame,
                          None if aux0 is None else _dev(aux0, aux0.dtype, "gemm.aux0"),
-                         None if aux1 is None else _dev(aux1, aux1.dtype, "gemm.aux1"))
+                         None if aux1 is None else _dev(aux1, aux1.dtype, "gemm.aux1"), int(flags))
     _lib.check(lib.hirest_gemm_bf16(C.byref(args), stream_ptr()), "hirest_gemm_bf16")
     return out
 

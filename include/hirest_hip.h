@@ -83,7 +83,12 @@ typedef struct hirest_gemm_args {
     /* LN-fold epilogues only (see enum): */
     void* aux0;
     void* aux1;
+    int32_t flags;                        /* HIREST_GEMM_REVERSE: the persistent kernels walk their tile list backwards.  Same
+                                             results; a kernel that starts where its producer stopped finds the producer's
+                                             last ~256 MB in the Infinity Cache (the tower runs fc2 backwards: it reads fc1's
+                                             output, and the next qkv reads fc2's) */
 } hirest_gemm_args;
+enum { HIREST_GEMM_REVERSE = 1 };
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
 /* Kernel selection for tests / A-B timing: 0 = automatic (default), 1 = force the 128x128 kernel,
@@ -97,7 +102,8 @@ int hirest_gemm_select_kernel(int32_t which);
  * every tile (L2-resident operands).  Bits 3-5 only reorder the persistent kernel's tile walk (results stay correct):
  * bit3 force the grouped order, bit4 force panel-major, bit5 pair ragged edge tiles into equal-duration units.
  * Persistent kernel, results wrong: bit6 no wait for the LDS-DMA, bit7 DMA of the A operand only, bit8 half the fragment
- * reads.  Any non-zero value selects a separate (slower-scheduled) instantiation.  0 restores normal operation. */
+ * reads.  Any of these selects a separate (slower-scheduled) instantiation.  bit9 (512, results unchanged, normal kernels):
+ * ignore HIREST_GEMM_REVERSE.  0 restores normal operation. */
 int hirest_gemm_debug_mode(int32_t bits);
 
 /* ------------------------------------------------------------------------------------

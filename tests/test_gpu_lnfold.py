@@ -110,3 +110,32 @@ def test_fold_epilogues_reject_small_problems(dev):
     s = torch.zeros((256,), device=dev)
     with pytest.raises(RuntimeError):
         ops.gemm(A, W, None, out, _lib.EPI_LNFOLD_BF16, aux0=st, aux1=s)
+
+
+def test_reverse_walk_is_bit_identical(dev):
+    """HIREST_GEMM_REVERSE only changes the order in which the tiles are taken."""
+    from hirest_amd import _lib, ops
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    for M, N, K, epi in [(4112, 4224, 1408, _lib.EPI_BIAS_BF16), (4112, 6144, 1408, _lib.EPI_BIAS_GELU_BF16),
+                         (4112, 1408, 6144, _lib.EPI_BIAS_RESID_F32), (2999, 1408, 1408, _lib.EPI_BIAS_RESID_LNSTATS_F32),
+                         (4112, 1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32), (2999, 4224, 1408, _lib.EPI_LNFOLD_BF16)]:
+        A = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
+        W = (torch.randn((N, K), device=dev, generator=g) * 0.03).to(torch.bfloat16)
+        bias = torch.randn((N,), device=dev, generator=g)
+        f32 = epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_RESID_LNSTATS_F32)
+        base = torch.randn((M, N), device=dev, generator=g).to(torch.float32 if f32 else torch.bfloat16)
+        res = []
+        for flags in (0, 1):
+            out = base.clone()
+            aux0 = aux1 = None
+            if epi == _lib.EPI_BIAS_RESID_LNSTATS_F32:
+                aux0 = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+                aux1 = torch.zeros((M, (N + 63) // 64, 2), device=dev)
+            elif epi == _lib.EPI_LNFOLD_BF16:
+                aux0 = torch.cat([torch.full((M + 1, 1), 0.25, device=dev), torch.full((M + 1, 1), 0.75, device=dev)], 1)[:M]
+                aux1 = torch.linspace(-1, 1, N, device=dev)
+            ops.gemm(A, W, bias, out, epi, aux0=aux0, aux1=aux1, flags=flags)
+            res.append((out, aux0 if epi == _lib.EPI_BIAS_RESID_LNSTATS_F32 else None, aux1 if epi == _lib.EPI_BIAS_RESID_LNSTATS_F32 else None))
+        assert torch.equal(res[0][0], res[1][0]), (M, N, K, epi)
+        if res[0][1] is not None:
+            assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
