@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--dbg", type=int, default=0, help="hirest_gemm_debug_mode bits (timing experiments)")
     ap.add_argument("--nk", type=int, nargs=3, action="append", default=[], metavar=("N", "K", "EPI"),
                     help="extra shape (repeatable), named n<N>k<K>e<EPI>")
+    ap.add_argument("--reverse", action="store_true", help="HIREST_GEMM_REVERSE: walk the tile list backwards")
     ap.add_argument("--a-scale", type=float, default=1.0, help="A = randn * scale + offset (does operand distribution move the time?)")
     ap.add_argument("--a-offset", type=float, default=0.0)
     a = ap.parse_args()
@@ -62,7 +63,7 @@ def main():
 
         def run():
             if not a.alias and not a.lda_pad:
-                return ops.gemm(A, W, bias, out, epi, aux0=aux0, aux1=aux1)
+                return ops.gemm(A, W, bias, out, epi, aux0=aux0, aux1=aux1, flags=1 if a.reverse else 0)
             lda = 0 if a.alias else K + a.lda_pad
             args = _lib.GemmArgs(A.data_ptr(), lda, W.data_ptr(), 0 if a.alias else K, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
             _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "gemm")
