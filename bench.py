@@ -7,8 +7,12 @@ One step = the hot path over one batch: 32 videos x 32 frames -> encode_image (4
 cosine matrix -> top-10.  Inputs (bf16 NCHW frames, token ids) are resident in HBM before the
 timed region; weights are random-init of the real architecture (no checkpoints offline).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          N > 1: re-executes itself as N ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` is binding: run directly it starts N ranks under torch.distributed.run (hirest_amd/launch.py) and fails
+loudly when fewer than N GPUs are visible; run under a launcher, WORLD_SIZE must equal N.  The JSON line carries
+`rccl_ranks` = the size of the process group the timed all-gather ran on.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      live per-launch timing (hipEvent pairs recorded by the library on the launch
@@ -23,13 +27,12 @@ import os
 import sys
 import time
 
-# the host driver only supports dmabuf IPC: RCCL's intra-node transport needs this before the HIP runtime starts
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-import torch  # noqa: E402
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+
+from hirest_amd import launch  # noqa: E402  (sets HSA_ENABLE_IPC_MODE_LEGACY=0 before the HIP runtime starts)
+
+import torch  # noqa: E402
 
 FRAMES_PER_STEP = 1024          # configs[1]
 FRAMES_PER_VIDEO = 32
@@ -37,6 +40,87 @@ N_QUERIES = 546                 # size of the real HiREST test prompt set
 TOPK = 10
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 GFLOP_PER_FRAME = 534.06        # algorithmic work of the vision tower
+PROFILE_ROUNDS = ("r02", "r01")  # newest first: where roofline.traffic is looked up
+
+
+def matched_recall(model, dev):
+    """R@1/5/10 of the GPU path against GT(q) = the real reference's top-1 video on the committed C3 sub-corpus, with the
+    margin report that says which disagreements a bf16 encoder is entitled to (evaluate.py:33-81 semantics: ranking by
+    (score, name), recall = fraction of queries whose ground-truth video is in the top k)."""
+    import numpy as np
+    from hirest_amd import retrieval, synth
+    path = os.path.join(REPO, "tests", "golden", "eva_g14_c3.npz")
+    if not os.path.isfile(path):
+        return {"skipped": "tests/golden/eva_g14_c3.npz missing"}
+    g = np.load(path)
+    V, F, seed = int(g["V"]), int(g["F"]), int(g["seed"])
+    saved = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(synth.eva_clip_state_dict(synth.EVA_CLIP_G_14, seed), strict=True)
+    try:
+        base = synth.frames("c3.base", (V, 1, 3, 224, 224), 5)
+        frames = (base + 0.1 * synth.frames("c3.noise", (V, F, 3, 224, 224), 6)).to(dev)
+        names = [f"vid_{(v * 37) % 101:03d}.mp4" for v in range(V)]
+        pooled = retrieval.encode_videos(model, frames)
+        texts = retrieval.encode_texts(model, torch.from_numpy(g["tokens"].astype(np.int64)).to(dev))
+        scores, _, idx = retrieval.retrieve(texts, pooled, 10, retrieval.tie_rank_from_names(names, dev))
+    finally:
+        model.load_state_dict(saved, strict=True)
+    idx = idx.cpu().long()
+    ref_scores = torch.from_numpy(g["scores"])
+    gt = torch.from_numpy(g["top10"][:, 0].astype(np.int64))
+    margin = torch.from_numpy(g["margin"])
+    err = (scores.cpu() - ref_scores).abs()
+    res = {f"matched_R@{k}": 100.0 * (idx[:, :k] == gt[:, None]).any(dim=1).float().mean().item() for k in (1, 5, 10)}
+    flipped = idx[:, 0] != gt
+    res.update({"queries": int(gt.numel()), "videos": V, "frames_per_video": F,
+                "max_abs_score_error": err.max().item(), "mean_abs_score_error": err.mean().item(),
+                "median_top1_margin": margin.median().item(),
+                "top1_flips": int(flipped.sum()),
+                "max_margin_of_a_flip": margin[flipped].max().item() if flipped.any() else 0.0,
+                "top1_exact_where_margin_gt_2x_error": bool((~flipped | (margin <= 2 * err.max())).all()),
+                "pooled_min_cosine_vs_reference": torch.nn.functional.cosine_similarity(
+                    pooled.cpu(), torch.from_numpy(g["pooled"]), dim=-1).min().item(),
+                "ground_truth": "top-1 of the real reference EVA_CLIP (fp32, CPU) on the same corpus / prompts / synthetic "
+                                "weights: tests/golden/eva_g14_c3.npz"})
+    return res
+
+
+def cpu_baseline(model, frames, cfg, n):
+    """The fp32 CPU oracle (oracle/ref_cpu.py, torch CPU; kind "port") on the first n frames of the same batch: one warm-up
+    frame, then 3 timed passes at 32 threads and at os.cpu_count() threads (median reported), and one single-thread pass
+    of one frame (a single-thread pass of n frames x 3 would be minutes)."""
+    from oracle import ref_cpu
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("visual.")}
+    sample = frames.reshape(-1, 3, 224, 224)[:n].float().cpu()
+    ncpu = os.cpu_count() or 1
+    rates, spent, cpu_out = {}, 0.0, None
+    with torch.no_grad():
+        for threads in sorted({min(32, ncpu), ncpu}):
+            torch.set_num_threads(threads)
+            ref_cpu.eva_encode_image(sd, sample[:1], cfg)       # warm-up
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                cpu_out = ref_cpu.eva_encode_image(sd, sample, cfg)
+                times.append(time.perf_counter() - t0)
+            spent += sum(times)
+            rates[threads] = n / sorted(times)[1]
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        ref_cpu.eva_encode_image(sd, sample[:1], cfg)
+        one = time.perf_counter() - t0
+        spent += one
+    best = max(rates, key=rates.get)
+    torch.set_num_threads(min(32, ncpu))
+    # same kernels as the timed path: tower calls of >= 64 frames fold the LayerNorms into the GEMMs, so encode 64+ and keep n
+    gpu_out = model.encode_image(frames.reshape(-1, 3, 224, 224)[:max(n, 64)])[:n].float().cpu()
+    cos = torch.nn.functional.cosine_similarity(cpu_out, gpu_out, dim=-1).min().item()
+    return {"value": rates[best], "unit": "frames/s", "cores": best, "kind": "port",
+            "by_threads": {str(t): r for t, r in rates.items()}, "single_thread": 1.0 / one, "host_cpus": ncpu,
+            "sample": f"{n} frames of the same synthetic batch, full 40-layer EVA-CLIP-g/14 fp32 (oracle/ref_cpu.py, torch "
+                      f"CPU): per thread count 1 warm-up frame + 3 timed passes (median); value = the faster of "
+                      f"{sorted(rates)} threads; single_thread = 1 frame, 1 pass; {spent:.1f} s of timed CPU work",
+            "min_cosine_gpu_vs_cpu_on_sample": cos}
 
 
 def main():
@@ -47,23 +131,25 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
     ap.add_argument("--chunk", type=int, default=1024, help="frames per tower call (micro-batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the batch timed on the CPU oracle (~10-15 s)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames per timed pass of the CPU oracle (3 passes per thread count)")
+    ap.add_argument("--no-matched-recall", action="store_true", help="skip the matched-R@k leg (reference-pinned sub-corpus)")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 force t128, 2 force t256 (A/B timing)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: run the LayerNorm passes instead of folding them into the GEMMs")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="hirest_gemm_debug_mode bits: TIMING EXPERIMENTS ONLY, the line is not a valid result")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.frames % FRAMES_PER_VIDEO != 0:
+        raise SystemExit(f"--frames must be a multiple of {FRAMES_PER_VIDEO} (whole videos): a remainder would be counted "
+                         "in frames/s without being encoded")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    launch.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], visible_devices=torch.cuda.device_count())
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    rank, local_rank, world = launch.init_ranks(args.gpus, "nccl", device=dev)   # "nccl" is RCCL on ROCm
+    assert world == args.gpus and (world == 1 or dist.get_world_size() == args.gpus)
 
     import hirest_amd
     from hirest_amd import _lib, retrieval, synth
@@ -92,32 +178,16 @@ def main():
         _, val, idx = retrieval.retrieve(text_n, allv, min(TOPK, V_total))
         return idx
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    lib.hirest_profile_enable(1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        idx = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, idx = launch.timed_steps(step, args.warmup, args.steps, torch.cuda.synchronize,
+                                      on_timed_start=lambda: lib.hirest_profile_enable(1), reduce_device=dev)
     # per-launch records of the timed steps (this rank)
     recs = (_lib.ProfRecord * 200000)()
     nrec = lib.hirest_profile_collect(recs, len(recs))
     lib.hirest_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
 
     out = None
     if rank == 0:
-        frames_total = args.frames * world * args.steps
+        frames_total = V_local * FRAMES_PER_VIDEO * world * args.steps
         value = frames_total / elapsed
         # ---- roofline of the dominant kernel, from the live records
         groups = {}
@@ -145,25 +215,29 @@ def main():
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC profile (FETCH_SIZE + WRITE_SIZE,
             # separate passes, gfx950 correction; tools/pmc_traffic.sh).  bench.py cannot sample counters on itself.
             try:
-                prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")))
+                prof_path = next(p for p in (os.path.join(REPO, "profiles", r, "pmc_traffic.json") for r in PROFILE_ROUNDS)
+                                 if os.path.isfile(p))
+                prof = json.load(open(prof_path))
                 same_tag = [e for e in breakdown if e["kernel"] == "gemm" and e["tag"] == dom["tag"]
                             and e["launches"] == dom["launches"]]
                 same_tag.sort(key=lambda e: -e["dims"][0] * e["dims"][2])            # more operand bytes first
                 cands = [k for k in prof["kernels"] if (f"gemm_p256<{dom['tag']}," in k["kernel"] or f"gemm_pp256<{dom['tag']}>" in k["kernel"])
                          and k["launches"] * args.steps in (dom["launches"], dom["launches"] - args.steps)]
                 cands.sort(key=lambda k: -k["fetch_bytes_per_launch"])
-                idx = same_tag.index(dom)
-                if idx < len(cands):
-                    traffic = cands[idx]["traffic_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
+                which = same_tag.index(dom)
+                if which < len(cands):
+                    traffic = cands[which]["traffic_bytes_per_launch"]
+            except (OSError, ValueError, KeyError, StopIteration):
                 traffic = None
         if dom:
             epi = {0: "bias", 1: "bias+gelu", 2: "bias+quickgelu", 3: "bias+residual", 4: "bias->f32", 5: "patch+pos",
                    6: "bias+residual+ln-stats", 7: "ln-fold+bias", 8: "ln-fold+bias+gelu"}
             roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                        "traffic_note": "bytes per launch through the L2's memory side (Infinity-Cache hits included), from "
-                                        "profiles/r01/pmc_traffic.json; null if no matching profile",
+                        "traffic_note": "bytes per launch through the L2's memory side (Infinity-Cache hits included), from the "
+                                        "newest committed profiles/rNN/pmc_traffic.json (rocprofv3 PMC passes of this same "
+                                        "command; tests/test_abi_and_host.py checks its kernel names against the current "
+                                        "dispatch); null if no matching profile",
                         "kernel": f"gemm<{epi.get(dom['tag'], dom['tag'])}> M={dom['dims'][0]} N={dom['dims'][1]} K={dom['dims'][2]}",
                         "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                         "algorithmic_flops_per_launch": 2.0 * dom["dims"][0] * dom["dims"][1] * dom["dims"][2],
@@ -171,7 +245,7 @@ def main():
                         "whole_tower_frac": value / world * GFLOP_PER_FRAME / 1e3 / MFMA_BF16_PEAK_TFLOPS,
                         "breakdown": breakdown[:12]}
         out = {"metric": "encoded frames/sec (EVA-CLIP-g/14 224^2)", "value": value, "unit": "frames/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "EVA-CLIP-g/14 frame encoder, 1024-frame synthetic batch bf16 per GPU per step "
@@ -183,31 +257,20 @@ def main():
         if args.gemm_dbg & ~512:                       # bit 9 only switches the kernels' walk direction off (A/B), results unchanged
             out["INVALID"] = f"timing experiment: hirest_gemm_debug_mode({args.gemm_dbg})"
 
+    # ---- matched R@k at EVA-CLIP-g/14 scale (BASELINE.json's "at matched R@1"), outside the timed region, rank 0:
+    # the sub-corpus and the 546 real prompts whose rankings the REAL reference produced in the build container
+    # (tests/golden/eva_g14_c3.npz, made by tests/golden/make_golden.py gen_c3) are re-encoded here by the same kernels
+    # the timed step ran (one >= 64-frame tower call) and ranked; GT(q) = the reference's top-1.
+    if rank == 0 and not args.no_matched_recall:
+        out["matched_recall"] = matched_recall(model, dev)
+
     # ---- CPU baseline: the fp32 oracle on this host's cores, bounded sample (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import ref_cpu
-        # torch's CPU kernels stop scaling (and then collapse) far below this box's 256 hardware threads,
-        # so the baseline uses a fixed 32-thread pool; "cores" reports exactly that.
-        ncores = min(os.cpu_count() or 1, 32)
-        torch.set_num_threads(ncores)
-        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("visual.")}
-        n = args.cpu_frames
-        sample = frames.reshape(-1, 3, 224, 224)[:n].float().cpu()
-        with torch.no_grad():
-            ref_cpu.eva_encode_image(sd, sample[:1], cfg)       # warm-up
-            t0 = time.perf_counter()
-            cpu_out = ref_cpu.eva_encode_image(sd, sample, cfg)
-            dt = time.perf_counter() - t0
-        # same kernels as the timed path: tower calls of >= 64 frames fold the LayerNorms into the GEMMs, so encode 64+ and keep n
-        gpu_out = model.encode_image(frames.reshape(-1, 3, 224, 224)[:max(n, 64)])[:n].float().cpu()
-        cos = torch.nn.functional.cosine_similarity(cpu_out, gpu_out, dim=-1).min().item()
-        out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"{n} frames of the same synthetic batch, full 40-layer EVA-CLIP-g/14 fp32 "
-                                         f"(oracle/ref_cpu.py, torch CPU), 1 warm-up frame + 1 timed pass = {dt:.1f} s",
-                               "min_cosine_gpu_vs_cpu_on_sample": cos}
+        out["cpu_baseline"] = cpu_baseline(model, frames, cfg, args.cpu_frames)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                 # rank 0's untimed legs (matched R@k) are done before anyone tears the group down
         dist.destroy_process_group()
 
 

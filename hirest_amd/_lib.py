@@ -15,14 +15,24 @@ LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
 (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_POS_F32,
  EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16) = range(9)
 
+TOWER_NO_LNFOLD = 1
+ABI_VERSION = 3   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
+
 ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}
 
 
 class GemmArgs(C.Structure):
-    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
+    _fields_ = [("struct_size", C.c_uint64),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
                 ("bias", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
                 ("pos", C.c_void_p), ("patches_per_frame", C.c_int32), ("aux0", C.c_void_p), ("aux1", C.c_void_p), ("flags", C.c_int32)]
+
+    @classmethod
+    def make(cls, *fields):
+        """GemmArgs with struct_size filled in; `fields` are the members after it, in header order."""
+        return cls(C.sizeof(cls), *fields)
+
 
 
 class BlockWeights(C.Structure):
@@ -70,8 +80,8 @@ _SIGNATURES = {
                                         C.c_float, C.c_int32, C.c_void_p]),
     "hirest_patchify": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_void_p]),
-    "hirest_rowstats_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
-    "hirest_ln_stats_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_rowstats_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hirest_ln_stats_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "hirest_write_cls_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_void_p]),
     "hirest_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -116,7 +126,8 @@ _SIGNATURES = {
                                                   C.c_int32, C.c_void_p]),
     "hirest_vision_workspace_bytes": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),
     "hirest_vision_forward": (C.c_int, [C.POINTER(VisionTower), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+                                        C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "hirest_vision_guard_offset": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),
     "hirest_text_workspace_bytes": (C.c_size_t, [C.POINTER(TextTower), C.c_int32]),
     "hirest_text_forward": (C.c_int, [C.POINTER(TextTower), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
@@ -138,8 +149,9 @@ def load():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.hirest_abi_version() != 2:
-        raise RuntimeError("libhirest_hip.so ABI version mismatch")
+    if lib.hirest_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libhirest_hip.so ABI version {lib.hirest_abi_version()} != binding {ABI_VERSION}: rebuild with "
+                           "`python -m hirest_amd.build --force`")
     _lib = lib
     return lib
 

@@ -33,32 +33,43 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build the gfx950 kernels)")
 
 
-def _stale() -> bool:
-    if not os.path.isfile(LIB_PATH):
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+           [os.path.join(os.path.dirname(HERE), "include", "hirest_hip.h"), os.path.abspath(__file__)]
+
+
+def _obj_stale(src: str, obj: str) -> bool:
+    if not os.path.isfile(obj):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "hirest_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + _headers())
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return LIB_PATH
+    """Compile the stale objects (in parallel) and relink.  An object is stale when its source, any header or this
+    file (the flags) is newer than it."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and not _obj_stale(os.path.join(CSRC, src), obj):
+            continue
         cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
         cmd += EXTRA_FLAGS.get(src, [])
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        jobs.append(cmd)
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.isfile(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
+        run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 

@@ -115,7 +115,7 @@ class OpenAIVisionTower(_Tower):
         for s in range(0, B, step):
             n = min(step, B - s)
             _lib.check(lib.hirest_vision_forward(C.byref(prep["desc"]), x[s:s + n].data_ptr(), ops._IN_DTYPES[x.dtype], n,
-                                                 out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(), ops.stream_ptr()),
+                                                 out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(), 0, ops.stream_ptr()),
                        "hirest_vision_forward")
         return out[:, 1:, :]            # w/o cls token (model.py:269)
 

@@ -147,14 +147,9 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
 template <int DH, int DP, int NT>
 int launch(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
     using C = AttnCfg<DH, DP, NT>;
-    static bool configured = false;
+    static HirestDevCfg cfg;
     auto kern = attention_kernel<DH, DP, NT>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, C::LDS_BYTES, cfg)) return e;
     hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), C::LDS_BYTES, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
     return hirest_launch_status();
 }
@@ -529,13 +524,9 @@ int launch3_impl(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scal
     using C = AttnCfg2<DH, DP, NT>;
     constexpr int LDS = (2 * C::NPAD + C::KP) * C::RS;
     static_assert(LDS <= 163840, "K x2 + V must fit the CU's LDS");
-    static bool configured = false;
+    static HirestDevCfg cfg;
     auto kern = attention_kernel_v3<DH, DP, NT, FAST, DBG>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, LDS, cfg)) return e;
     hipLaunchKernelGGL(kern, dim3(B), dim3(576), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg);
     return hirest_launch_status();
 }
@@ -552,14 +543,9 @@ int g_attn_variant = 3;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3
 template <int DH, int DP, int NT>
 int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
     using C = AttnCfg2<DH, DP, NT>;
-    static bool configured = false;
+    static HirestDevCfg cfg;
     auto kern = attention_kernel_v2<DH, DP, NT>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, C::LDS_BYTES, cfg)) return e;
     hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), C::LDS_BYTES, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal);
     return hirest_launch_status();
 }

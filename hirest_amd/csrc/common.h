@@ -19,6 +19,32 @@ static inline int hirest_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// Per-DEVICE one-time kernel configuration (a function attribute set on device 0 says nothing about device 1, and the
+// reference's drivers move models with .to(device) without ever calling set_device): raises the dynamic-LDS limit of
+// `kern` on the current device the first time it is launched there and reports that device's CU count.
+struct HirestDevCfg {
+    static constexpr int MAXDEV = 64;
+    bool done[MAXDEV] = {};
+    int cus[MAXDEV] = {};
+};
+template <class Kern>
+static inline int hirest_configure(Kern kern, int lds_bytes, HirestDevCfg& c, int* cus = nullptr) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= HirestDevCfg::MAXDEV) return HIREST_E_BADARG;
+    if (!c.done[dev]) {
+        if (lds_bytes > 0) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        if ((e = hipDeviceGetAttribute(&c.cus[dev], hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+        c.done[dev] = true;
+    }
+    if (cus) *cus = c.cus[dev];
+    return 0;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

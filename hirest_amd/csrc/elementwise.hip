@@ -133,11 +133,22 @@ __global__ __launch_bounds__(256) void layernorm_rows_bulk(const float* __restri
 //   ln_finalize_kernel     per-row (sum, sum of squares) of G 32-column groups -> (mean, rstd); 8 lanes per row, the G
 //                          partials are combined in double so the E[x^2] - mean^2 form loses nothing to their order
 // ---------------------------------------------------------------------------------------------
+// Guard of the folded form: max over rows of |mean| * rstd = |mean| / sigma of the rounded row.  The fold feeds the GEMM
+// the UN-normalised bf16 row, so a row-wide offset of r sigma costs r / 2^9 sigma of rounding error per element where the
+// LayerNorm pass would have cost 2^-9 of the normalised value; the host falls back to the LayerNorm pass for a call whose
+// worst row exceeds its threshold (hirest_vision_forward, HIREST_TOWER_NO_LNFOLD).  Non-negative floats order like their
+// bit patterns, so the maximum is an integer atomicMax; the plain read in front keeps the steady state atomic-free.
+__device__ __forceinline__ void guard_max(float* guard, float v) {
+    if (v > __builtin_nontemporal_load(guard)) atomicMax(reinterpret_cast<int*>(guard), __float_as_int(v));
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void rowstats_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ xb,
-                                                            float* __restrict__ stats, float eps, int rows, int D) {
+                                                            float* __restrict__ stats, float eps, int rows, int D,
+                                                            float* __restrict__ guard) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
+    float worst = 0.f;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const float* xr = x + (int64_t)row * ldx;
         float s = 0.f, q = 0.f;
@@ -156,12 +167,15 @@ __global__ __launch_bounds__(256) void rowstats_bf16_kernel(const float* __restr
         const double mean = S / D;
         double var = Q / D - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (int64_t)row) = f32x2{(float)mean, (float)(1.0 / sqrt(var + (double)eps))};
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (int64_t)row) = f32x2{(float)mean, rstd};
+        worst = fmaxf(worst, fabsf((float)mean) * rstd);
     }
+    if (guard && lane == 0) guard_max(guard, worst);
 }
 
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int G, float* __restrict__ stats,
-                                                          float eps, int rows, int D) {
+                                                          float eps, int rows, int D, float* __restrict__ guard) {
     const int sub = threadIdx.x & 7;
     const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     double S = 0.0, Q = 0.0;
@@ -171,11 +185,18 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
     }
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) { S += __shfl_xor(S, m); Q += __shfl_xor(Q, m); }
+    float ratio = 0.f;
     if (row < rows && sub == 0) {
         const double mean = S / D;
         double var = Q / D - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{(float)mean, (float)(1.0 / sqrt(var + (double)eps))};
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{(float)mean, rstd};
+        ratio = fabsf((float)mean) * rstd;
+    }
+    if (guard) {
+        ratio = wave_max(ratio);
+        if ((threadIdx.x & 63) == 0) guard_max(guard, ratio);
     }
 }
 
@@ -321,24 +342,24 @@ extern "C" int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_
 }
 
 extern "C" int hirest_rowstats_bf16(const float* x, int64_t ldx, hirest_bf16* xb, float* stats, float eps, int32_t rows, int32_t D,
-                                    void* stream) {
+                                    float* guard, void* stream) {
     if (!x || !xb || !stats || rows <= 0) return HIREST_E_BADARG;
     if (D <= 0 || D % 4 != 0 || D > 6 * 256 || ldx % 4 != 0) return HIREST_E_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     bf16_t* o = reinterpret_cast<bf16_t*>(xb);
     const int nv = (D / 4 + 63) / 64;
     const int grid = rows / 4 + 1 < 256 * 16 ? rows / 4 + 1 : 256 * 16;
-#define RS_CASE(NVV) case NVV: hipLaunchKernelGGL((rowstats_bf16_kernel<NVV>), dim3(grid), dim3(256), 0, s, x, ldx, o, stats, eps, rows, D); break;
+#define RS_CASE(NVV) case NVV: hipLaunchKernelGGL((rowstats_bf16_kernel<NVV>), dim3(grid), dim3(256), 0, s, x, ldx, o, stats, eps, rows, D, guard); break;
     switch (nv) { RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) default: return HIREST_E_SHAPE; }
 #undef RS_CASE
     return hirest_launch_status();
 }
 
 extern "C" int hirest_ln_stats_finalize(const float* partials, int32_t groups, float* stats, float eps, int32_t rows, int32_t D,
-                                        void* stream) {
+                                        float* guard, void* stream) {
     if (!partials || !stats || rows <= 0 || groups <= 0 || D <= 0) return HIREST_E_BADARG;
     hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partials, groups,
-                       stats, eps, rows, D);
+                       stats, eps, rows, D, guard);
     return hirest_launch_status();
 }
 

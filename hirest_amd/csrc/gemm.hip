@@ -1473,18 +1473,11 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
 
 template <int EPI>
 int launch_pp256(GemmP p, hipStream_t s) {
-    static bool configured = false;
-    static int cus = 0;
+    static HirestDevCfg cfg;
+    int cus = 0;
     auto kern = gemm_pp256<EPI>;
     constexpr int LDS = 2 * Q_STEP + 8 * p_stg_bytes(EPI);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, LDS, cfg, &cus)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
     p.ppx = (p.nbm + 7) / 8;
     int nslot = cus / 8; nslot = nslot < 1 ? 1 : nslot;
@@ -1496,19 +1489,12 @@ int launch_pp256(GemmP p, hipStream_t s) {
 
 template <int EPI, int WN, bool DBG>
 int launch_p256_impl(GemmP p, hipStream_t s) {
-    static bool configured = false;
-    static int cus = 0;
+    static HirestDevCfg cfg;
+    int cus = 0;
     auto kern = gemm_p256<EPI, WN, DBG>;
     constexpr int NW = 512 / WN;
     constexpr int LDS = 2 * Q_STEP + NW * p_stg_bytes(EPI);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, LDS, cfg, &cus)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
     p.ppx = (p.nbm + 7) / 8;
     int nslot = cus / 8; nslot = nslot < 1 ? 1 : nslot;
@@ -1529,14 +1515,9 @@ int launch_p256(GemmP p, hipStream_t s) {
 
 template <int EPI>
 int launch256q(GemmP p, hipStream_t s) {
-    static bool configured = false;
+    static HirestDevCfg cfg;
     auto kern = gemm_t256q<EPI>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * Q_STEP);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, 2 * Q_STEP, cfg)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
     p.ppx = (p.nbm + 7) / 8;
     const int grid = 8 * p.ppx * p.nbn;
@@ -1546,14 +1527,9 @@ int launch256q(GemmP p, hipStream_t s) {
 
 template <int EPI>
 int launch256p(GemmP p, hipStream_t s) {
-    static bool configured = false;
+    static HirestDevCfg cfg;
     auto kern = gemm_t256p<EPI>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           4 * T_SLAB);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, 4 * T_SLAB, cfg)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
     p.ppx = (p.nbm + 7) / 8;
     const int grid = 8 * p.ppx * p.nbn;
@@ -1563,14 +1539,9 @@ int launch256p(GemmP p, hipStream_t s) {
 
 template <int EPI, int T_NST>
 int launch256(GemmP p, hipStream_t s) {
-    static bool configured = false;
+    static HirestDevCfg cfg;
     auto kern = gemm_t256<EPI, T_NST>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           T_NST * T_SLAB);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = hirest_configure(kern, T_NST * T_SLAB, cfg)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
     p.ppx = (p.nbm + 7) / 8;
     const int grid = 8 * p.ppx * p.nbn;
@@ -1620,7 +1591,7 @@ extern "C" int hirest_gemm_select_kernel(int32_t which) {
 }
 
 extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
-    if (!a || !a->A || !a->W || !a->out) return HIREST_E_BADARG;
+    if (!a || a->struct_size != sizeof(hirest_gemm_args) || !a->A || !a->W || !a->out) return HIREST_E_BADARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return HIREST_E_BADARG;
     if (a->K % BK != 0 || a->K % T_BK != 0 || a->N % 4 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return HIREST_E_SHAPE;
     GemmP p;

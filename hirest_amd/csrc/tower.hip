@@ -16,7 +16,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Regions {
-    size_t x, h, big, eot, xb, part, stats, total;
+    size_t x, h, big, eot, xb, part, stats, guard, total;
 };
 
 // lnfold: also the folded-LayerNorm buffers (vision): xb bf16 [M,D] = rounded copy of the residual stream (A operand of
@@ -28,11 +28,12 @@ Regions plan(int64_t M, int D, int wide, int B, bool lnfold = false) {
     r.h = off; off += align256((size_t)M * D * 2);
     r.big = off; off += align256((size_t)M * wide * 2);
     r.eot = off; off += align256((size_t)B * 4);
-    r.xb = r.part = r.stats = off;
+    r.xb = r.part = r.stats = r.guard = off;
     if (lnfold) {
         r.xb = off; off += align256((size_t)M * D * 2);
         r.part = off; off += align256((size_t)M * ((D + 63) / 64) * 8);
         r.stats = off; off += align256((size_t)M * 8);
+        r.guard = off; off += 256;                      // one float: max |mean| / sigma over all rows and layers of the call
     }
     r.total = off;
     return r;
@@ -60,6 +61,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bi
          int K, int epi, void* stream, const float* pos = nullptr, int P = 0, void* aux0 = nullptr, void* aux1 = nullptr,
          int flags = 0) {
     hirest_gemm_args a;
+    a.struct_size = sizeof(a);
     a.A = reinterpret_cast<const hirest_bf16*>(A); a.lda = lda;
     a.W = reinterpret_cast<const hirest_bf16*>(W); a.ldw = ldw;
     a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
@@ -85,13 +87,13 @@ int run_block(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf
 // the same block with both LayerNorms folded into the GEMMs around them (include/hirest_hip.h, HIREST_EPI_LNFOLD_*):
 // on entry xb / stats describe x; proj and fc2 refresh them in their epilogues
 int run_block_lnfold(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf16* big, hirest_bf16* xb, float* part,
-                     float* stats, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream) {
+                     float* stats, float* guard, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream) {
     const int M = B * T, G = (D + 63) / 64;
     CHECK(gemm(xb, D, w.qkv_wf, D, w.qkv_bf, big, 3 * D, M, 3 * D, D, HIREST_EPI_LNFOLD_BF16, stream, nullptr, 0, stats,
                const_cast<float*>(w.qkv_s)));
     CHECK(hirest_attention_bf16(big, h, B, T, heads, dh, 1.0f / sqrtf((float)dh), 0, stream));
     CHECK(gemm(h, D, w.proj_w, D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
-    CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, stream));
+    CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, guard, stream));
     CHECK(gemm(xb, D, w.fc1_wf, D, w.fc1_bf, big, Dm, M, Dm, D, HIREST_EPI_LNFOLD_GELU_BF16, stream, nullptr, 0, stats,
                const_cast<float*>(w.fc1_s)));
     // fc2 walks its rows backwards: it starts on the part of the hidden activation fc1 wrote last, and the next block's qkv
@@ -99,7 +101,7 @@ int run_block_lnfold(const hirest_block_weights& w, float* x, hirest_bf16* h, hi
     // kernel of the chain, attention included, measured less: the grouped tile order of qkv / fc1 runs slower backwards.)
     CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part,
                HIREST_GEMM_REVERSE));
-    CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, stream));
+    CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, guard, stream));
     return 0;
 }
 
@@ -117,13 +119,19 @@ extern "C" size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, in
     return plan((int64_t)B * T, t->width, vision_wide(t), B, vision_lnfold(t, B)).total;
 }
 
+extern "C" size_t hirest_vision_guard_offset(const hirest_vision_tower* t, int32_t B) {
+    if (!t || B <= 0 || !vision_lnfold(t, B)) return (size_t)-1;
+    const int T = (t->image_size / t->patch) * (t->image_size / t->patch) + 1;
+    return plan((int64_t)B * T, t->width, vision_wide(t), B, true).guard;
+}
+
 extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* frames, int32_t in_dtype, int32_t B,
-                                     float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                                     float* out, void* workspace, size_t workspace_bytes, int32_t flags, void* stream) {
     if (!t || !frames || !out || !workspace || B <= 0 || !t->blocks) return HIREST_E_BADARG;
     if (t->width != t->heads * t->head_dim || t->image_size % t->patch != 0) return HIREST_E_SHAPE;
     const int G = t->image_size / t->patch, P = G * G, T = P + 1, D = t->width;
-    const bool lnfold = vision_lnfold(t, B);
-    const Regions r = plan((int64_t)B * T, D, vision_wide(t), B, lnfold);
+    const bool can_fold = vision_lnfold(t, B), lnfold = can_fold && !(flags & HIREST_TOWER_NO_LNFOLD);
+    const Regions r = plan((int64_t)B * T, D, vision_wide(t), B, can_fold);   // one layout for both forms of a call
     if (workspace_bytes < r.total) return HIREST_E_WORKSPACE;
     char* ws = reinterpret_cast<char*>(workspace);
     float* x = reinterpret_cast<float*>(ws + r.x);
@@ -141,9 +149,11 @@ extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* f
         hirest_bf16* xb = reinterpret_cast<hirest_bf16*>(ws + r.xb);
         float* part = reinterpret_cast<float*>(ws + r.part);
         float* stats = reinterpret_cast<float*>(ws + r.stats);
-        CHECK(hirest_rowstats_bf16(x, D, xb, stats, t->ln_eps, B * T, D, stream));
+        float* guard = reinterpret_cast<float*>(ws + r.guard);
+        if (hipMemsetAsync(guard, 0, 256, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return hirest_launch_status();
+        CHECK(hirest_rowstats_bf16(x, D, xb, stats, t->ln_eps, B * T, D, guard, stream));
         for (int l = 0; l < t->layers; ++l)
-            CHECK(run_block_lnfold(t->blocks[l], x, h, big, xb, part, stats, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps,
+            CHECK(run_block_lnfold(t->blocks[l], x, h, big, xb, part, stats, guard, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps,
                                    stream));
     } else {
         for (int l = 0; l < t->layers; ++l)

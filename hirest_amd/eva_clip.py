@@ -34,7 +34,11 @@ from . import _lib, ops, synth
 OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)   # eva_clip.py:16
 OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)   # eva_clip.py:17
 
-_MODEL_CONFIGS: Dict[str, dict] = {"EVA_CLIP_g_14": synth.EVA_CLIP_G_14, "EVA_CLIP_tiny_test": synth.EVA_CLIP_TINY}
+_NO_GUARD = (1 << 64) - 1           # hirest_vision_guard_offset: (size_t)-1 = this call does not fold
+
+_MODEL_CONFIGS: Dict[str, dict] = {"EVA_CLIP_g_14": synth.EVA_CLIP_G_14, "EVA_CLIP_tiny_test": synth.EVA_CLIP_TINY,
+                                   # the tiny towers with EVA-CLIP-g's 1024-d output: what MomentModel.clip_g_map_text takes
+                                   "EVA_CLIP_tiny_e1024_test": dict(synth.EVA_CLIP_TINY, embed_dim=1024)}
 
 
 def list_models():
@@ -139,6 +143,9 @@ class VisionTower(_Tower):
         self.image_mean, self.image_std = OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
         self.max_frames_per_call = 1024  # micro-batch per tower call (workspace ~5.4 GB at 1024 frames)
         self.fold_layernorm = True       # tower calls of >= 64 frames fold both LayerNorms of a block into its GEMMs
+        self.fold_guard_ratio = 4.0      # a call whose worst token row sits > 4 sigma off zero is redone with LayerNorm passes
+        self.last_fold_ratio = 0.0       # (None: never check).  Largest |mean| / sigma seen by the last forward()
+        self.fold_fallbacks = 0          # calls redone so far
 
     def _prepare(self, device):
         if self._prepared is not None and self._prepared["device"] == device:
@@ -188,6 +195,7 @@ class VisionTower(_Tower):
         return self._prepared
 
     @torch.no_grad()
+    @ops.on_tensor_device
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         """image: [B,3,S,S] float (already normalised; NCHW) or uint8 [B,S,S,3] raw RGB (fused
         ToTensor+Normalize).  Returns [B, embed_dim] fp32, not normalised (vit_model.py:348-351)."""
@@ -204,15 +212,31 @@ class VisionTower(_Tower):
         image = image.contiguous()
         B = image.shape[0]
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=image.device)
-        step = max(1, int(self.max_frames_per_call))
-        nbytes = lib.hirest_vision_workspace_bytes(C.byref(prep["desc"]), min(B, step))
+        if B == 0:
+            return out
+        # Near-equal micro-batches instead of full ones + a remainder: with max_frames_per_call = 1024, 1030 frames run as
+        # 515 + 515, not 1024 + 6, so a small tail never drops below the 64-frame boundary where the tower switches
+        # kernels (folded LayerNorm / persistent attention) — every frame of a >= 64-frame call takes the same path.
+        calls = -(-B // max(1, int(self.max_frames_per_call)))
+        step = -(-B // calls)
+        nbytes = lib.hirest_vision_workspace_bytes(C.byref(prep["desc"]), step)
         ws = self._ws(nbytes, image.device)
         code = ops._IN_DTYPES[image.dtype]
+        self.last_fold_ratio = 0.0
         for s in range(0, B, step):
             n = min(step, B - s)
-            _lib.check(lib.hirest_vision_forward(C.byref(prep["desc"]), image[s:s + n].data_ptr(), code, n,
-                                                 out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(), ops.stream_ptr()),
-                       "hirest_vision_forward")
+            args = (C.byref(prep["desc"]), image[s:s + n].data_ptr(), code, n, out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel())
+            _lib.check(lib.hirest_vision_forward(*args, 0, ops.stream_ptr()), "hirest_vision_forward")
+            # Guard of the folded LayerNorm (include/hirest_hip.h): the call reports the largest |mean| / sigma any token row
+            # had in any layer.  Row offsets of more than `fold_guard_ratio` sigma would lose precision in the un-normalised
+            # bf16 operand, so such a call is repeated with the LayerNorm passes (one 4-byte read-back per call).
+            goff = lib.hirest_vision_guard_offset(C.byref(prep["desc"]), n) if self.fold_guard_ratio is not None else _NO_GUARD
+            if goff != _NO_GUARD:
+                ratio = float(ws[goff:goff + 4].view(torch.float32).item())
+                self.last_fold_ratio = max(self.last_fold_ratio, ratio)
+                if not ratio <= self.fold_guard_ratio:                      # also catches NaN
+                    self.fold_fallbacks += 1
+                    _lib.check(lib.hirest_vision_forward(*args, _lib.TOWER_NO_LNFOLD, ops.stream_ptr()), "hirest_vision_forward")
         return out
 
 
@@ -271,6 +295,7 @@ class TextTower(_Tower):
         return self._prepared
 
     @torch.no_grad()
+    @ops.on_tensor_device
     def forward(self, text: torch.Tensor) -> torch.Tensor:
         """text: [B, context_length] int64 token ids (EOT = row max). Returns [B, embed_dim] fp32."""
         if text.dim() != 2 or text.shape[1] != self.context_length:
@@ -298,7 +323,8 @@ class EVA_CLIP(nn.Module):
         v, t = dict(vision_cfg), dict(text_cfg)
         self.visual = VisionTower(v.get("image_size", 224), v.get("patch_size", 16), v.get("width", 768),
                                   v.get("layers", 12), v.get("width", 768) // v.get("head_width", 64),
-                                  v.get("mlp_ratio", 4.0), embed_dim, quick_gelu)
+                                  v.get("mlp_ratio", 4.0), embed_dim)   # always nn.GELU: the reference passes
+        # act_layer to the TextTransformer only (eva_model.py:283-312), also under force_quick_gelu
         self.text = TextTower(t.get("vocab_size", 49408), t.get("width", 512), t.get("layers", 12), t.get("heads", 8),
                               t.get("context_length", 77), embed_dim, quick_gelu)
         self.output_dtype = torch.float32
@@ -370,6 +396,10 @@ def create_model(model_name: str, pretrained: str = "", precision: str = "fp32",
     cfg = deepcopy(_MODEL_CONFIGS[model_name])
     if force_quick_gelu:
         cfg["quick_gelu"] = True
+    synthetic = isinstance(pretrained, str) and pretrained.startswith("synth:")
+    if not synthetic and not os.path.isfile(pretrained):
+        # what the reference's torch.load raises after it has built the 1.2 B-parameter model; raised before building here
+        raise FileNotFoundError(f"[Errno 2] No such file or directory: '{pretrained}'")
     model = EVA_CLIP(**cfg)
     if isinstance(pretrained, str) and pretrained.startswith("synth:"):
         model.load_state_dict(synth.eva_clip_state_dict(cfg, int(pretrained.split(":", 1)[1])), strict=True)

@@ -18,6 +18,7 @@ Step captioning (modeling.py:556-632): trim_feats, the same fusion/encoder on 20
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import json
 import os
@@ -61,12 +62,23 @@ def _seq(**mods):
     return m
 
 
-class MomentModel(nn.Module):
-    """modeling.py:18-129 (inference subset).  ``clip_model`` may be a hirest_amd.EVA_CLIP (its
-    ``encode_text`` is what test_step calls, modeling.py:286,364) or None when text features are fed
-    through ``batch['text_feat']`` (the commented-out alternative at modeling.py:284)."""
+_BUILD_CLIP = "build"      # default of MomentModel(clip_model=...): construct the CLIP as the reference's __init__ does
 
-    def __init__(self, n_frames=-1, asr_dim=-1, args=None, clip_model=None, max_position_embeddings=2048):
+
+class MomentModel(nn.Module):
+    """modeling.py:18-129 (inference subset).
+
+    ``MomentModel(n_frames, asr_dim, args)`` — the reference's three-argument call (run.py:52-56) — builds and freezes its
+    own text encoder exactly as modeling.py:115-123 does: ``build_eva_model_and_transforms("EVA_CLIP_g_14",
+    pretrained="./pretrained_weights/eva_clip_psz14.pt")``, ``.float()``, ``.eval()``, ``freeze_clip()``; a missing
+    checkpoint raises ``FileNotFoundError`` there as it does in the reference.  The towers stay on the host until the
+    model is moved; their kernel-ready device buffers are prepared on the first ``encode_text`` after ``.to(cuda)``.
+    ``args.clip_model_name`` / ``args.clip_pretrained`` (not reference options; default to the two literals above)
+    redirect the build, e.g. to a synthetic checkpoint offline.
+    Pass ``clip_model=<EVA_CLIP>`` to share an already built encoder, or ``clip_model=None`` for a model that is fed
+    ``batch['text_feat']`` (the commented-out alternative at modeling.py:284) and owns no CLIP."""
+
+    def __init__(self, n_frames=-1, asr_dim=-1, args=None, clip_model=_BUILD_CLIP, max_position_embeddings=2048):
         super().__init__()
         self.args, self.n_frames, self.asr_dim = args, n_frames, asr_dim
         self.use_asr = asr_dim > 0
@@ -122,7 +134,16 @@ class MomentModel(nn.Module):
         self.clip4cap_model.decoder = dec
         self.tokenizer_vocab = None      # optional id -> token list (BERT vocab is not available offline)
         self.clip_g_map, self.clip_g_map_text = _Lin(E, 1024), _Lin(E, 1024)
+        if isinstance(clip_model, str) and clip_model == _BUILD_CLIP:
+            from .eva_clip import build_eva_model_and_transforms                 # modeling.py:114-123
+            clip_model, self.clip_preprocess = build_eva_model_and_transforms(
+                getattr(args, "clip_model_name", None) or "EVA_CLIP_g_14",
+                pretrained=getattr(args, "clip_pretrained", None) or "./pretrained_weights/eva_clip_psz14.pt")
+            print("Loaded EVA CLIP G")
+            clip_model = clip_model.float()
+            clip_model.eval()
         self.clip_model = clip_model
+        self.freeze_clip()
         self.heads = 12
         self._cache = None
 
@@ -272,14 +293,18 @@ class MomentModel(nn.Module):
 
     def test_step(self, batch, **kwargs):
         task = batch["tasks"][0]
-        if task == "moment_retrieval":
-            return self.test_moment_retrieval(batch, **kwargs)
-        elif task == "moment_segmentation":
-            return self.test_moment_segmentation(batch, **kwargs)
-        elif task == "step_captioning":
-            return self.test_step_captioning(batch, **kwargs)
-        else:
-            raise NotImplementedError
+        dev = self.clip_g_map.weight.device
+        # kernels launch on the model's device, whatever the process's current device is (the reference never calls
+        # set_device in single-process runs: run.py:61-65)
+        with torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext():
+            if task == "moment_retrieval":
+                return self.test_moment_retrieval(batch, **kwargs)
+            elif task == "moment_segmentation":
+                return self.test_moment_segmentation(batch, **kwargs)
+            elif task == "step_captioning":
+                return self.test_step_captioning(batch, **kwargs)
+            else:
+                raise NotImplementedError
 
     def train_step(self, batch):
         raise NotImplementedError("hirest_amd.MomentModel is inference-only (training is out of scope, SURVEY 2.1 #9)")

@@ -7,6 +7,7 @@ contiguity and raise RuntimeError on violations (the reference's ATen ops raise 
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional
 
 import torch
@@ -16,11 +17,28 @@ from ._lib import (EPI_BIAS_BF16, EPI_BIAS_F32, EPI_BIAS_GELU_BF16, EPI_BIAS_QGE
                    EPI_PATCH_POS_F32)
 
 __all__ = ["gemm", "layernorm", "attention", "patchify", "write_cls_rows", "embed_tokens", "to_bf16",
-           "pool_l2norm", "similarity", "topk", "stream_ptr"]
+           "pool_l2norm", "similarity", "topk", "stream_ptr", "on_tensor_device"]
 
 
 def stream_ptr() -> int:
+    """Raw hipStream_t of torch's current stream on the CURRENT device (wrappers switch to their tensors' device first)."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def on_tensor_device(fn):
+    """Run `fn` with the device of its first GPU tensor argument current.  The reference's drivers place models with
+    ``.to(device)`` and never call ``set_device`` (run.py:61-65, inference_video_retrieval.py:195-201); a kernel must
+    then launch on the stream — and with the per-device kernel attributes — of the tensors' device, not of cuda:0."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kw)
+                break
+        return fn(*args, **kw)
+    return wrapped
 
 
 def _dev(t: torch.Tensor, dtype, name: str) -> int:
@@ -37,6 +55,7 @@ def _opt(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
     return None if t is None else _dev(t, dtype, name)
 
 
+@on_tensor_device
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epilogue: int,
          pos: Optional[torch.Tensor] = None, patches_per_frame: int = 0,
          aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
@@ -49,7 +68,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
         raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
     out_dtype = torch.bfloat16 if epilogue in (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, _lib.EPI_LNFOLD_BF16,
                                               _lib.EPI_LNFOLD_GELU_BF16) else torch.float32
-    args = _lib.GemmArgs(_dev(a, torch.bfloat16, "gemm.a"), K, _dev(w, torch.bfloat16, "gemm.w"), K,
+    args = _lib.GemmArgs.make(_dev(a, torch.bfloat16, "gemm.a"), K, _dev(w, torch.bfloat16, "gemm.w"), K,
                          _opt(bias, torch.float32, "gemm.bias"), _dev(out, out_dtype, "gemm.out"), out.shape[-1],
                          M, N, K, epilogue, _opt(pos, torch.float32, "gemm.pos"), patches_per_frame,
                          None if aux0 is None else _dev(aux0, aux0.dtype, "gemm.aux0"),
@@ -67,6 +86,7 @@ def attention_select_kernel(which: int):
     _lib.check(_lib.load().hirest_attention_select_kernel(int(which)), "hirest_attention_select_kernel")
 
 
+@on_tensor_device
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor,
               row_index: Optional[torch.Tensor] = None, ldx: Optional[int] = None, rows: Optional[int] = None):
     lib = _lib.load()
@@ -81,6 +101,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
+@on_tensor_device
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, N: int, H: int, dh: int, causal: bool,
               scale: Optional[float] = None):
     lib = _lib.load()
@@ -94,6 +115,7 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, N: int, H: int, dh: 
 _IN_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.uint8: 2}
 
 
+@on_tensor_device
 def patchify(frames: torch.Tensor, patch: int, kpad: int, out: torch.Tensor, mean=None, std=None):
     lib = _lib.load()
     if frames.dtype not in _IN_DTYPES:
@@ -107,6 +129,7 @@ def patchify(frames: torch.Tensor, patch: int, kpad: int, out: torch.Tensor, mea
     return out
 
 
+@on_tensor_device
 def write_cls_rows(x: torch.Tensor, cls: torch.Tensor, pos0: torch.Tensor, B: int, T: int, D: int):
     lib = _lib.load()
     _lib.check(lib.hirest_write_cls_rows(_dev(x, torch.float32, "x"), D, _dev(cls, torch.float32, "cls"),
@@ -114,6 +137,7 @@ def write_cls_rows(x: torch.Tensor, cls: torch.Tensor, pos0: torch.Tensor, B: in
     return x
 
 
+@on_tensor_device
 def embed_tokens(tokens: torch.Tensor, tok_emb: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, eot_row: torch.Tensor):
     lib = _lib.load()
     B, L = tokens.shape
@@ -124,6 +148,7 @@ def embed_tokens(tokens: torch.Tensor, tok_emb: torch.Tensor, pos: torch.Tensor,
     return x
 
 
+@on_tensor_device
 def to_bf16(t: torch.Tensor) -> torch.Tensor:
     """fp32 -> bf16 (RNE) on device through the library's cast kernel."""
     lib = _lib.load()
@@ -136,6 +161,7 @@ def to_bf16(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@on_tensor_device
 def pool_l2norm(frame_embeds: torch.Tensor, normalize_frames_first: bool = False) -> torch.Tensor:
     """[V,F,E] f32 -> [V,E]: mean over frames then L2 (inference_video_retrieval.py:283-285)."""
     lib = _lib.load()
@@ -146,6 +172,7 @@ def pool_l2norm(frame_embeds: torch.Tensor, normalize_frames_first: bool = False
     return out
 
 
+@on_tensor_device
 def similarity(text_n: torch.Tensor, video_n: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     Q, E = text_n.shape
@@ -156,6 +183,7 @@ def similarity(text_n: torch.Tensor, video_n: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@on_tensor_device
 def topk(scores: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
     lib = _lib.load()
     Q, V = scores.shape

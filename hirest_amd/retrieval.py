@@ -59,20 +59,52 @@ def encode_texts(model, tokens: torch.Tensor) -> torch.Tensor:
     return ops.pool_l2norm(te.unsqueeze(1).contiguous())
 
 
+class RowGather:
+    """The exchange step of the sharded corpus: every rank contributes an equally padded block [per, E] of pooled
+    rows, one ``all_gather_into_tensor`` (RCCL over xGMI on GPU tensors, gloo on CPU tensors) returns [n_total, E] in
+    rank order.  Send and receive buffers are allocated ONCE per (shape, dtype, device) and reused by every call —
+    a steady-state retrieval step allocates nothing."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._key = None
+        self._send = self._recv = None
+
+    def _buffers(self, per, tail, dtype, device, world):
+        key = (per, tail, dtype, device, world)
+        if key != self._key:
+            self._send = torch.zeros((per,) + tail, dtype=dtype, device=device)
+            self._recv = torch.empty((world * per,) + tail, dtype=dtype, device=device)
+            self._key = key
+        return self._send, self._recv
+
+    def __call__(self, local: torch.Tensor, n_total: int) -> torch.Tensor:
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return local[:n_total]
+        world = dist.get_world_size(self.group)
+        per = (n_total + world - 1) // world
+        if local.shape[0] > per:
+            raise RuntimeError(f"gather_rows: {local.shape[0]} local rows > ceil({n_total}/{world}) = {per}")
+        send, recv = self._buffers(per, tuple(local.shape[1:]), local.dtype, local.device, world)
+        if local.shape[0] == per and local.is_contiguous():
+            send = local                                   # full block: gather straight from the caller's tensor
+        else:
+            send[: local.shape[0]].copy_(local)            # the last rank's short block; the pad rows stay zero
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv[:n_total]
+
+
+_default_gather: Dict[object, RowGather] = {}
+
+
 def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """All-gather equally padded row blocks [per, E] -> [n_total, E] in rank order.  Works on any
-    backend (RCCL on GPU tensors, gloo on CPU tensors); a no-op without an initialised group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local[:n_total]
-    world = dist.get_world_size(group)
-    per = (n_total + world - 1) // world
-    if local.shape[0] != per:
-        pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[: local.shape[0]] = local
-        local = pad
-    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out[:n_total]
+    """All-gather equally padded row blocks [per, E] -> [n_total, E] in rank order.  Works on any backend (RCCL on GPU
+    tensors, gloo on CPU tensors); a no-op without an initialised group.  The returned tensor is a view of a buffer that
+    the next call with the same shape overwrites (see RowGather)."""
+    g = _default_gather.get(group)
+    if g is None:
+        g = _default_gather[group] = RowGather(group)
+    return g(local, n_total)
 
 
 def tie_rank_from_names(names: Sequence[str], device=None) -> torch.Tensor:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HIREST_ABI_VERSION 2
+#define HIREST_ABI_VERSION 3   /* 3: hirest_gemm_args gained struct_size (first member) and flags */
 
 #define HIREST_E_BADARG   (-1)
 #define HIREST_E_SHAPE    (-2)   /* unsupported shape (see each function) */
@@ -71,6 +71,9 @@ enum hirest_epilogue {
 };
 
 typedef struct hirest_gemm_args {
+    uint64_t struct_size;                 /* = sizeof(hirest_gemm_args) of the header the caller was built against; a
+                                             binding with another layout is rejected (HIREST_E_BADARG) instead of being
+                                             read past its end */
     const hirest_bf16* A;  int64_t lda;   /* [M,K] */
     const hirest_bf16* W;  int64_t ldw;   /* [N,K] */
     const float* bias;                    /* [N] or NULL */
@@ -155,8 +158,13 @@ int hirest_write_cls_rows(float* x, int64_t ldx, const float* cls, const float* 
  *   hirest_rowstats_bf16       x f32 [rows, D] -> xb bf16 [rows, D] (the GEMM's A operand) and stats f32 [rows, 2] =
  *                              (mean, 1/sqrt(var + eps)) of the ROUNDED row, biased variance.  D % 4 == 0, D <= 1536.
  *   hirest_ln_stats_finalize   partials f32 [rows, groups, 2] written by HIREST_EPI_BIAS_RESID_LNSTATS_F32 -> stats. */
-int hirest_rowstats_bf16(const float* x, int64_t ldx, hirest_bf16* xb, float* stats, float eps, int32_t rows, int32_t D, void* stream);
-int hirest_ln_stats_finalize(const float* partials, int32_t groups, float* stats, float eps, int32_t rows, int32_t D, void* stream);
+/* `guard` (device float, may be NULL): both kernels raise it to max over their rows of |mean| * rstd — how many sigmas the
+ * worst row sits away from zero.  The fold hands the GEMM the UN-normalised bf16 row, so a row offset of r sigma costs
+ * about r times the rounding noise of the LayerNorm pass; callers zero it before a tower call and compare afterwards. */
+int hirest_rowstats_bf16(const float* x, int64_t ldx, hirest_bf16* xb, float* stats, float eps, int32_t rows, int32_t D,
+                         float* guard, void* stream);
+int hirest_ln_stats_finalize(const float* partials, int32_t groups, float* stats, float eps, int32_t rows, int32_t D,
+                             float* guard, void* stream);
 
 /* Text prologue: x[b,t,:] = tok_emb[tok[b,t]] + pos[t]  (eva_model.py:233-235); also writes
  * eot_row[b] = b*L + argmax_t tok[b,t] (first maximum) for the EOT gather (eva_model.py:243). */
@@ -228,10 +236,16 @@ typedef struct hirest_vision_tower {       /* EVA ViT (vit_model.py:248-351) */
 
 size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B);
 /* frames: see hirest_patchify in_dtype; out: f32 [B, embed_dim] (not normalised), like
- * EVA_CLIP.encode_image (eva_model.py:317). */
+ * EVA_CLIP.encode_image (eva_model.py:317).
+ * flags: HIREST_TOWER_NO_LNFOLD runs the LayerNorm passes even where the folded form would apply (same workspace).
+ * A folded call leaves, at byte offset hirest_vision_guard_offset(t, B) of the workspace, one float = the largest
+ * |mean| / sigma any token row of any layer had (see hirest_rowstats_bf16); the offset is (size_t)-1 for calls that do
+ * not fold.  The host layer re-runs a call with HIREST_TOWER_NO_LNFOLD when that value exceeds its threshold. */
+enum { HIREST_TOWER_NO_LNFOLD = 1 };
 int hirest_vision_forward(const hirest_vision_tower* t, const void* frames, int32_t in_dtype,
                           int32_t B, float* out, void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          int32_t flags, void* stream);
+size_t hirest_vision_guard_offset(const hirest_vision_tower* t, int32_t B);
 
 typedef struct hirest_text_tower {         /* CLIP text transformer (eva_model.py:177-250) */
     int32_t context, vocab, width, heads, layers, embed_dim;

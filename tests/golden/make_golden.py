@@ -214,6 +214,60 @@ def gen_eval():
 
 
 
+C3_V, C3_F = 64, 4          # sub-corpus of the matched-R@k check: 64 videos x 4 frames = 256 frames on the real reference
+
+
+def c3_corpus():
+    """SURVEY 8d C3 corpus rule: video v's frames = base_v + 0.1 * noise_f (non-degenerate, seeded)."""
+    base = synth.frames("c3.base", (C3_V, 1, 3, 224, 224), 5)
+    return base + 0.1 * synth.frames("c3.noise", (C3_V, C3_F, 3, 224, 224), 6)
+
+
+def c3_names():
+    # deliberately NOT in index order under string sort, so the (score, name) tie rule of evaluate.py:58-60 is exercised
+    return [f"vid_{(v * 37) % 101:03d}.mp4" for v in range(C3_V)]
+
+
+def gen_c3(prompts):
+    """BASELINE configs[2] at EVA-CLIP-g/14 scale on the REAL reference: encode the C3 sub-corpus and the 546 real test
+    prompts with eva_model.EVA_CLIP (synthetic weights), pool / normalise / score exactly as
+    inference_video_retrieval.py:207-212,283-285,323-334 does, rank as evaluate.py:58-60 does.  GT(q) = the reference's
+    top-1 video (with random weights a planted text<->video truth is meaningless); the fixture also holds the
+    top-2 margins that decide where a bf16 encoder may legitimately flip a rank."""
+    import eva_model
+    import clip as ref_clip
+    cfg, seed = synth.EVA_CLIP_G_14, 3
+    torch.manual_seed(0)
+    model = eva_model.EVA_CLIP(**cfg)
+    print(model.load_state_dict(synth.eva_clip_state_dict(cfg, seed), strict=True))
+    model.eval().float()
+    frames = c3_corpus().reshape(C3_V * C3_F, 3, 224, 224)
+    tok = ref_clip.tokenize(prompts)
+    fe, te = [], []
+    with torch.no_grad():
+        for s in range(0, frames.shape[0], 8):
+            fe.append(model.encode_image(frames[s:s + 8]).float())
+            print("frames", s + 8, flush=True)
+        for s in range(0, tok.shape[0], 10):                       # batch 10: inference_video_retrieval.py:203-212
+            f = model.encode_text(tok[s:s + 10]).float()
+            te.append(f / f.norm(dim=-1, keepdim=True))
+    fe = torch.cat(fe).view(C3_V, C3_F, -1)
+    vid = fe.mean(dim=1)                                           # :283-285
+    vid = vid / vid.norm(dim=-1, keepdim=True)
+    te = torch.cat(te)
+    scores = te @ vid.t()                                          # :334
+    names = c3_names()
+    top10 = []
+    for q in range(scores.shape[0]):
+        sc, nm = zip(*sorted(zip(scores[q].tolist(), names)))      # evaluate.py:58-60
+        top10.append([names.index(n) for n in nm[::-1][:10]])
+    top2 = scores.topk(2, dim=1).values
+    save("eva_g14_c3.npz", seed=seed, V=C3_V, F=C3_F, frame_embed16=np32(fe.view(-1, fe.shape[-1])[:16]),
+         pooled=np32(vid), text_embed32=np32(te[:32]), tokens=tok.numpy().astype(np.int32), scores=np32(scores),
+         top10=np.array(top10, dtype=np.int32), margin=np32(top2[:, 0] - top2[:, 1]))
+    print("c3: median top-1 margin", float((top2[:, 0] - top2[:, 1]).median()), "min", float((top2[:, 0] - top2[:, 1]).min()))
+
+
 def build_reference_moment_model():
     """Construct the REAL reference MomentModel (modeling.py:18-129) with the offline work-arounds of
     SURVEY 8c: stub the packages it imports but does not use on this path, skip the three file / network
@@ -290,6 +344,9 @@ def joint_inputs(name, B, T, seed):
     return vis, asr, text, vis_mask, moment_mask, bounds
 
 
+JOINT_CASES = {"a": (3, 64), "b": (2, 300), "c120": (5, 120), "c571": (5, 571), "c1855": (5, 1855)}
+
+
 def gen_joint():
     model, args = build_reference_moment_model()
     names = [k for k in model.state_dict().keys() if not k.startswith("clip_model.")]
@@ -301,7 +358,9 @@ def gen_joint():
     n_train = sum(p.numel() for n, p in model.named_parameters() if not n.startswith("clip_model."))
     print("joint params", n_train)
     out = {"n_params": n_train}
-    for case, (B, T) in {"a": (3, 64), "b": (2, 300)}.items():
+    # a, b: small cases with intermediate rows; c120 / c571 / c1855: SURVEY 8d C4 sizes (B = 5; median / p95 / max of the
+    # real video durations), predictions + logits only
+    for case, (B, T) in JOINT_CASES.items():
         vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"joint.{case}", B, T, 41)
         model.clip_model.encode_text = lambda ids, _t=text: _t          # explicit text features
         ids = torch.zeros(B, 77, dtype=torch.long)
@@ -583,6 +642,7 @@ def main():
         "eval": gen_eval,
         "openai_b32": lambda: gen_openai("openai_b32", synth.OPENAI_VIT_B32, 1, 64, 16, prompts=prompts),
         "eva_g14": lambda: gen_eva("eva_g14", synth.EVA_CLIP_G_14, 3, 2, 8),
+        "c3": lambda: gen_c3(prompts),
         "joint": gen_joint,
         "caption": gen_caption,
         "preprocess": gen_preprocess,

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/hirest_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.hirest_abi_version() == 2
+    assert lib.hirest_abi_version() == 3 == _lib.ABI_VERSION
     assert b"gfx950" in lib.hirest_build_info()
 
 
@@ -36,6 +36,11 @@ def test_argument_errors_without_gpu(lib):
     from hirest_amd import _lib
     a = _lib.GemmArgs()  # all-NULL
     assert lib.hirest_gemm_bf16(ctypes.byref(a), None) == -1
+    # a binding built against another struct layout (ABI 2 had no struct_size / flags) is rejected before any member
+    # behind its end is read: non-NULL operands, valid shape, wrong struct_size -> BADARG, never a launch
+    b = _lib.GemmArgs(ctypes.sizeof(_lib.GemmArgs) - 8, 1 << 20, 64, 1 << 21, 64, None, 1 << 22, 64, 64, 64, 64, 0)
+    assert lib.hirest_gemm_bf16(ctypes.byref(b), None) == -1
+    assert _lib.GemmArgs.make().struct_size == ctypes.sizeof(_lib.GemmArgs) == 120
     assert lib.hirest_layernorm(None, 0, None, None, None, 0.0, None, 0, 0, 0, 0, None) == -1
     assert lib.hirest_attention_bf16(None, None, 1, 1, 1, 64, 1.0, 0, None) == -1
     assert lib.hirest_vision_workspace_bytes(None, 4) == 0
@@ -105,3 +110,34 @@ def test_image_transform_geometry():
     std = np.array(hirest_amd.eva_clip.OPENAI_DATASET_STD, dtype=np.float32).reshape(3, 1, 1)
     want = (arr.astype(np.float32).transpose(2, 0, 1) / 255.0 - mean) / std
     assert np.allclose(t.numpy(), want, atol=1e-6)
+
+
+def test_moment_model_builds_its_own_clip_like_the_reference(tmp_path, monkeypatch):
+    """modeling.py:115-129: MomentModel(n_frames, asr_dim, args) builds EVA_CLIP_g_14 from ./pretrained_weights/
+    eva_clip_psz14.pt, casts to float, puts it in eval mode and freezes it.  Offline the two args fields redirect the build
+    to a synthetic checkpoint of the tiny towers; without them the reference's file is looked for and its absence is the
+    reference's error."""
+    import hirest_amd
+    from hirest_amd import synth
+
+    class Args:
+        clip_model_name = "EVA_CLIP_tiny_e1024_test"
+        clip_pretrained = "synth:11"
+    m = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=Args())
+    assert isinstance(m.clip_model, hirest_amd.EVA_CLIP) and not m.clip_model.training
+    assert all(not p.requires_grad for p in m.clip_model.parameters())
+    assert all(p.dtype == torch.float32 for p in m.clip_model.parameters())
+    assert any(p.requires_grad for n, p in m.named_parameters() if not n.startswith("clip_model."))
+    sd = m.state_dict()
+    assert "clip_model.text.token_embedding.weight" in sd and "clip_model.visual.blocks.0.attn.q_bias" in sd
+    want = synth.eva_clip_state_dict(dict(synth.EVA_CLIP_TINY, embed_dim=1024), 11)
+    assert torch.equal(sd["clip_model.text.text_projection"], want["text.text_projection"])
+    assert m.clip_preprocess is not None
+    with pytest.raises(RuntimeError):                       # no CPU fallback: the text tower refuses host tensors
+        m.test_step({"tasks": ["moment_retrieval"], "clip_text_ids": torch.zeros(1, 77, dtype=torch.long),
+                     "vis_feats": torch.zeros(1, 4, 1024), "vis_mask": torch.ones(1, 4, dtype=torch.long),
+                     "moment_mask": torch.ones(1, 4, dtype=torch.long), "asr_feats": torch.zeros(1, 4, 384)})
+    monkeypatch.chdir(tmp_path)                             # no ./pretrained_weights here
+    with pytest.raises(FileNotFoundError):
+        hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None)
+    assert hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None).clip_model is None

@@ -22,7 +22,7 @@ def test_bench_line_contract():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["metric"].startswith("encoded frames/sec") and d["unit"] == "frames/s" and d["higher_is_better"] is True
-    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "bf16"
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "bf16"
     assert d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
     assert d["value"] > 100 and abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
@@ -34,3 +34,32 @@ def test_bench_line_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert cb["min_cosine_gpu_vs_cpu_on_sample"] > 0.999
+    assert cb["single_thread"] > 0 and str(cb["cores"]) in cb["by_threads"] and cb["host_cpus"] >= cb["cores"]
+    # matched R@k at EVA-CLIP-g/14 scale against the real reference's rankings (tests/golden/eva_g14_c3.npz)
+    mr = d["matched_recall"]
+    assert mr["queries"] == 546 and mr["videos"] == 64
+    assert mr["matched_R@5"] == 100.0 and mr["matched_R@10"] == 100.0 and mr["matched_R@1"] >= 85.0
+    assert mr["top1_exact_where_margin_gt_2x_error"] is True and mr["pooled_min_cosine_vs_reference"] > 0.999
+
+
+def test_bench_gpus_flag_is_binding():
+    """`python bench.py --gpus N` on a box with fewer than N GPUs must fail, not report a 1-GPU run (VERDICT r1 item 1);
+    with >= 2 GPUs it must print n_gpus = rccl_ranks = 2 from a self-launched 2-rank RCCL job."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "64",
+                        "--chunk", "64", "--no-cpu-baseline", "--no-matched-recall"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    else:
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["global_batch"] == 128
+
+
+def test_bench_rejects_partial_videos():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--frames", "100"], capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert r.returncode != 0 and "multiple of 32" in r.stderr

@@ -64,7 +64,7 @@ def _case(golden_dir, case):
     return shapes, pred, g, joint_inputs(f"joint.{case}", pred["B"], pred["T"], 41)
 
 
-@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("case", ["a", "b", "c120", "c571", "c1855"])     # c*: SURVEY 8d C4 sizes (B = 5), real-reference goldens
 def test_moment_model_vs_reference(dev, golden_dir, case):
     import hirest_amd
     shapes, pred, g, (vis, asr, text, vis_mask, moment_mask, bounds) = _case(golden_dir, case)
@@ -74,7 +74,7 @@ def test_moment_model_vs_reference(dev, golden_dir, case):
         visual_num_hidden_layers = 2
         moment_segmentation_difference_threshold = 0.5
         moment_segmentation_max_iterations = 20
-    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=Args())
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=Args(), clip_model=None)
     res = model.load_state_dict(sd, strict=False)
     assert not res.missing_keys                                   # every parameter we own is in the reference schema
     model = model.to(dev).eval()
@@ -115,7 +115,7 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     moment_mask = torch.zeros(B, T, dtype=torch.long)
     for b in range(B):
         moment_mask[b, 5 + b:5 + b + pred["lens"][b]] = 1
-    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None)
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
     model.load_state_dict(sd, strict=False)
     model = model.to(dev).eval()
     trimmed = model._trim(vis.to(dev), moment_mask.to(dev), 20)
@@ -125,3 +125,55 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     res = model.test_step(batch, num_beams=pred["beams"], return_ids=True)
     assert res["prediction"] == pred["prediction"]
     assert [" ".join(str(i) for i in h) for h in res["token_ids"]] == pred["prediction"]
+
+
+def test_clip_text_ids_path_equals_text_feat_path(dev, golden_dir):
+    """The reference's only way to text features is clip_model.encode_text(batch['clip_text_ids']) inside test_step
+    (modeling.py:286,364,568).  A MomentModel that built its own (tiny, 1024-d) EVA_CLIP the reference's way runs all three
+    tasks from token ids; feeding the same encoder's output as batch['text_feat'] must give bit-identical predictions,
+    and the ids really matter (other prompts -> other text features)."""
+    import hirest_amd
+    sys.path.insert(0, golden_dir)
+    from make_golden import joint_inputs
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    sd = synth.joint_state_dict(shapes, 31)
+    sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
+
+    class Args:
+        clip_model_name = "EVA_CLIP_tiny_e1024_test"
+        clip_pretrained = "synth:11"
+        visual_num_hidden_layers = 2
+        moment_segmentation_difference_threshold = 0.5
+        moment_segmentation_max_iterations = 20
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=Args())          # builds + freezes its CLIP
+    res = model.load_state_dict(sd, strict=False)                                     # BEST.pth-style: no clip_model.* keys
+    assert all(k.startswith("clip_model.") for k in res.missing_keys)
+    model = model.to(dev).eval()
+    B, T = 3, 64
+    vis, asr, _, vis_mask, moment_mask, bounds = joint_inputs("ids.path", B, T, 43)
+    prompts = json.load(open(os.path.join(golden_dir, "test_prompts.json")))[:B]
+    ids = hirest_amd.tokenize(prompts)
+    text = model.clip_model.encode_text(ids.to(dev)).float()
+    assert tuple(text.shape) == (B, 1024)
+    other = model.clip_model.encode_text(hirest_amd.tokenize(prompts[::-1]).to(dev)).float()
+    assert not torch.equal(text, other)
+    cap_mask = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate([7, 20, 37]):
+        cap_mask[b, 5 + b:5 + b + n] = 1
+    batches = {
+        "moment_retrieval": {"vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "asr_feats": asr},
+        "moment_segmentation": {"vis_feats": vis, "vis_mask": vis_mask, "asr_feats": asr, "moment_bound_frames": bounds},
+        "step_captioning": {"vis_feats": vis, "vis_mask": vis_mask, "moment_mask": cap_mask, "asr_feats": asr},
+    }
+    for task, b in batches.items():
+        kw = {"num_beams": 3} if task == "step_captioning" else {}
+        from_ids = model.test_step(dict(b, tasks=[task], clip_text_ids=ids), **kw)["prediction"]
+        from_feat = model.test_step(dict(b, tasks=[task], text_feat=text), **kw)["prediction"]
+        assert from_ids == from_feat, task
+        assert len(from_ids) == B
+    # a model without a CLIP and without text_feat has nothing to encode the ids with
+    bare = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=Args(), clip_model=None)
+    bare.load_state_dict(sd, strict=False)
+    bare = bare.to(dev).eval()
+    with pytest.raises(RuntimeError):
+        bare.test_step(dict(batches["moment_retrieval"], tasks=["moment_retrieval"], clip_text_ids=ids))

@@ -19,7 +19,7 @@ def dev():
 def _finalize(part, rows, D, eps, dev):
     from hirest_amd import _lib, ops
     stats = torch.empty((rows, 2), device=dev)
-    _lib.check(_lib.load().hirest_ln_stats_finalize(part.data_ptr(), part.shape[1], stats.data_ptr(), eps, rows, D, ops.stream_ptr()),
+    _lib.check(_lib.load().hirest_ln_stats_finalize(part.data_ptr(), part.shape[1], stats.data_ptr(), eps, rows, D, None, ops.stream_ptr()),
                "hirest_ln_stats_finalize")
     return stats
 
@@ -69,7 +69,7 @@ def test_consumer_equals_layernorm_then_gemm(dev, M, N, K, gelu):
     xb = torch.empty((M, K), device=dev, dtype=torch.bfloat16)
     stats = torch.empty((M + 1, 2), device=dev)[:M]                 # readable up to an even row count (header contract)
     if K <= 1536:
-        _lib.check(_lib.load().hirest_rowstats_bf16(x.data_ptr(), K, xb.data_ptr(), stats.data_ptr(), eps, M, K, ops.stream_ptr()), "rowstats")
+        _lib.check(_lib.load().hirest_rowstats_bf16(x.data_ptr(), K, xb.data_ptr(), stats.data_ptr(), eps, M, K, None, ops.stream_ptr()), "rowstats")
     else:                                                           # wider than any LayerNorm on the path: statistics from torch
         xb.copy_(x.to(torch.bfloat16))
         fd = xb.double()
@@ -139,3 +139,78 @@ def test_reverse_walk_is_bit_identical(dev):
         assert torch.equal(res[0][0], res[1][0]), (M, N, K, epi)
         if res[0][1] is not None:
             assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_guard_value_is_the_worst_row_offset_in_sigmas(dev):
+    """hirest_rowstats_bf16 / hirest_ln_stats_finalize raise *guard to max_rows |mean| * rstd (never lower it)."""
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device=dev); g.manual_seed(17)
+    M, D = 3001, 1408
+    x = torch.randn((M, D), device=dev, generator=g)
+    x[1234] += 7.5                                                   # one row 7.5 sigma off zero
+    xb = torch.empty((M, D), device=dev, dtype=torch.bfloat16)
+    stats = torch.empty((M, 2), device=dev)
+    guard = torch.zeros(64, device=dev)
+    _lib.check(lib.hirest_rowstats_bf16(x.data_ptr(), D, xb.data_ptr(), stats.data_ptr(), 1e-6, M, D, guard.data_ptr(), ops.stream_ptr()), "rowstats")
+    want = (stats[:, 0].abs() * stats[:, 1]).max().item()
+    assert guard[0].item() == want and 7.0 < want < 8.0 and (stats[:, 0].abs() * stats[:, 1]).argmax().item() == 1234
+    # the finalize kernel on the partials of the same rows: same statistics, same guard; a larger previous value is kept
+    G = D // 64
+    f = xb.float().reshape(M, G, 64)
+    part = torch.stack([f.sum(-1), (f * f).sum(-1)], -1).contiguous()
+    for start, expect in ((0.0, want), (99.0, 99.0)):
+        guard.fill_(start)
+        st2 = torch.empty((M, 2), device=dev)
+        _lib.check(lib.hirest_ln_stats_finalize(part.data_ptr(), G, st2.data_ptr(), 1e-6, M, D, guard.data_ptr(), ops.stream_ptr()), "finalize")
+        assert abs(guard[0].item() - expect) <= 1e-4 * expect
+        assert (st2 - stats).abs().max().item() < 1e-4
+
+
+def test_fold_guard_falls_back_on_row_offsets_not_on_outlier_channels(dev):
+    """VERDICT r1 8c.  Real ViT-g checkpoints have massive activations: a few CHANNELS hundreds of sigma out.  Those do
+    not hurt the folded form (the LayerNorm pass rounds the same element with the same relative error).  A row-wide OFFSET
+    does: |mean| >> sigma means the un-normalised bf16 operand spends its mantissa on the offset.  The tower measures
+    max |mean| / sigma per call and redoes a call above `fold_guard_ratio` with the LayerNorm passes."""
+    import hirest_amd
+    from hirest_amd import synth
+    from oracle import ref_cpu as O
+    cfg, seed, B = synth.EVA_CLIP_TINY, 11, 64
+    img = synth.frames("guard.img", (B, 3, 224, 224), 3)
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
+
+    def run(mutate, **attrs):
+        sd = synth.eva_clip_state_dict(cfg, seed)
+        mutate(sd)
+        model = hirest_amd.EVA_CLIP(**cfg)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dev).eval()
+        for k, v in attrs.items():
+            setattr(model.visual, k, v)
+        out = model.encode_image(img.to(dev)).cpu()
+        return out, model.visual, sd
+
+    # (1) stock synthetic weights: folded, far below the threshold
+    out, vis, sd = run(lambda sd: None)
+    assert vis.fold_fallbacks == 0 and 0.0 < vis.last_fold_ratio < 4.0
+    assert cos(out, O.eva_encode_image(sd, img, cfg)) > 0.999
+    # (2) a 300x outlier channel planted into the residual stream by layer 0: stays folded, same bar against the oracle
+    def outlier(sd):
+        sd["visual.blocks.0.attn.proj.bias"][5] += 300.0
+    out, vis, sd = run(outlier)
+    ref = O.eva_encode_image(sd, img, cfg)
+    assert vis.fold_fallbacks == 0 and vis.last_fold_ratio < 4.0, vis.last_fold_ratio
+    assert cos(out, ref) > 0.999
+    # (3) a 10-sigma row offset: the guard fires, the call is redone with LayerNorm passes, the result equals a model that
+    # never folds (bit for bit) and meets the bar; with the guard switched off the folded result is measurably worse
+    def offset(sd):
+        sd["visual.blocks.0.attn.proj.bias"] += 10.0
+    out, vis, sd = run(offset)
+    ref = O.eva_encode_image(sd, img, cfg)
+    assert vis.fold_fallbacks == 1 and vis.last_fold_ratio > 4.0
+    plain, _, _ = run(offset, fold_layernorm=False)
+    unguarded, vis_u, _ = run(offset, fold_guard_ratio=None)
+    assert torch.equal(out, plain) and vis_u.fold_fallbacks == 0
+    c_guard, c_raw = cos(out, ref), cos(unguarded, ref)
+    print(f"10-sigma row offset: guarded (LayerNorm passes) cos {c_guard:.6f}, folded anyway cos {c_raw:.6f}, ratio {vis.last_fold_ratio:.2f}")
+    assert c_guard > 0.999 and c_guard >= c_raw

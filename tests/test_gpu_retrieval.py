@@ -1,6 +1,8 @@
 """BASELINE configs[2] in miniature: the full video-retrieval data path on the GPU (encode frames -> mean-pool
 + L2 -> score 'queries' -> top-k) against the CPU oracle on the same corpus.  Ground truth is defined as in
 SURVEY 8d: GT(q) = the oracle's top-1 video; 'matched R@k' = fraction of queries whose GT is in the GPU top-k."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -80,3 +82,62 @@ def test_raw_uint8_videos_are_preprocessed_on_device():
     ref = O.pool_video(O.eva_encode_image(sd, torch.from_numpy(x), cfg).reshape(V, F, -1))
     cos = torch.nn.functional.cosine_similarity(pooled, ref, dim=-1)
     assert cos.min().item() > 0.999, cos
+
+
+def test_c3_matched_recall_at_g14_scale_vs_real_reference(golden_dir):
+    """BASELINE configs[2] / "matched R@1" at EVA-CLIP-g/14 scale.  tests/golden/eva_g14_c3.npz holds
+    what the REAL reference (eva_model.EVA_CLIP fp32 on CPU, synthetic weights; make_golden.py gen_c3) produced for a
+    64-video x 4-frame sub-corpus (SURVEY 8d corpus rule) and the 546 real HiREST test prompts: pooled video rows, scores,
+    top-10 under evaluate.py's (score, name) order, top-2 margins.  GT(q) = the reference's top-1.  The GPU path must
+    rank every query's GT inside its top-5, agree on top-1 wherever the reference's margin exceeds twice the score error
+    bf16 encoding causes, and reproduce the reference's embeddings at the parity bar."""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import hirest_amd
+    from hirest_amd import retrieval
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "eva_g14_c3.npz"))
+    V, F, seed = int(g["V"]), int(g["F"]), int(g["seed"])
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_g_14", pretrained=f"synth:{seed}")
+    model = model.to(dev).eval()
+    base = synth.frames("c3.base", (V, 1, 3, 224, 224), 5)
+    frames = base + 0.1 * synth.frames("c3.noise", (V, F, 3, 224, 224), 6)
+    names = [f"vid_{(v * 37) % 101:03d}.mp4" for v in range(V)]
+    tok = torch.from_numpy(g["tokens"].astype(np.int64))
+    assert torch.equal(tok, hirest_amd.tokenize(json.load(open(os.path.join(golden_dir, "test_prompts.json")))))
+    pooled, fe = retrieval.encode_videos(model, frames.to(dev), return_frame_embeds=True)     # one 256-frame tower call
+    texts = retrieval.encode_texts(model, tok.to(dev))
+    scores, val, idx = retrieval.retrieve(texts, pooled, 10, retrieval.tie_rank_from_names(names, dev))
+    idx, scores = idx.cpu().long(), scores.cpu()
+    # ---- embeddings against the reference's own outputs (16 frames of the 40-layer tower, 32 text rows, 64 pooled rows)
+    cosf = torch.nn.functional.cosine_similarity
+    c_frame = cosf(fe.reshape(V * F, -1)[:16].cpu(), torch.from_numpy(g["frame_embed16"]), dim=-1).min().item()
+    c_pool = cosf(pooled.cpu(), torch.from_numpy(g["pooled"]), dim=-1).min().item()
+    c_text = cosf(texts[:32].cpu(), torch.from_numpy(g["text_embed32"]), dim=-1).min().item()
+    assert c_frame > 0.999 and c_pool > 0.999 and c_text > 0.999, (c_frame, c_pool, c_text)
+    # ---- matched R@k: GT(q) = reference top-1; evaluate.py:62-81 semantics through the pinned restatement
+    ref_scores = torch.from_numpy(g["scores"])
+    gt_idx = torch.from_numpy(g["top10"][:, 0].astype(np.int64))
+    margin = torch.from_numpy(g["margin"])
+    err = (scores - ref_scores).abs().max().item()
+    rec = retrieval.recall_at_k(idx, names, [[names[int(i)]] for i in gt_idx], ks=(1, 5, 10))
+    same = O.recall_at_k(scores, names, [[names[int(i)]] for i in gt_idx])
+    assert all(abs(rec[k] - same[k]) < 1e-9 for k in rec)                  # kernel top-k == sort-based oracle on the same scores
+    flips = idx[:, 0] != gt_idx
+    hist = torch.histc(margin, bins=8, min=0.0, max=float(margin.max())).long().tolist()
+    print(f"C3 @ g/14: matched R@1/5/10 = {rec['R@1']:.2f} / {rec['R@5']:.2f} / {rec['R@10']:.2f} %; max |score error| {err:.2e}; "
+          f"reference top-1 margins: median {margin.median().item():.2e}, min {margin.min().item():.2e}, histogram(8 bins) {hist}; "
+          f"top-1 flips {int(flips.sum())}, largest margin among them {margin[flips].max().item() if flips.any() else 0.0:.2e}; "
+          f"min cosine frame/pooled/text {c_frame:.6f} / {c_pool:.6f} / {c_text:.6f}")
+    assert rec["R@5"] == 100.0 and rec["R@10"] == 100.0
+    safe = margin > 2 * err
+    assert torch.equal(idx[safe, 0], gt_idx[safe])                         # exact wherever the margin decides
+    assert rec["R@1"] >= 100.0 * safe.float().mean().item() - 1e-9
+    # whole top-10 lists agree wherever every adjacent gap of the reference's list exceeds twice the error
+    ref_top = torch.from_numpy(g["top10"].astype(np.int64))
+    gaps = torch.gather(ref_scores, 1, ref_top[:, :-1]) - torch.gather(ref_scores, 1, ref_top[:, 1:])
+    ref_sorted = ref_scores.sort(dim=1, descending=True).values
+    clear = (gaps.min(dim=1).values > 2 * err) & ((ref_sorted[:, 9] - ref_sorted[:, 10]) > 2 * err)
+    assert torch.equal(idx[clear], ref_top[clear])

@@ -10,7 +10,7 @@ from make_golden import joint_inputs
 shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "joint_schema.json"))).items()}
 sd = synth.joint_state_dict(shapes, 31)
 dev = torch.device("cuda:0")
-model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None)
+model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
 model.load_state_dict(sd, strict=False)
 model = model.to(dev).eval()
 B, T = 5, 300

@@ -65,7 +65,7 @@ def main():
             if not a.alias and not a.lda_pad:
                 return ops.gemm(A, W, bias, out, epi, aux0=aux0, aux1=aux1, flags=1 if a.reverse else 0)
             lda = 0 if a.alias else K + a.lda_pad
-            args = _lib.GemmArgs(A.data_ptr(), lda, W.data_ptr(), 0 if a.alias else K, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
+            args = _lib.GemmArgs.make(A.data_ptr(), lda, W.data_ptr(), 0 if a.alias else K, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
             _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "gemm")
         for v in a.variants:
             ops.gemm_select_kernel(v)
