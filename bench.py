@@ -85,41 +85,73 @@ def matched_recall(model, dev):
     return res
 
 
+def _log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(model, frames, cfg, n):
-    """The fp32 CPU oracle (oracle/ref_cpu.py, torch CPU; kind "port") on the first n frames of the same batch: one warm-up
-    frame, then 3 timed passes at 32 threads and at os.cpu_count() threads (median reported), and one single-thread pass
-    of one frame (a single-thread pass of n frames x 3 would be minutes)."""
+    """The fp32 CPU oracle (oracle/ref_cpu.py, torch CPU; kind "port") on the first n frames of the same batch.
+    Reported at three thread counts: 32, os.cpu_count() and 1.  Only the 32-thread figure is a full measurement
+    (1 warm-up frame + 3 timed passes of the whole 40-layer tower, median); torch's CPU kernels collapse far below this
+    box's 256 hardware threads and a single thread needs ~15 s per frame, so those two are first PROBED on the first 2 of
+    the 40 (identical) blocks and the full 3-pass measurement is only run for a thread count whose probe beats the
+    32-thread rate — otherwise the probe's extrapolation (x 40 / 2 layers) is what is reported, and labelled so."""
     from oracle import ref_cpu
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("visual.")}
     sample = frames.reshape(-1, 3, 224, 224)[:n].float().cpu()
     ncpu = os.cpu_count() or 1
-    rates, spent, cpu_out = {}, 0.0, None
-    with torch.no_grad():
-        for threads in sorted({min(32, ncpu), ncpu}):
-            torch.set_num_threads(threads)
-            ref_cpu.eva_encode_image(sd, sample[:1], cfg)       # warm-up
-            times = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                cpu_out = ref_cpu.eva_encode_image(sd, sample, cfg)
-                times.append(time.perf_counter() - t0)
-            spent += sum(times)
-            rates[threads] = n / sorted(times)[1]
-        torch.set_num_threads(1)
+    L = cfg["vision_cfg"]["layers"]
+    spent = 0.0
+
+    def full(threads):
+        nonlocal spent
+        torch.set_num_threads(threads)
+        ref_cpu.eva_encode_image(sd, sample[:1], cfg)       # warm-up
+        times, out = [], None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = ref_cpu.eva_encode_image(sd, sample, cfg)
+            times.append(time.perf_counter() - t0)
+        spent += sum(times)
+        return n / sorted(times)[1], out
+
+    def probe(threads, layers=2):
+        nonlocal spent
+        torch.set_num_threads(threads)
+        ref_cpu.eva_encode_image(sd, sample[:1], cfg, n_layers=1)
         t0 = time.perf_counter()
-        ref_cpu.eva_encode_image(sd, sample[:1], cfg)
-        one = time.perf_counter() - t0
-        spent += one
-    best = max(rates, key=rates.get)
-    torch.set_num_threads(min(32, ncpu))
+        ref_cpu.eva_encode_image(sd, sample[:1], cfg, n_layers=layers)
+        dt = time.perf_counter() - t0
+        spent += dt
+        return 1.0 / (dt * L / layers)
+    with torch.no_grad():
+        base_threads = min(32, ncpu)
+        _log(f"cpu baseline: {base_threads} threads, 3 passes x {n} frames")
+        rate32, cpu_out = full(base_threads)
+        by_threads = {str(base_threads): {"frames_per_s": rate32, "how": "measured: 3 passes, median"}}
+        best_threads, best = base_threads, rate32
+        if ncpu != base_threads:
+            _log(f"cpu baseline: probing {ncpu} threads on 2 of {L} blocks")
+            est = probe(ncpu)
+            if est > rate32:
+                r, _ = full(ncpu)
+                by_threads[str(ncpu)] = {"frames_per_s": r, "how": "measured: 3 passes, median"}
+                if r > best:
+                    best_threads, best = ncpu, r
+            else:
+                by_threads[str(ncpu)] = {"frames_per_s": est, "how": f"extrapolated from a 2-block probe (slower than {base_threads} threads, full passes skipped)"}
+        _log("cpu baseline: probing 1 thread on 2 blocks")
+        one = probe(1)
+        by_threads["1"] = {"frames_per_s": one, "how": "extrapolated from a 2-block probe of one frame"}
+    torch.set_num_threads(base_threads)
     # same kernels as the timed path: tower calls of >= 64 frames fold the LayerNorms into the GEMMs, so encode 64+ and keep n
     gpu_out = model.encode_image(frames.reshape(-1, 3, 224, 224)[:max(n, 64)])[:n].float().cpu()
     cos = torch.nn.functional.cosine_similarity(cpu_out, gpu_out, dim=-1).min().item()
-    return {"value": rates[best], "unit": "frames/s", "cores": best, "kind": "port",
-            "by_threads": {str(t): r for t, r in rates.items()}, "single_thread": 1.0 / one, "host_cpus": ncpu,
+    return {"value": best, "unit": "frames/s", "cores": best_threads, "kind": "port", "by_threads": by_threads,
+            "single_thread": one, "host_cpus": ncpu,
             "sample": f"{n} frames of the same synthetic batch, full 40-layer EVA-CLIP-g/14 fp32 (oracle/ref_cpu.py, torch "
-                      f"CPU): per thread count 1 warm-up frame + 3 timed passes (median); value = the faster of "
-                      f"{sorted(rates)} threads; single_thread = 1 frame, 1 pass; {spent:.1f} s of timed CPU work",
+                      f"CPU), 1 warm-up frame + 3 timed passes (median) at {base_threads} threads; {ncpu} threads and 1 thread "
+                      f"probed on 2 of the 40 blocks (see by_threads); {spent:.1f} s of timed CPU work",
             "min_cosine_gpu_vs_cpu_on_sample": cos}
 
 
@@ -262,7 +294,9 @@ def main():
     # (tests/golden/eva_g14_c3.npz, made by tests/golden/make_golden.py gen_c3) are re-encoded here by the same kernels
     # the timed step ran (one >= 64-frame tower call) and ranked; GT(q) = the reference's top-1.
     if rank == 0 and not args.no_matched_recall:
+        _log("matched R@k leg: synthetic checkpoint of the reference-pinned sub-corpus")
         out["matched_recall"] = matched_recall(model, dev)
+        _log("matched R@k leg done")
 
     # ---- CPU baseline: the fp32 oracle on this host's cores, bounded sample (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

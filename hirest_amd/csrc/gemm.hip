@@ -13,27 +13,13 @@
 // MFMA operands are swapped (a = W fragment, b = A fragment) so each lane ends up owning 4
 // CONSECUTIVE output columns of one output row (D rows = n, D col = m): epilogue loads/stores
 // are 8-B (bf16) / 16-B (f32) vectors and bias is a 16-B load.
-#include "common.h"
-#include "profile.h"
+#include "gemm_shared.h"
 
 namespace {
 
-struct GemmP {
-    const bf16_t* A; int64_t lda;
-    const bf16_t* W; int64_t ldw;
-    const float* bias;
-    void* out; int64_t ldo;
-    int M, N, K;
-    const float* pos; int P;
-    int rev;                  // walk the tile list backwards (HIREST_GEMM_REVERSE)
-    void* aux0; void* aux1;   // LN-fold epilogues (see hirest_hip.h): producer = bf16 copy / row partials, consumer = row stats / column sums
-    int nbm, nbn, ppx;   // tile counts, M-panels per XCD
-    int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
-};
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
-constexpr int GROUP_M = 8;                        // M-panels walked together inside one XCD
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmP& p, int m, int n, f32x4 v) {
@@ -187,11 +173,10 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) {
 //  WAR  slot (s+2)&3 last held slab s-2, whose last reads complete right after G = 4s-5; the first
 //       DMA into it is issued after G = 4s-1.
 // =================================================================================================
-constexpr int T_BM = 256, T_BN = 256, T_BK = 32;
+constexpr int T_BK = 32;
 constexpr int T_SLAB = (T_BM + T_BN) * T_BK * 2;   // 32 KiB
 constexpr int T_WOFF = T_BM * T_BK * 2;            // W rows start here inside a slab
 
-#define HX_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // wait until at most `slabs` whole slabs (4 LDS-DMA pieces each, per wave) are still in flight
 __device__ __forceinline__ void wait_slabs_in_flight(int slabs) {
     if (slabs <= 0) HX_WAIT_VM(0);
@@ -199,7 +184,6 @@ __device__ __forceinline__ void wait_slabs_in_flight(int slabs) {
     else if (slabs == 2) HX_WAIT_VM(8);
     else HX_WAIT_VM(12);
 }
-#define HX_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int EPI, int T_NST>
 __global__ __launch_bounds__(512) void gemm_t256(GemmP p) {
@@ -611,9 +595,6 @@ __global__ __launch_bounds__(512) void gemm_t256p(GemmP p) {
 // exists yet) before barrier(2t+1).  WAR: slot t&1 is last read during iteration 2t (k 32..63 of step t);
 // those reads are complete before barrier(2t+1), the DMA is issued after it.
 // =================================================================================================
-constexpr int Q_BK = 64;
-constexpr int Q_STEP = (T_BM + T_BN) * Q_BK * 2;   // 64 KiB
-constexpr int Q_WOFF = T_BM * Q_BK * 2;
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_t256q(GemmP p) {
@@ -775,252 +756,6 @@ __global__ __launch_bounds__(512) void gemm_t256q(GemmP p) {
 // Comparison that motivated it (rocprofv3 PMC, fc1 shape, same clocks ~1.6 GHz): hipBLASLt's 256x256x64
 // stream-K kernel keeps the matrix pipe 72 % busy, t256q 58 %.
 // =================================================================================================
-constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128 B
-constexpr bool epi_is_lnfold(int epi) { return epi == HIREST_EPI_LNFOLD_BF16 || epi == HIREST_EPI_LNFOLD_GELU_BF16; }
-// the LN-fold consumers keep the (mean, rstd) pairs of the wave's 128 rows behind their staging area
-constexpr int p_stg_bytes(int epi) { return epi_is_lnfold(epi) ? P_STG + 1024 : P_STG; }
-
-// Epilogue of p256: accumulators are 16x16 MFMA tiles, acc[mi][ni][e] = C[mi*16 + (lane&15)][ni*16 + 4*(lane>>4) + e]
-// (operands swapped, so a lane owns 4 consecutive columns of one row).  16 rows at a time go through a wave-private
-// XOR-swizzled staging area so that HBM sees whole 128-B lines.
-// Compiler-only ordering point for a wave-private LDS staging area: the LDS executes one wave's DS instructions in issue
-// order (a ds_read issued after a ds_write of the same bytes returns the new data, a ds_write issued after a ds_read
-// cannot overtake it), so no s_waitcnt is needed between the staging writes and the read-back — a wavefront-scope fence
-// would drain lgkmcnt twice per 16-row pass.
-#define HX_LDS_ORDER() asm volatile("" ::: "memory")
-
-// Epilogue of HIREST_EPI_BIAS_RESID_LNSTATS_F32 (64-column wave tiles): x += acc + bias as in the plain residual form, plus
-//   * the bf16 copy of the new rows (next GEMM's A operand): both 32-column halves of a pass are regrouped with one DPP
-//     exchange per value so that every lane stores 16 B and a row's 64 columns leave as one full 128-B line;
-//   * (sum, sum of squares) of the ROUNDED values per row and 64-column group -> aux1 [M, ceil(N/64), 2]
-//     (hirest_ln_stats_finalize folds the groups into (mean, rstd)).
-// The residual operands of pass mi + 1 are requested before pass mi is processed.
-__device__ __forceinline__ float dpp_xor1(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float sum8(float v) {   // over the 8 lanes lane & ~7 .. | 7: quad xor 1, xor 2, then the mirrored quad
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    return v;
-}
-__device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8][4], char* stg, int Mw, int Nw, int lane) {
-    const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;
-    const int rr = lane >> 3, rc = lane & 7;
-    float* outp = reinterpret_cast<float*>(p.out);
-    bf16_t* xb = reinterpret_cast<bf16_t*>(p.aux0);
-    float* part = reinterpret_cast<float*>(p.aux1);
-    const int G = (p.N + 63) >> 6;
-    f32x4 bv[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int col = Nw + n * 16 + 4 * kg;
-        bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int n0 = Nw + rc * 4, n1 = Nw + 32 + rc * 4;               // this lane's columns in the two 32-column halves
-    auto load_res = [&](int mi, f32x4 (&o)[2][2]) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int m = Mw + mi * 16 + it * 8 + rr;
-            const float* row = outp + (int64_t)(m < p.M ? m : p.M - 1) * p.ldo;
-            o[0][it] = n0 < p.N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            o[1][it] = n1 < p.N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    f32x4 oc[2][2], on[2][2];
-    load_res(0, oc);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        if (mi + 1 < 8) load_res(mi + 1, on);
-        f32x4 wv[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
-                *reinterpret_cast<f32x4*>(stg + srow * 128 + (((nn * 4 + kg) ^ sw) << 4)) = acc[mi][h * 2 + nn] + bv[h * 2 + nn];
-            HX_LDS_ORDER();
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int r = it * 8 + rr;
-                wv[h][it] = *reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4)) + oc[h][it];
-            }
-            HX_LDS_ORDER();
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int m = Mw + mi * 16 + it * 8 + rr;
-            const bool okm = m < p.M, ok0 = okm && n0 < p.N, ok1 = okm && n1 < p.N;
-            if (ok0) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
-            if (ok1) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
-            union { bf16x4 v; float f[2]; } b0, b1, snd, rcv;
-            float ps = 0.f, pq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                b0.v[e] = (bf16_t)wv[0][it][e]; b1.v[e] = (bf16_t)wv[1][it][e];
-                const float f0 = ok0 ? (float)b0.v[e] : 0.f, f1 = ok1 ? (float)b1.v[e] : 0.f;
-                ps += f0 + f1; pq = fmaf(f0, f0, fmaf(f1, f1, pq));
-            }
-            snd.v = (rc & 1) ? b0.v : b1.v;                          // odd lanes hand over their left half, even lanes their right half
-            rcv.f[0] = dpp_xor1(snd.f[0]); rcv.f[1] = dpp_xor1(snd.f[1]);
-            union { bf16x8 v; float f[4]; } w8;
-            int col;
-            if (rc & 1) { w8.f[0] = rcv.f[0]; w8.f[1] = rcv.f[1]; w8.f[2] = b1.f[0]; w8.f[3] = b1.f[1]; col = n1 - 4; }
-            else        { w8.f[0] = b0.f[0]; w8.f[1] = b0.f[1]; w8.f[2] = rcv.f[0]; w8.f[3] = rcv.f[1]; col = n0; }
-            if (okm && col + 8 <= p.N) __builtin_nontemporal_store(w8.v, reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col));
-            ps = sum8(ps); pq = sum8(pq);
-            if (rc == 0 && okm && Nw < p.N) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
-        }
-        if (mi + 1 < 8) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int it = 0; it < 2; ++it) oc[h][it] = on[h][it];
-        }
-    }
-}
-
-// (mean, rstd) of rows Mw + 2*lane and Mw + 2*lane + 1 for the LN-fold consumers (gemm_p256 brings them in by LDS-DMA at
-// the start of a tile instead, so the latency hides behind the K loop)
-__device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane) {
-    const float* st = reinterpret_cast<const float*>(p.aux0);
-    const int r0 = Mw + 2 * lane;
-    const f32x2 v0 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 < p.M ? r0 : p.M - 1));
-    const f32x2 v1 = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r0 + 1 < p.M ? r0 + 1 : p.M - 1));
-    return f32x4{v0[0], v0[1], v1[0], v1[1]};
-}
-
-template <int EPI, int NI, bool PRE = false>   // PRE: the caller has already brought the row statistics into LDS
-__device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
-    if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
-        static_assert(NI == 4, "the statistics producer is written for 64-column wave tiles");
-        epilogue_lnstats(p, acc, stg, Mw, Nw, lane);
-        return;
-    }
-    constexpr bool FOLD = epi_is_lnfold(EPI);
-    constexpr bool OUT_BF16 = (EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_QGELU_BF16 || FOLD);
-    const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;   // sw = srow & 7
-    const int rr = lane >> 3, rc = lane & 7;                     // read-back: row (it*8 + rr), 16-B chunk rc
-    if constexpr (OUT_BF16) {
-        bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-        if constexpr (FOLD) {   // (mean, rstd) of this wave's 128 rows -> LDS behind the staging area (one 16-B load per lane)
-            if constexpr (!PRE) *reinterpret_cast<f32x4*>(stg + P_STG + 16 * lane) = load_row_stats(p, Mw, lane);
-            HX_LDS_ORDER();
-        }
-#pragma unroll
-        for (int jp = 0; jp < NI; jp += 4) {                     // 64-column groups
-            f32x4 bv[4], sv[FOLD ? 4 : 1];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int col = Nw + (jp + n) * 16 + 4 * kg;
-                bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (FOLD)
-                    sv[n] = col < p.N ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux1) + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            f32x2 mr_next = {0.f, 1.f};
-            if constexpr (FOLD) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + srow * 8);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const f32x2 mr = mr_next;                              // (mean, rstd) of row mi*16 + srow, read one pass ahead
-                if constexpr (FOLD) { if (mi + 1 < 8) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + ((mi + 1) * 16 + srow) * 8); }
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    f32x4 v;
-                    if constexpr (FOLD) {   // LayerNorm folded into the GEMM: rstd * x~ W'^T + (b' - rstd * mean * rowsum(W'))
-                        const float c = -mr[0] * mr[1];                // whole-vector forms: two v_pk_fma_f32 each
-                        v = acc[mi][jp + n] * f32x4{mr[1], mr[1], mr[1], mr[1]} + (sv[n] * f32x4{c, c, c, c} + bv[n]);
-                    } else {
-                        v = acc[mi][jp + n] + bv[n];
-                    }
-                    if constexpr (EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_LNFOLD_GELU_BF16) {
-                        const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
-                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
-                    }
-                    if constexpr (EPI == HIREST_EPI_BIAS_QGELU_BF16) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-                    *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((n * 2 + (kg >> 1)) ^ sw) << 4) + (kg & 1) * 8) = o;
-                }
-                HX_LDS_ORDER();
-                const int mb = Mw + mi * 16;
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int r = it * 8 + rr;
-                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
-                    const int m = mb + r, n = Nw + jp * 16 + rc * 8;
-                    if (m < p.M) {
-                        bf16_t* dst = outp + (int64_t)m * p.ldo + n;
-                        if (n + 8 <= p.N) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst));
-                        else if (n + 4 <= p.N) *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
-                    }
-                }
-                HX_LDS_ORDER();
-            }
-        }
-    } else {
-        float* outp = reinterpret_cast<float*>(p.out);
-#pragma unroll
-        for (int jp = 0; jp < NI; jp += 2) {                     // 32-column groups
-            f32x4 bv[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int col = Nw + (jp + n) * 16 + 4 * kg;
-                bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            // the 8 operand loads of each 64x32 block (residual / pos rows) are issued before the first pass: the
-            // residual stream lives in HBM and a load-per-pass schedule left the epilogue latency-bound
-            // (proj: 1.23 ms with the residual read vs 0.92 ms without).
-            const int n = Nw + jp * 16 + rc * 4;
-#pragma unroll
-            for (int mh = 0; mh < 8; mh += 4) {                  // 64 rows per batch
-                f32x4 o[8];
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int m = Mw + mh * 16 + it * 8 + rr;
-                    const bool ok = m < p.M && n < p.N;
-                    if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
-                        const int mm = ok ? m : 0;
-                        const int pp = mm % p.P;
-                        o[it] = ok ? *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(1 + pp) * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    } else if constexpr (EPI == HIREST_EPI_BIAS_RESID_F32) {
-                        o[it] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(outp + (int64_t)m * p.ldo + n)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-#pragma unroll
-                for (int mi = mh; mi < mh + 4; ++mi) {
-#pragma unroll
-                    for (int nn = 0; nn < 2; ++nn) {
-                        const f32x4 v = acc[mi][jp + nn] + bv[nn];
-                        *reinterpret_cast<f32x4*>(stg + srow * 128 + (((nn * 4 + kg) ^ sw) << 4)) = v;
-                    }
-                    HX_LDS_ORDER();
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int r = it * 8 + rr;
-                        f32x4 w = *reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
-                        if constexpr (EPI != HIREST_EPI_BIAS_F32) w += o[(mi - mh) * 2 + it];
-                        const int m = Mw + mi * 16 + r;
-                        if (m < p.M && n < p.N) {
-                            int64_t off;
-                            if constexpr (EPI == HIREST_EPI_PATCH_POS_F32) {
-                                const int b = m / p.P, pp = m - b * p.P;
-                                off = ((int64_t)b * (p.P + 1) + 1 + pp) * p.ldo + n;
-                            } else {
-                                off = (int64_t)m * p.ldo + n;
-                            }
-                            __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(outp + off));
-                        }
-                    }
-                    HX_LDS_ORDER();
-                }
-            }
-        }
-    }
-}
-
 template <int EPI, int WN, bool DBG>
 __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     // timing-experiment switches (hirest_gemm_debug_mode) exist only in the DBG instantiation: a branch inside the K loop
@@ -1549,6 +1284,12 @@ int launch256(GemmP p, hipStream_t s) {
     return hirest_launch_status();
 }
 
+}  // namespace
+int hirest_launch_w4(int epi, const void* gemm_p, hipStream_t s, int flags);   // gemm_w4.hip
+namespace {
+
+int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
+
 // LN-fold epilogues exist in the persistent kernels only
 template <int EPI>
 int launch_fused(const GemmP& p, hipStream_t s) {
@@ -1556,11 +1297,11 @@ int launch_fused(const GemmP& p, hipStream_t s) {
     if (!big || !p.aux0 || !p.aux1) return !big ? HIREST_E_SHAPE : HIREST_E_BADARG;
     if (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
     GemmP q = p; q.dbg = 0;
-    if (p.K >= 4096) return launch_pp256<EPI>(q, s);
+    if (g_force_kernel >= 9) return hirest_launch_w4(EPI, &q, s, g_force_kernel - 9);
+    if (p.K >= 4096 && g_force_kernel != 6) return launch_pp256<EPI>(q, s);
     return launch_p256_impl<EPI, 64, false>(q, s);
 }
 
-int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
 
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
@@ -1569,6 +1310,9 @@ int launch(const GemmP& p, hipStream_t s) {
     if (g_force_kernel == 0 && big && p.K >= 4096) return launch_pp256<EPI>(p, s);
     if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);
     if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
+    if constexpr (EPI != HIREST_EPI_BIAS_QGELU_BF16 && EPI != HIREST_EPI_PATCH_POS_F32) {
+        if (g_force_kernel >= 9 && big) return hirest_launch_w4(EPI, &p, s, g_force_kernel - 9);
+    }
     if (g_force_kernel == 8) return launch_pp256<EPI>(p, s);
     if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4) return launch256p<EPI>(p, s);
@@ -1585,7 +1329,7 @@ int g_gemm_dbg = 0;
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    if (which < 0 || which > 8) return HIREST_E_BADARG;
+    if (which < 0 || which > 15) return HIREST_E_BADARG;   // 10..15: w4 schedule experiments (9 + FLAGS, plain epilogue)
     g_force_kernel = which;
     return 0;
 }

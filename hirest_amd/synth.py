@@ -56,10 +56,20 @@ def uniform_pm1(name: str, n: int, seed: int) -> np.ndarray:
 
 
 def tensor(name: str, shape, std: float, seed: int, mean: float = 0.0) -> torch.Tensor:
-    """fp32 tensor with the given std (uniform distribution of matching variance)."""
+    """fp32 tensor with the given std (uniform distribution of matching variance).  Same values as
+    ``(uniform_pm1(...) * (std * sqrt(3)) + mean).astype(float32)``, produced chunk by chunk straight into the fp32
+    result (a 1 B-parameter checkpoint never exists in float64)."""
     n = int(np.prod(shape)) if len(shape) else 1
-    u = uniform_pm1(name, n, seed)
-    v = (u * (std * math.sqrt(3.0)) + mean).astype(np.float32)
+    base = np.uint64((_fnv1a64(name) ^ ((seed * 0x9E3779B97F4A7C15) & _M64)) & _M64)
+    v = np.empty(n, dtype=np.float32)
+    scale = std * math.sqrt(3.0)
+    step = 1 << 20
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        with np.errstate(over="ignore"):
+            idx = np.arange(s, e, dtype=np.uint64) + base
+        u = (_splitmix64(idx) >> np.uint64(40)).astype(np.float64) * (2.0 / (1 << 24)) - 1.0
+        v[s:e] = u * scale + mean
     return torch.from_numpy(v.reshape(tuple(shape)))
 
 
@@ -206,10 +216,17 @@ def _init_rule(name: str, shape) -> Tuple[float, float]:
 
 
 def state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str, torch.Tensor]:
-    out = {}
-    for name, shape in shapes.items():
+    # tensors are independent pure functions of (name, seed): generate them on a few threads (numpy releases the GIL)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    def make(item):
+        name, shape = item
         std, mean = _init_rule(name, shape)
-        out[name] = tensor(name, shape, std, seed, mean)
+        return name, tensor(name, shape, std, seed, mean)
+    items = list(shapes.items())
+    with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+        out = dict(ex.map(make, items))
     # the decoder's input embedding and its LM-head matrix are ONE tied parameter in the reference
     # (module_decoder.py:171-176,284-285): a checkpoint carries the same values under both names
     tied_a = "clip4cap_model.decoder.embeddings.word_embeddings.weight"

@@ -35,6 +35,7 @@ def test_bench_line_contract():
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert cb["min_cosine_gpu_vs_cpu_on_sample"] > 0.999
     assert cb["single_thread"] > 0 and str(cb["cores"]) in cb["by_threads"] and cb["host_cpus"] >= cb["cores"]
+    assert set(cb["by_threads"]) >= {"1", str(min(32, cb["host_cpus"]))} and all(v["frames_per_s"] > 0 for v in cb["by_threads"].values())
     # matched R@k at EVA-CLIP-g/14 scale against the real reference's rankings (tests/golden/eva_g14_c3.npz)
     mr = d["matched_recall"]
     assert mr["queries"] == 546 and mr["videos"] == 64

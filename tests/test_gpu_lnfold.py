@@ -16,6 +16,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[0, 9], ids=["auto", "w4"])
+def fused_kernel(request):
+    """The LN-fold epilogues exist in the persistent kernels: the default dispatch and the 4-wave kernel (gemm_w4.hip)."""
+    from hirest_amd import ops
+    ops.gemm_select_kernel(request.param)
+    yield request.param
+    ops.gemm_select_kernel(0)
+
+
 def _finalize(part, rows, D, eps, dev):
     from hirest_amd import _lib, ops
     stats = torch.empty((rows, 2), device=dev)
@@ -25,7 +34,7 @@ def _finalize(part, rows, D, eps, dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(2570, 1408, 1408), (2056, 1408, 6144), (1999, 1056, 704)])
-def test_producer_writes_residual_copy_and_row_sums(dev, M, N, K):
+def test_producer_writes_residual_copy_and_row_sums(dev, fused_kernel, M, N, K):
     from hirest_amd import _lib, ops
     g = torch.Generator(device=dev); g.manual_seed(M + N)
     A = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
@@ -33,7 +42,9 @@ def test_producer_writes_residual_copy_and_row_sums(dev, M, N, K):
     bias = torch.randn((N,), device=dev, generator=g)
     x0 = torch.randn((M, N), device=dev, generator=g) * 3 + 0.7
     ref = x0.clone()
+    ops.gemm_select_kernel(0)
     ops.gemm(A, W, bias, ref, _lib.EPI_BIAS_RESID_F32)
+    ops.gemm_select_kernel(fused_kernel)
     out = x0.clone()
     xb = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16)
     G = (N + 63) // 64
@@ -55,7 +66,7 @@ def test_producer_writes_residual_copy_and_row_sums(dev, M, N, K):
 
 @pytest.mark.parametrize("gelu", [False, True])
 @pytest.mark.parametrize("M,N,K", [(2570, 4224, 1408), (2056, 6144, 1408), (1999, 2100, 704), (520, 4608, 4096)])
-def test_consumer_equals_layernorm_then_gemm(dev, M, N, K, gelu):
+def test_consumer_equals_layernorm_then_gemm(dev, fused_kernel, M, N, K, gelu):
     from hirest_amd import _lib, ops
     g = torch.Generator(device=dev); g.manual_seed(M * 3 + N)
     x = torch.randn((M, K), device=dev, generator=g) * 2.5 + 0.4

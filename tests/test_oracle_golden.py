@@ -183,3 +183,36 @@ def test_step_captioning_matches_reference(golden_dir, case):
     assert np.array_equal(O.trim_feats(vis, moment_mask, 20)[:, [0, 7, 19]].numpy(), g["trimmed_rows"])
     hyps, _ = O.step_captioning(sd, vis, text, asr, moment_mask, beams=pred["beams"])
     assert [" ".join(str(i) for i in h) for h in hyps] == pred["prediction"]
+
+
+def test_c3_fixture_and_host_recall(golden_dir):
+    """tests/golden/eva_g14_c3.npz (real reference, EVA-CLIP-g/14, 64 videos x 4 frames x 546 prompts) is self-consistent
+    under the oracle's scoring / ranking restatement, and hirest_amd.retrieval.recall_at_k (index form, used on GPU top-k
+    output) equals the oracle's evaluate.py restatement on it and on the tie-laden retrieval_eval.json scores."""
+    from hirest_amd import retrieval
+    g = load(golden_dir, "eva_g14_c3.npz")
+    V = int(g["V"])
+    names = [f"vid_{(v * 37) % 101:03d}.mp4" for v in range(V)]
+    pooled, scores = torch.from_numpy(g["pooled"]), torch.from_numpy(g["scores"])
+    assert np.abs(pooled.norm(dim=-1).numpy() - 1).max() < 1e-5
+    assert np.abs(O.similarity(torch.from_numpy(g["text_embed32"]), pooled).numpy() - g["scores"][:32]).max() < 2e-6
+    for q in range(0, scores.shape[0], 7):
+        assert [names.index(n) for n in O.rank_videos(scores[q].tolist(), names)[:10]] == g["top10"][q].tolist()
+    top2 = scores.topk(2, dim=1).values
+    assert np.allclose((top2[:, 0] - top2[:, 1]).numpy(), g["margin"], atol=1e-7)
+    # index-form recall == name-form recall, GT = the reference's top-1 / top-3 sets
+    tie = retrieval.tie_rank_from_names(names)
+    idx = O.topk_with_ties(scores, tie, 10)
+    assert np.array_equal(idx.numpy(), g["top10"])
+    gt = [[names[int(i)] for i in row[:1]] for row in g["top10"]]
+    assert retrieval.recall_at_k(idx, names, gt, ks=(1, 5, 10)) == {"R@1": 100.0, "R@5": 100.0, "R@10": 100.0}
+    gt3 = [[names[int(row[2])]] for row in g["top10"]]                       # GT = the rank-3 video: R@1 0, R@5 100
+    assert retrieval.recall_at_k(idx, names, gt3, ks=(1, 5)) == {"R@1": 0.0, "R@5": 100.0}
+    d = json.load(open(os.path.join(golden_dir, "retrieval_eval.json")))
+    nm, prompts = d["names"], d["prompts"]
+    u = synth.uniform_pm1("eval.scores", len(prompts) * len(nm), d["scores_seed"]).reshape(len(prompts), -1)
+    sc = torch.from_numpy(np.round(u * 8).astype(np.float32) / 8.0)
+    top = O.topk_with_ties(sc, retrieval.tie_rank_from_names(nm), 50)
+    got = retrieval.recall_at_k(top, nm, [d["gt"][p] for p in prompts])
+    for k in ("R@1", "R@5", "R@10", "R@50"):
+        assert got[k] == pytest.approx(d["recall"][k])                       # == the real evaluate_video_retrieval
