@@ -13,6 +13,7 @@
 // MFMA operands are swapped (a = W fragment, b = A fragment) so each lane ends up owning 4
 // CONSECUTIVE output columns of one output row (D rows = n, D col = m): epilogue loads/stores
 // are 8-B (bf16) / 16-B (f32) vectors and bias is a 16-B load.
+#include <cstdio>
 #include "gemm_shared.h"
 
 namespace {
@@ -1329,8 +1330,40 @@ int g_gemm_dbg = 0;
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    if (which < 0 || which > 15) return HIREST_E_BADARG;   // 10..15: w4 schedule experiments (9 + FLAGS, plain epilogue)
+    if (which < 0 || which > 17) return HIREST_E_BADARG;   // 10..15: w4 schedule experiments (9 + FLAGS, plain epilogue); 17: w4 schedule H
     g_force_kernel = which;
+    return 0;
+}
+
+// Which kernel instantiation hirest_gemm_bf16 launches for these arguments under the current hirest_gemm_select_kernel /
+// hirest_gemm_debug_mode state, spelled the way rocprofv3 prints kernel names (template arguments included).  Mirrors
+// launch() / launch_fused() above; pure host logic (no launch, usable without a GPU).  Profiles committed under profiles/
+// are checked against it (tests/test_abi_and_host.py), so a profile of kernels the tower no longer runs cannot be quoted.
+extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, int32_t out_len) {
+    if (!a || a->struct_size != sizeof(hirest_gemm_args) || !out || out_len < 48) return HIREST_E_BADARG;
+    const int epi = a->epilogue, f = g_force_kernel;
+    if (epi < 0 || epi > HIREST_EPI_LNFOLD_GELU_BF16) return HIREST_E_BADARG;
+    const bool big = (int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256;
+    const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
+    const bool w4_ok = epi != HIREST_EPI_BIAS_QGELU_BF16 && epi != HIREST_EPI_PATCH_POS_F32;
+    const bool dbg_inst = !fused && (g_gemm_dbg & ~512) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
+    if (fused && !big) return HIREST_E_SHAPE;
+    if (f >= 9 && big && (fused || w4_ok)) {
+        int flags = f - 9;
+        if (flags != 8 && !(flags && epi == HIREST_EPI_BIAS_BF16 && (flags == 1 || flags == 2 || flags == 4 || flags == 6))) flags = 0;
+        snprintf(out, out_len, "gemm_w4<%d, %d>", epi, flags);
+    } else if (fused) {
+        if (a->K >= 4096 && f != 6) snprintf(out, out_len, "gemm_pp256<%d>", epi);
+        else snprintf(out, out_len, "gemm_p256<%d, 64, false>", epi);
+    } else if (f == 0 && big && a->K >= 4096) snprintf(out, out_len, "gemm_pp256<%d>", epi);
+    else if (f == 6 || (f == 0 && big)) snprintf(out, out_len, "gemm_p256<%d, 64, %s>", epi, dbg_inst ? "true" : "false");
+    else if (f == 7) snprintf(out, out_len, "gemm_p256<%d, 128, false>", epi);
+    else if (f == 8) snprintf(out, out_len, "gemm_pp256<%d>", epi);
+    else if (f == 5) snprintf(out, out_len, "gemm_t256q<%d>", epi);
+    else if (f == 4) snprintf(out, out_len, "gemm_t256p<%d>", epi);
+    else if (f == 2) snprintf(out, out_len, "gemm_t256<%d, 4>", epi);
+    else if (f == 3) snprintf(out, out_len, "gemm_t256<%d, 5>", epi);
+    else snprintf(out, out_len, "gemm_t128<%d>", epi);
     return 0;
 }
 

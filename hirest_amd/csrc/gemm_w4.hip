@@ -101,6 +101,20 @@ __global__ __launch_bounds__(256) void gemm_w4(GemmP p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, w_off[q],
                                                      dma_k * (Q_BK * 2), 0, 0);
     };
+    auto stage_a_range = [&](int q0, int q1) {
+        char* buf = smem + (dma_g & 1) * Q_STEP + wave * (PPW * 1024);
+#pragma unroll
+        for (int q = q0; q < q1; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, a_off[q],
+                                                     dma_k * (Q_BK * 2), 0, 0);
+    };
+    auto stage_w_range = [&](int q0, int q1) {
+        char* buf = smem + (dma_g & 1) * Q_STEP + Q_WOFF + wave * (PPW * 1024);
+#pragma unroll
+        for (int q = q0; q < q1; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, w_off[q],
+                                                     dma_k * (Q_BK * 2), 0, 0);
+    };
     auto advance = [&]() {   // wave-uniform; past the last tile the stream refetches its last step (never consumed)
         ++dma_g;
         if (dma_live && ++dma_k == nst) {
@@ -126,6 +140,21 @@ __global__ __launch_bounds__(256) void gemm_w4(GemmP p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const bf16x8*>(buf + a_blk + m * 16 * 128 + foff[h]);
     };
+    auto read_w = [&](const char* buf, int h, bf16x8 (&w)[8]) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) w[n] = *reinterpret_cast<const bf16x8*>(buf + w_blk + n * 16 * 128 + foff[h]);
+    };
+    auto read_a = [&](const char* buf, int h, bf16x8 (&a)[8]) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const bf16x8*>(buf + a_blk + m * 16 * 128 + foff[h]);
+    };
+    // MFMAs i0 .. i1-1 of one 32-deep half-step in (row tile, column tile) order: i -> (i / 8, i % 8)
+    auto mfma_span = [&](f32x4 (&acc)[8][NI], int i0, int i1, bf16x8 (&a)[8], bf16x8 (&w)[8]) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+            acc[i >> 3][i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i & 7], a[i >> 3], acc[i >> 3][i & 7], 0, 0, 0);
+    };
+#define HX_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
     auto mfma_rows = [&](f32x4 (&acc)[8][NI], int m0, int cnt, bf16x8 (&a)[8], bf16x8 (&w)[8]) {   // cnt row tiles x 8 column tiles
 #pragma unroll
         for (int m = m0; m < m0 + cnt; ++m)
@@ -157,8 +186,9 @@ __global__ __launch_bounds__(256) void gemm_w4(GemmP p) {
         tile_origin(slot, m0, n0);
         set_sources(m0, n0);
     }
-    stage_a(); stage_w(); advance();
-    stage_a(); stage_w(); advance();
+    // (W before A, the order every loop below issues a step in: the counted waits of schedule H name pieces by position)
+    stage_w(); stage_a(); advance();
+    stage_w(); stage_a(); advance();
     HX_WAIT_VM(16);                      // step 0 landed (the 16 newest pieces are step 1's)
     __builtin_amdgcn_s_barrier();
 
@@ -187,6 +217,94 @@ __global__ __launch_bounds__(256) void gemm_w4(GemmP p) {
 #pragma unroll
                 for (int jn = 0; jn < NI; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
             read_frags(smem + (g & 1) * Q_STEP, 0, A0, W0);
+            if constexpr (FLAGS & 8) {
+              // Schedule H: every memory instruction alone in the shadow of an MFMA, each operand's ring region released as
+              // soon as its k 32..63 fragments are read, four barriers per step each between two MFMAs:
+              //   k 0..31 :  8 reads W(k 32..63) | lgkm, B1 (W region of slot s free) | 5 DMA W(g+2) + 5 reads A(k 32..63)
+              //              | 3 reads A | lgkm, B2 (A region free) | 3 DMA W + 2 DMA A(g+2)
+              //   k 32..63:  vmcnt(18), B3 (W of step g+1 landed) | 8 reads W'(k 0..31, step g+1) | 5 DMA A
+              //              | vmcnt(15), B4 (A of step g+1 landed) | 8 reads A' | 1 DMA A
+              // vmcnt(18) = 8 A(g+1) + 8 W(g+2) + 2 A(g+2) still in flight allowed; vmcnt(15) = 8 W(g+2) + 7 A(g+2).
+              for (int t = 0; t < nst; ++t, ++g) {
+                const char* cur = smem + (g & 1) * Q_STEP;
+                const char* nxt = smem + ((g + 1) & 1) * Q_STEP;
+                __builtin_amdgcn_sched_barrier(0);
+                // R1: MFMA 0..19 | 8 reads W1
+                read_w(cur, 1, W1);
+                mfma_span(acc, 0, 20, A0, W0);
+                HX_SG(0x008, 1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { HX_SG(0x100, 1); HX_SG(0x008, 2); }
+                HX_SG(0x008, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                HX_WAIT_LGKM0();
+                mfma_span(acc, 20, 21, A0, W0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                                   // B1
+                __builtin_amdgcn_sched_barrier(0);
+                // R2: MFMA 21..49 | 5 DMA W + 8 reads A1
+                // (program order interleaved: an LDS-DMA writes LDS, so the compiler never moves a ds_read across one)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    stage_w_range(i, i + 1);
+                    A1[i] = *reinterpret_cast<const bf16x8*>(cur + a_blk + i * 16 * 128 + foff[1]);
+                }
+#pragma unroll
+                for (int i = 5; i < 8; ++i) A1[i] = *reinterpret_cast<const bf16x8*>(cur + a_blk + i * 16 * 128 + foff[1]);
+                mfma_span(acc, 21, 50, A0, W0);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { HX_SG(0x008, 1); HX_SG(0x020, 1); HX_SG(0x008, 2); HX_SG(0x100, 1); }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { HX_SG(0x008, 2); HX_SG(0x100, 1); }
+                HX_SG(0x008, 8);
+                __builtin_amdgcn_sched_barrier(0);
+                HX_WAIT_LGKM0();
+                mfma_span(acc, 50, 51, A0, W0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                                   // B2
+                __builtin_amdgcn_sched_barrier(0);
+                // R3: MFMA 51..63 | 3 DMA W + 2 DMA A
+                stage_w_range(5, 8);
+                stage_a_range(0, 2);
+                mfma_span(acc, 51, 64, A0, W0);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { HX_SG(0x008, 2); HX_SG(0x020, 1); }
+                HX_SG(0x008, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                // R4: MFMA 64..66 (k 32..63)
+                mfma_span(acc, 0, 3, A1, W1);
+                __builtin_amdgcn_sched_barrier(0);
+                HX_WAIT_VM(18);
+                mfma_span(acc, 3, 4, A1, W1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                                   // B3
+                __builtin_amdgcn_sched_barrier(0);
+                // R5: MFMA 68..103 | 8 reads W0 (step g+1) + 5 DMA A
+                read_w(nxt, 0, W0);
+                stage_a_range(2, 7);
+                mfma_span(acc, 4, 40, A1, W1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { HX_SG(0x008, 2); HX_SG(0x100, 1); }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { HX_SG(0x008, 2); HX_SG(0x020, 1); }
+                HX_SG(0x008, 10);
+                __builtin_amdgcn_sched_barrier(0);
+                HX_WAIT_VM(15);
+                mfma_span(acc, 40, 41, A1, W1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                                   // B4
+                __builtin_amdgcn_sched_barrier(0);
+                // R6: MFMA 105..127 | 8 reads A0 (step g+1) + 1 DMA A
+                read_a(nxt, 0, A0);
+                stage_a_range(7, 8);
+                mfma_span(acc, 41, 64, A1, W1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { HX_SG(0x008, 2); HX_SG(0x100, 1); }
+                HX_SG(0x008, 1); HX_SG(0x020, 1); HX_SG(0x008, 6);
+                __builtin_amdgcn_sched_barrier(0);
+                advance();
+              }
+            } else
             for (int t = 0; t < nst; ++t, ++g) {
                 const char* cur = smem + (g & 1) * Q_STEP;
                 const char* nxt = smem + ((g + 1) & 1) * Q_STEP;
@@ -296,12 +414,18 @@ __global__ __launch_bounds__(256) void gemm_w4(GemmP p) {
             }
             epilogue_p<EPI, NI, epi_is_lnfold(EPI), 4>(p, acc, stg, Mw, Nw, lane);
         } else {
-            // the same barrier / DMA skeleton for a wave whose block lies outside the matrix (M edge)
+            // the same barrier / DMA skeleton for a wave whose block lies outside the matrix (M edge): as many barriers per
+            // step as the active waves of this tile execute (4 in schedule H's 2 x 2 form, 2 otherwise), W pieces after the
+            // barrier that releases the W region, A pieces after the one that releases the A region
+            const bool four = (FLAGS & 8) && !edge;
             for (int t = 0; t < nst; ++t, ++g) {
                 __builtin_amdgcn_s_barrier();
-                if constexpr (!(FLAGS & 1)) { stage_w(); stage_a(); }
+                if constexpr (!(FLAGS & 1)) stage_w();
+                if (four) __builtin_amdgcn_s_barrier();
+                if constexpr (!(FLAGS & 1)) stage_a();
                 HX_WAIT_VM(16);
                 __builtin_amdgcn_s_barrier();
+                if (four) __builtin_amdgcn_s_barrier();
                 advance();
             }
         }
@@ -338,6 +462,18 @@ int hirest_launch_w4(int epi, const void* gemm_p, hipStream_t s, int flags) {
             case 4: return launch_w4_impl<HIREST_EPI_BIAS_BF16, 4>(p, s);
             case 6: return launch_w4_impl<HIREST_EPI_BIAS_BF16, 6>(p, s);
             default: break;
+        }
+    }
+    if (flags == 8) {                                   // schedule H (gemm_w4<EPI, 8>): every tower epilogue
+        switch (epi) {
+            case HIREST_EPI_BIAS_BF16: return launch_w4_impl<HIREST_EPI_BIAS_BF16, 8>(p, s);
+            case HIREST_EPI_BIAS_GELU_BF16: return launch_w4_impl<HIREST_EPI_BIAS_GELU_BF16, 8>(p, s);
+            case HIREST_EPI_BIAS_RESID_F32: return launch_w4_impl<HIREST_EPI_BIAS_RESID_F32, 8>(p, s);
+            case HIREST_EPI_BIAS_F32: return launch_w4_impl<HIREST_EPI_BIAS_F32, 8>(p, s);
+            case HIREST_EPI_BIAS_RESID_LNSTATS_F32: return launch_w4_impl<HIREST_EPI_BIAS_RESID_LNSTATS_F32, 8>(p, s);
+            case HIREST_EPI_LNFOLD_BF16: return launch_w4_impl<HIREST_EPI_LNFOLD_BF16, 8>(p, s);
+            case HIREST_EPI_LNFOLD_GELU_BF16: return launch_w4_impl<HIREST_EPI_LNFOLD_GELU_BF16, 8>(p, s);
+            default: return HIREST_E_BADARG;
         }
     }
     switch (epi) {

@@ -108,6 +108,10 @@ int hirest_gemm_select_kernel(int32_t which);
  * reads.  Any of these selects a separate (slower-scheduled) instantiation.  bit9 (512, results unchanged, normal kernels):
  * ignore HIREST_GEMM_REVERSE.  0 restores normal operation. */
 int hirest_gemm_debug_mode(int32_t bits);
+/* Name of the kernel instantiation hirest_gemm_bf16 would launch for `args` under the current selection state, as rocprofv3
+ * prints it (e.g. "gemm_p256<8, 64, false>", "gemm_pp256<6>").  Host logic only; out_len >= 48.  Lets a committed profile be
+ * checked against what the library dispatches today. */
+int hirest_gemm_dispatch_name(const hirest_gemm_args* args, char* out, int32_t out_len);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the last dim (biased variance, fp32 statistics), fp32 in -> bf16 or f32 out.

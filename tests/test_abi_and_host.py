@@ -141,3 +141,45 @@ def test_moment_model_builds_its_own_clip_like_the_reference(tmp_path, monkeypat
     with pytest.raises(FileNotFoundError):
         hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None)
     assert hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None).clip_model is None
+
+
+def test_profiled_kernels_are_the_dispatched_ones(lib):
+    """a committed profile must describe kernels the library launches TODAY.  Every gemm_* instantiation named in
+    the newest profiles/rNN/pmc_traffic.json and pmc_summary.md (section 1: the bench's kernels) has to be what
+    hirest_gemm_dispatch_name returns for one of the tower's problems under the default selection; and bench.py's roofline
+    looks its traffic figure up in that same directory."""
+    import json
+    from hirest_amd import _lib
+
+    def name(M, N, K, epi):
+        a = _lib.GemmArgs.make(1, K, 1, K, None, 1, N, M, N, K, epi)
+        buf = ctypes.create_string_buffer(64)
+        assert lib.hirest_gemm_dispatch_name(ctypes.byref(a), buf, 64) == 0
+        return buf.value.decode()
+    lib.hirest_gemm_select_kernel(0)
+    lib.hirest_gemm_debug_mode(0)
+    Mv, Mp, Mt = 1024 * 257, 1024 * 256, 546 * 77
+    problems = [(Mv, 4224, 1408, _lib.EPI_LNFOLD_BF16), (Mv, 1408, 1408, _lib.EPI_BIAS_RESID_LNSTATS_F32),
+                (Mv, 6144, 1408, _lib.EPI_LNFOLD_GELU_BF16), (Mv, 1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32),
+                (Mp, 1408, 640, _lib.EPI_PATCH_POS_F32), (1024, 1024, 1408, _lib.EPI_BIAS_F32),
+                # text tower (546 prompts x 77 tokens, width 768): qkv, out_proj, c_fc, c_proj, projection
+                (Mt, 2304, 768, _lib.EPI_BIAS_BF16), (Mt, 768, 768, _lib.EPI_BIAS_RESID_F32), (Mt, 3072, 768, _lib.EPI_BIAS_GELU_BF16),
+                (Mt, 768, 3072, _lib.EPI_BIAS_RESID_F32), (546, 1024, 768, _lib.EPI_BIAS_F32)]
+    dispatched = {name(*p) for p in problems}
+    assert {"gemm_p256<7, 64, false>", "gemm_p256<6, 64, false>", "gemm_p256<8, 64, false>", "gemm_pp256<6>"} <= dispatched
+    rounds = sorted(d for d in os.listdir(os.path.join(REPO, "profiles")) if re.fullmatch(r"r\d\d", d))
+    newest = os.path.join(REPO, "profiles", rounds[-1])
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert f'"{rounds[-1]}"' in src.split("PROFILE_ROUNDS")[1].split("\n")[0]      # bench.py reads the newest round first
+    prof = json.load(open(os.path.join(newest, "pmc_traffic.json")))
+    named = set()
+    for k in prof["kernels"]:
+        named |= set(re.findall(r"gemm_\w+<[^>]*>", k["kernel"]))
+    sec1 = open(os.path.join(newest, "pmc_summary.md")).read().split("## 2.")[0]
+    named |= set(re.findall(r"`(gemm_\w+<[^>`]*>)`", sec1))
+    assert named, "no GEMM kernels found in the newest profile"
+    assert named <= dispatched, f"profiled but no longer dispatched: {sorted(named - dispatched)}"
+    # selection switches change the answer (the entry point mirrors the dispatch, it is not a constant table)
+    lib.hirest_gemm_select_kernel(17)
+    assert name(Mv, 6144, 1408, _lib.EPI_LNFOLD_GELU_BF16) == "gemm_w4<8, 8>"
+    lib.hirest_gemm_select_kernel(0)
