@@ -757,7 +757,7 @@ __global__ __launch_bounds__(512) void gemm_t256q(GemmP p) {
 // Comparison that motivated it (rocprofv3 PMC, fc1 shape, same clocks ~1.6 GHz): hipBLASLt's 256x256x64
 // stream-K kernel keeps the matrix pipe 72 % busy, t256q 58 %.
 // =================================================================================================
-template <int EPI, int WN, bool DBG>
+template <int EPI, int WN, bool DBG, int RD = 1>   // RD: residual look-ahead of the LN-statistics epilogue (gemm_shared.h)
 __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     // timing-experiment switches (hirest_gemm_debug_mode) exist only in the DBG instantiation: a branch inside the K loop
     // splits the scheduling region and destroys the MFMA / ds_read / LDS-DMA interleave
@@ -796,6 +796,11 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     if (panel_major) nunit = (np >> 1) * upp + ((np & 1) ? ncf + (half_edge ? 1 : 0) : 0);
     else { const int rem = np % GROUP_M; nunit = (np / GROUP_M) * ugf + (rem ? rem * ncf + (half_edge ? (rem + 1) / 2 : 0) : 0); }
     if (slot >= nunit) return;
+    if (p.stagger) {   // timing experiment: de-synchronise the CUs so that their HBM-heavy epilogues do not coincide
+        const int who = p.stagger == 1 ? (slot & 3) : p.stagger == 2 ? (xcd & 3) : ((slot + xcd) & 7);
+        const int units = who * (p.stagger == 3 ? (p.K / Q_BK + 15) / 16 : (p.K / Q_BK + 7) / 8);
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // tile `sub` of unit j -> origin; returns the number of tiles in the unit (1 or 2)
     auto unit_tile = [&](int j, int sub, int& M0, int& N0) -> int {
         if (p.rev) j = nunit - 1 - j;                                    // (not combined with the paired-edge experiment)
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 advance();
             }
-            epilogue_p<EPI, NI, epi_is_lnfold(EPI)>(p, acc, stg, M0 + wr * 128, N0 + wc * WN, lane);
+            epilogue_p<EPI, NI, epi_is_lnfold(EPI), 8, RD>(p, acc, stg, M0 + wr * 128, N0 + wc * WN, lane);
         } else {
             for (int t = 0; t < nst; ++t, ++g) {
                 HX_WAIT_VM(0);
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
 //        of either group comes after a barrier at which the other group had already passed that lgkmcnt(0).
 // Registers: one A sub-block (8 fragments) + both W sub-blocks (2 x 4): 64 VGPRs — nothing is prefetched across phases.
 // =================================================================================================
-template <int EPI>
+template <int EPI, int RD = 1>
 __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
     constexpr int NI = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1004,6 +1009,11 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
     const bool panel_major = p.nbn <= 8;
     const int nunit = np * p.nbn;
     if (slot >= nunit) return;
+    if (p.stagger) {   // timing experiment: de-synchronise the CUs so that their HBM-heavy epilogues do not coincide
+        const int who = p.stagger == 1 ? (slot & 3) : p.stagger == 2 ? (xcd & 3) : ((slot + xcd) & 7);
+        const int units = who * (p.stagger == 3 ? (p.K / Q_BK + 15) / 16 : (p.K / Q_BK + 7) / 8);
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     auto tile_origin = [&](int j, int& M0, int& N0) {        // same walk as p256 (see there)
         if (p.rev) j = nunit - 1 - j;
         if (panel_major) {
@@ -1184,7 +1194,7 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
                 mfma_q(1, 0, W0);
                 bar();
             }
-            epilogue_p<EPI, NI>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
+            epilogue_p<EPI, NI, false, 8, RD>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
         } else {
             // the same wait / DMA / barrier skeleton for a wave whose output block lies in the padding of a ragged edge tile
             for (int t = 0; t < nst; ++t, ++g) {
@@ -1207,11 +1217,11 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
     HX_WAIT_VM(0);
 }
 
-template <int EPI>
+template <int EPI, int RD = 1>
 int launch_pp256(GemmP p, hipStream_t s) {
     static HirestDevCfg cfg;
     int cus = 0;
-    auto kern = gemm_pp256<EPI>;
+    auto kern = gemm_pp256<EPI, RD>;
     constexpr int LDS = 2 * Q_STEP + 8 * p_stg_bytes(EPI);
     if (int e = hirest_configure(kern, LDS, cfg, &cus)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
@@ -1223,11 +1233,11 @@ int launch_pp256(GemmP p, hipStream_t s) {
     return hirest_launch_status();
 }
 
-template <int EPI, int WN, bool DBG>
+template <int EPI, int WN, bool DBG, int RD = 1>
 int launch_p256_impl(GemmP p, hipStream_t s) {
     static HirestDevCfg cfg;
     int cus = 0;
-    auto kern = gemm_p256<EPI, WN, DBG>;
+    auto kern = gemm_p256<EPI, WN, DBG, RD>;
     constexpr int NW = 512 / WN;
     constexpr int LDS = 2 * Q_STEP + NW * p_stg_bytes(EPI);
     if (int e = hirest_configure(kern, LDS, cfg, &cus)) return e;
@@ -1286,6 +1296,7 @@ int launch256(GemmP p, hipStream_t s) {
 }
 
 }  // namespace
+int g_gemm_dbg = 0;
 int hirest_launch_w4(int epi, const void* gemm_p, hipStream_t s, int flags);   // gemm_w4.hip
 namespace {
 
@@ -1326,7 +1337,6 @@ int launch(const GemmP& p, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_dbg = 0;
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
@@ -1346,7 +1356,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     const bool big = (int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256;
     const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
     const bool w4_ok = epi != HIREST_EPI_BIAS_QGELU_BF16 && epi != HIREST_EPI_PATCH_POS_F32;
-    const bool dbg_inst = !fused && (g_gemm_dbg & ~512) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
+    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
     if (f >= 9 && big && (fused || w4_ok)) {
         int flags = f - 9;
@@ -1379,7 +1389,8 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.pos = a->pos; p.P = a->patches_per_frame;
     p.aux0 = a->aux0; p.aux1 = a->aux1;
     p.rev = ((a->flags & HIREST_GEMM_REVERSE) && !(g_gemm_dbg & 512)) ? 1 : 0;   // debug bit 9: ignore the direction flags (A/B)
-    p.dbg = g_gemm_dbg & ~512;
+    p.dbg = g_gemm_dbg & ~(512 | 3072);
+    p.stagger = (g_gemm_dbg >> 10) & 3;   // A/B experiment: start the CUs of an XCD 0..3 quarter tiles apart (bits 10-11 = mode)
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
     p.ppx = (p.nbm + 7) / 8;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -16,6 +16,7 @@ struct GemmP {
     int rev;                  // walk the tile list backwards (HIREST_GEMM_REVERSE)
     void* aux0; void* aux1;   // LN-fold epilogues (see hirest_hip.h): producer = bf16 copy / row partials, consumer = row stats / column sums
     int nbm, nbn, ppx;   // tile counts, M-panels per XCD
+    int stagger;         // timing experiment (hirest_gemm_debug_mode bits 10-11): staggered start of the CUs
     int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
 };
 
@@ -60,7 +61,9 @@ __device__ __forceinline__ float sum8(float v) {   // over the 8 lanes lane & ~7
 // `jc` = first 16-column MFMA tile of the 64-column group this call handles (a 128-column wave tile calls it twice), Nw its
 // first column.
 // NM = 16-row tiles of the block that hold results (8; 4 for the 64-row blocks of w4's edge tiles).
-template <int NI, int NM>
+// RD = how many 16-row passes ahead the residual rows (fp32, HBM) are requested: every pass needs 4 x 16 B per lane, the
+// fragment registers of the K loop are dead here, and with one pass of look-ahead the epilogue was bound by the HBM round trip.
+template <int NI, int NM, int RD>
 __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8][NI], int jc, char* stg, int Mw, int Nw, int lane) {
     const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;
     const int rr = lane >> 3, rc = lane & 7;
@@ -84,11 +87,13 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
             o[1][it] = n1 < p.N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    f32x4 oc[2][2], on[2][2];
-    load_res(0, oc);
+    f32x4 ring[RD + 1][2][2];                                        // pass mi lives in ring[mi % (RD + 1)]
+#pragma unroll
+    for (int a = 0; a < RD && a < NM; ++a) load_res(a, ring[a]);
 #pragma unroll
     for (int mi = 0; mi < NM; ++mi) {
-        if (mi + 1 < NM) load_res(mi + 1, on);
+        if (mi + RD < NM) load_res(mi + RD, ring[(mi + RD) % (RD + 1)]);
+        f32x4 (&oc)[2][2] = ring[mi % (RD + 1)];
         f32x4 wv[2][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -127,12 +132,6 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
             ps = sum8(ps); pq = sum8(pq);
             if (rc == 0 && okm && Nw < p.N) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
         }
-        if (mi + 1 < NM) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int it = 0; it < 2; ++it) oc[h][it] = on[h][it];
-        }
     }
 }
 
@@ -146,12 +145,12 @@ __device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane
     return f32x4{v0[0], v0[1], v1[0], v1[1]};
 }
 
-template <int EPI, int NI, bool PRE = false, int NM = 8>   // PRE: the caller has already brought the row statistics into LDS
+template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1>   // PRE: the caller has already brought the row statistics into LDS
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
     if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
 #pragma unroll
         for (int jc = 0; jc < NI; jc += 4)                            // one 64-column group at a time
-            if (Nw + jc * 16 < p.N) epilogue_lnstats<NI, NM>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
+            if (Nw + jc * 16 < p.N) epilogue_lnstats<NI, NM, RD>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
         return;
     }
     constexpr bool FOLD = epi_is_lnfold(EPI);

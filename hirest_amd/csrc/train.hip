@@ -1,0 +1,409 @@
+// Training side of the joint model: the backward pass of MomentModel.train_moment_retrieval
+// (/root/reference/modeling.py:155-270: fusion -> VisualModel -> start / end heads -> masked BCE) for the 63 M trainable
+// parameters, in exact fp32 like the forward kernels of joint.hip.  Matrix products reuse hirest_gemm_f32 on transposed
+// operands (dX = dY W: A = dY, "W" = W^T;  dW = dY^T X: A = dY^T, "W" = X^T, reduction over the zero-padded row count); this
+// file holds what is not a GEMM: transposes, (weighted / selected) column sums for bias, LayerNorm-affine, embedding-table and
+// head-weight gradients, LayerNorm / GELU / tanh backward, the attention forward that keeps its probabilities and its
+// backward, dropout, the fusion's elementwise backward and the loss.  These problems are small (B*T <= a few thousand rows):
+// one wave per row, no tiling heroics.
+#include "common.h"
+
+namespace {
+
+// counter-based keep mask of the dropout sites: a pure function of (seed, element index), so backward regenerates it
+__device__ __forceinline__ float keep_scale(uint32_t seed, uint64_t idx, float p) {
+    if (p <= 0.f) return 1.f;
+    uint64_t z = idx + ((uint64_t)seed << 32) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);      // [0, 1)
+    return u < p ? 0.f : 1.0f / (1.0f - p);
+}
+
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, int64_t ld, int R, int C,
+                                                            float* __restrict__ out, int Rp) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(int64_t)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rp) out[(int64_t)c * Rp + r] = tile[tx][i];
+    }
+}
+
+// out[c] = sum_r w(r) x[r][c],  w(r) = (wt ? wt[r] : 1) * (sel ? sel[r] == sel_value : 1).  grid.x covers columns in
+// blocks of 64, 4 waves split the rows, LDS reduce.
+__global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
+                                                              const int32_t* __restrict__ sel, int sel_value, int R, int C,
+                                                              float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C)
+        for (int r = wave; r < R; r += 4) {
+            float w = wt ? wt[r] : 1.f;
+            if (sel && sel[r] != sel_value) w = 0.f;
+            s = fmaf(w, x[(int64_t)r * ldx + c], s);
+        }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__device__ __forceinline__ float gelu_grad(float x) {      // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+    const float phi = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return 0.5f * erfcf(-x * 0.7071067811865476f) + x * phi;
+}
+
+__global__ void act_kernel(const float* __restrict__ pre, float* __restrict__ y, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pre[i];
+    y[i] = act == 1 ? 0.5f * x * erfcf(-x * 0.7071067811865476f) : act == 2 ? tanhf(x) : x;
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dy, float* __restrict__ dx, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pre[i];
+    float g = 1.f;
+    if (act == 1) g = gelu_grad(x);
+    else if (act == 2) { const float t = tanhf(x); g = 1.f - t * t; }
+    else if (act == 3) g = 1.f - x * x;                      // `pre` holds y = tanh(pre): the forward kernel kept only that
+    dx[i] = dy[i] * g;
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y, int64_t n,
+                               float p, uint32_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (resid ? resid[i] : 0.f) + x[i] * keep_scale(seed, (uint64_t)i, p);
+}
+
+// LayerNorm backward, one wave per row: xhat = (x - mean) rstd (biased variance, eps inside the root), g = dy * gamma,
+// dx = rstd (g - mean(g) - xhat mean(g xhat));  dyxhat = dy * xhat (column sums of it = dgamma; column sums of dy = dbeta)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, float eps, float* __restrict__ dx,
+                                                            float* __restrict__ dyxhat, int R, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* xr = x + (int64_t)row * D;
+    const float* dr = dy + (int64_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = xr[c] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
+        a += g; b = fmaf(g, xh, b);
+    }
+    a = wave_sum(a) / D; b = wave_sum(b) / D;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
+        dx[(int64_t)row * D + c] = rstd * (g - a - xh * b);
+        dyxhat[(int64_t)row * D + c] = dr[c] * xh;
+    }
+}
+
+// ---- attention that keeps its probabilities (training): qkv fp32 [B*T, 3*H*64] (q | k | v, each (head, 64))
+// forward, one wave per (b, h, i): P[b,h,i,:] = softmax_j(fl(fl(q_i.k_j * scale) + add_const)) (module_visual.py:165-171:
+// the reference adds its all-zeros-mask constant -10000 to every score in fp32), ctx_i = sum_j drop(P_ij) v_j
+__global__ __launch_bounds__(64) void attention_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ P,
+                                                                 float* __restrict__ ctx, int B, int T, int H, float scale,
+                                                                 float add_const, float drop_p, uint32_t seed) {
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;                       // (b*H + h)*T + i
+    const int i = row % T, bh = row / T, h = bh % H, b = bh / H;
+    const int D = H * 64;
+    const float* qi = qkv + ((int64_t)(b * T + i) * 3 * D) + h * 64;
+    float* prow = P + row * T;
+    __shared__ float qs[64];
+    qs[lane] = qi[lane];
+    __syncthreads();
+    float mx = -3.0e38f;
+    for (int j = lane; j < T; j += 64) {
+        const float* kj = qkv + ((int64_t)(b * T + j) * 3 * D) + D + h * 64;
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) s = fmaf(qs[d], kj[d], s);
+        s = s * scale + add_const;
+        prow[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) { const float e = __expf(prow[j] - mx); prow[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < T; j += 64) prow[j] *= inv;
+    __syncthreads();                                      // one wave: orders the row's global writes before the re-reads below
+    float acc = 0.f;                                      // lane = output dim d
+    for (int j = 0; j < T; ++j) {
+        const float p = prow[j] * keep_scale(seed, (uint64_t)row * T + j, drop_p);
+        acc = fmaf(p, qkv[((int64_t)(b * T + j) * 3 * D) + 2 * D + h * 64 + lane], acc);
+    }
+    ctx[(int64_t)(b * T + i) * D + h * 64 + lane] = acc;
+}
+
+// backward A, one wave per (b, h, i): dP~_j = dctx_i . v_j, dP_j = dP~_j keep_j, dS_j = P_j (dP_j - sum_j P_j dP_j);
+// writes dS[b,h,i,:] and dq_i = scale sum_j dS_j k_j
+__global__ __launch_bounds__(64) void attention_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                   const float* __restrict__ dctx, float* __restrict__ dS,
+                                                                   float* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                                   float drop_p, uint32_t seed) {
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int i = row % T, bh = row / T, h = bh % H, b = bh / H;
+    const int D = H * 64;
+    __shared__ float dc[64];
+    dc[lane] = dctx[(int64_t)(b * T + i) * D + h * 64 + lane];
+    __syncthreads();
+    const float* prow = P + row * T;
+    float* dsrow = dS + row * T;
+    float delta = 0.f;
+    for (int j = lane; j < T; j += 64) {
+        const float* vj = qkv + ((int64_t)(b * T + j) * 3 * D) + 2 * D + h * 64;
+        float dp = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) dp = fmaf(dc[d], vj[d], dp);
+        dp *= keep_scale(seed, (uint64_t)row * T + j, drop_p);
+        dsrow[j] = dp;
+        delta = fmaf(prow[j], dp, delta);
+    }
+    delta = wave_sum(delta);
+    for (int j = lane; j < T; j += 64) dsrow[j] = prow[j] * (dsrow[j] - delta);
+    __syncthreads();
+    float acc = 0.f;
+    for (int j = 0; j < T; ++j) acc = fmaf(dsrow[j], qkv[((int64_t)(b * T + j) * 3 * D) + D + h * 64 + lane], acc);
+    dqkv[(int64_t)(b * T + i) * 3 * D + h * 64 + lane] = acc * scale;
+}
+
+// backward B, one wave per (b, h, j): dk_j = scale sum_i dS_ij q_i,  dv_j = sum_i drop(P_ij) dctx_i   (lane = dim)
+__global__ __launch_bounds__(64) void attention_train_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                    const float* __restrict__ dctx, const float* __restrict__ dS,
+                                                                    float* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                                    float drop_p, uint32_t seed) {
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int j = row % T, bh = row / T, h = bh % H, b = bh / H;
+    const int D = H * 64;
+    float dk = 0.f, dv = 0.f;
+    for (int i = 0; i < T; ++i) {
+        const int64_t pi = ((int64_t)bh * T + i) * T + j;
+        const float ds = dS[pi];
+        const float p = P[pi] * keep_scale(seed, (uint64_t)pi, drop_p);
+        dk = fmaf(ds, qkv[((int64_t)(b * T + i) * 3 * D) + h * 64 + lane], dk);
+        dv = fmaf(p, dctx[(int64_t)(b * T + i) * D + h * 64 + lane], dv);
+    }
+    dqkv[(int64_t)(b * T + j) * 3 * D + D + h * 64 + lane] = dk * scale;
+    dqkv[(int64_t)(b * T + j) * 3 * D + 2 * D + h * 64 + lane] = dv;
+}
+
+// masked BCE-with-logits of one head against a one-hot target (modeling.py:249-263):
+//   loss += weight * sum_{b,t} mask[b,t] * bce(logit[b,t], t == target[b]) / max(sum mask, 1),  dlogits = d loss / d logit
+__global__ __launch_bounds__(256) void bce_masked_kernel(const float* __restrict__ logits, const int32_t* __restrict__ target,
+                                                         const int32_t* __restrict__ mask, int B, int T, float weight,
+                                                         float* __restrict__ loss, float* __restrict__ dlogits) {
+    __shared__ float red[256];
+    __shared__ float cnt[256];
+    const int n = B * T;
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int b = i / T, t = i - b * T;
+        const float m = (float)mask[i], x = logits[i], y = (t == target[b]) ? 1.f : 0.f;
+        // max(x, 0) - x y + log(1 + exp(-|x|)): torch's stable form
+        const float l = fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)));
+        s = fmaf(m, l, s);
+        c += m;
+    }
+    red[threadIdx.x] = s; cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; cnt[threadIdx.x] += cnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    const float denom = fmaxf(cnt[0], 1.f);
+    if (threadIdx.x == 0) *loss += weight * red[0] / denom;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int b = i / T, t = i - b * T;
+        const float x = logits[i], y = (t == target[b]) ? 1.f : 0.f;
+        dlogits[i] = weight * (float)mask[i] * (1.0f / (1.0f + __expf(-x)) - y) / denom;
+    }
+}
+
+// fusion backward (modeling.py:163 feats = v * tn[:,None]):  dv = dbase * tn[b],  dtn[b] = sum_t dbase[b,t] * v[b,t]
+__global__ __launch_bounds__(256) void joint_base_bwd_kernel(const float* __restrict__ dbase, const float* __restrict__ v,
+                                                             const float* __restrict__ tn, float* __restrict__ dv,
+                                                             float* __restrict__ dtn, int B, int T, int E) {
+    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const float t = tn[(int64_t)b * E + e];
+    float acc = 0.f;
+    for (int tt = 0; tt < T; ++tt) {
+        const int64_t i = ((int64_t)b * T + tt) * E + e;
+        const float d = dbase[i];
+        dv[i] = d * t;
+        acc = fmaf(d, v[i], acc);
+    }
+    dtn[(int64_t)b * E + e] = acc;
+}
+
+// tn = t / |t|  ->  dt = (dtn - tn (tn . dtn)) / |t|     (one wave per row)
+__global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict__ t, const float* __restrict__ dtn,
+                                                        float* __restrict__ dt, int E) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const float* tr = t + (int64_t)b * E;
+    const float* dr = dtn + (int64_t)b * E;
+    float q = 0.f, d = 0.f;
+    for (int e = lane; e < E; e += 64) { q = fmaf(tr[e], tr[e], q); d = fmaf(tr[e], dr[e], d); }
+    q = wave_sum(q); d = wave_sum(d);
+    const float inv = 1.0f / sqrtf(q);
+    for (int e = lane; e < E; e += 64) dt[(int64_t)b * E + e] = (dr[e] - tr[e] * inv * (d * inv)) * inv;
+}
+
+// dfeats[r][c] = sum_h dl[h*rows + r] * w_h[c]   (heads are Linear(D, 1): modeling.py:80-99)
+__global__ void heads_bwd_kernel(const float* __restrict__ dl, int64_t rows, int D, int nheads, const float* __restrict__ w0,
+                                 const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ dfeats) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int64_t r = i / D;
+    const int c = i - r * D;
+    float acc = dl[r] * w0[c];
+    if (nheads > 1) acc = fmaf(dl[rows + r], w1[c], acc);
+    if (nheads > 2) acc = fmaf(dl[2 * rows + r], w2[c], acc);
+    dfeats[i] = acc;
+}
+
+// cross-entropy over frames of masked logits (modeling.py:343-344: logits[mask == 0] = -finfo.max, then F.cross_entropy with
+// mean reduction): one wave per sample.  *loss += weight * (lse - logit[target]) / B;  dlogits = weight (softmax - onehot) / B on
+// the frames of the moment, 0 outside (the in-place fill cuts their gradient).
+__global__ __launch_bounds__(64) void ce_masked_kernel(const float* __restrict__ logits, const int32_t* __restrict__ mask,
+                                                       const int32_t* __restrict__ target, int B, int T, float weight,
+                                                       float* __restrict__ loss, float* __restrict__ dlogits) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const float* lr = logits + (int64_t)b * T;
+    const int32_t* mr = mask + (int64_t)b * T;
+    const float NEG = -3.4028234663852886e38f;
+    float mx = NEG;
+    for (int t = lane; t < T; t += 64) mx = fmaxf(mx, mr[t] ? lr[t] : NEG);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) sum += __expf((mr[t] ? lr[t] : NEG) - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + __logf(sum);
+    const int tg = target[b];
+    for (int t = lane; t < T; t += 64) {
+        const float x = mr[t] ? lr[t] : NEG;
+        const float p = __expf(x - lse);
+        dlogits[(int64_t)b * T + t] = mr[t] ? weight * (p - (t == tg ? 1.f : 0.f)) / B : 0.f;
+    }
+    if (lane == 0) atomicAdd(loss, weight * (lse - (mr[tg] ? lr[tg] : NEG)) / B);
+}
+
+inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+#define S_(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int hirest_transpose_pad_f32(const float* in, int64_t ld_in, int32_t R, int32_t C, float* out, int32_t Rp, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0 || Rp < R) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, S_(stream), in, ld_in, R, C, out, Rp);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const float* row_weight, const int32_t* row_select,
+                                          int32_t select_value, int32_t R, int32_t C, float* out, void* stream) {
+    if (!x || !out || R <= 0 || C <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(weighted_colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, S_(stream), x, ldx, row_weight, row_select,
+                       select_value, R, C, out);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_act_f32(const float* pre, float* y, int64_t n, int32_t act, void* stream) {
+    if (!pre || !y || n <= 0 || act < 0 || act > 2) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(act_kernel, grid1(n), dim3(256), 0, S_(stream), pre, y, n, act);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_act_bwd_f32(const float* pre, const float* dy, float* dx, int64_t n, int32_t act, void* stream) {
+    if (!pre || !dy || !dx || n <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(act_bwd_kernel, grid1(n), dim3(256), 0, S_(stream), pre, dy, dx, n, act);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_dropout_add_f32(const float* x, const float* resid, float* y, int64_t n, float p, uint32_t seed, void* stream) {
+    if (!x || !y || n <= 0 || !(p >= 0.f && p < 1.f)) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(dropout_kernel, grid1(n), dim3(256), 0, S_(stream), x, resid, y, n, p, seed);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dyxhat,
+                                        int32_t R, int32_t D, void* stream) {
+    if (!x || !dy || !gamma || !dx || !dyxhat || R <= 0 || D <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, S_(stream), x, dy, gamma, eps, dx, dyxhat, R, D);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_train_fwd_f32(const float* qkv, float* P, float* ctx, int32_t B, int32_t T, int32_t H, int32_t dh,
+                                              float scale, float add_const, float drop_p, uint32_t seed, void* stream) {
+    if (!qkv || !P || !ctx || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
+    hipLaunchKernelGGL(attention_train_fwd_kernel, dim3((unsigned)((int64_t)B * H * T)), dim3(64), 0, S_(stream), qkv, P, ctx, B, T, H,
+                       scale, add_const, drop_p, seed);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_train_bwd_f32(const float* qkv, const float* P, const float* dctx, float* dS, float* dqkv, int32_t B,
+                                              int32_t T, int32_t H, int32_t dh, float scale, float drop_p, uint32_t seed, void* stream) {
+    if (!qkv || !P || !dctx || !dS || !dqkv || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
+    const dim3 grid((unsigned)((int64_t)B * H * T));
+    hipLaunchKernelGGL(attention_train_bwd_q_kernel, grid, dim3(64), 0, S_(stream), qkv, P, dctx, dS, dqkv, B, T, H, scale, drop_p, seed);
+    hipLaunchKernelGGL(attention_train_bwd_kv_kernel, grid, dim3(64), 0, S_(stream), qkv, P, dctx, dS, dqkv, B, T, H, scale, drop_p, seed);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_bce_masked_f32(const float* logits, const int32_t* target, const int32_t* mask, int32_t B, int32_t T, float weight,
+                                     float* loss_accum, float* dlogits, void* stream) {
+    if (!logits || !target || !mask || !loss_accum || !dlogits || B <= 0 || T <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(bce_masked_kernel, dim3(1), dim3(256), 0, S_(stream), logits, target, mask, B, T, weight, loss_accum, dlogits);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_joint_base_bwd_f32(const float* dbase, const float* v, const float* tn, float* dv, float* dtn, int32_t B, int32_t T,
+                                         int32_t E, void* stream) {
+    if (!dbase || !v || !tn || !dv || !dtn || B <= 0 || T <= 0 || E <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(joint_base_bwd_kernel, dim3((E + 255) / 256, B), dim3(256), 0, S_(stream), dbase, v, tn, dv, dtn, B, T, E);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_l2norm_bwd_f32(const float* t, const float* dtn, float* dt, int32_t B, int32_t E, void* stream) {
+    if (!t || !dtn || !dt || B <= 0 || E <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(64), 0, S_(stream), t, dtn, dt, E);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_heads_bwd_f32(const float* dlogits, int64_t rows, int32_t D, int32_t nheads, const float* w0, const float* w1,
+                                    const float* w2, float* dfeats, void* stream) {
+    if (!dlogits || !w0 || !dfeats || rows <= 0 || D <= 0 || nheads < 1 || nheads > 3) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(heads_bwd_kernel, grid1(rows * D), dim3(256), 0, S_(stream), dlogits, rows, D, nheads, w0, w1, w2, dfeats);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_ce_masked_f32(const float* logits, const int32_t* mask, const int32_t* target, int32_t B, int32_t T, float weight,
+                                    float* loss_accum, float* dlogits, void* stream) {
+    if (!logits || !mask || !target || !loss_accum || !dlogits || B <= 0 || T <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(ce_masked_kernel, dim3(B), dim3(64), 0, S_(stream), logits, mask, target, B, T, weight, loss_accum, dlogits);
+    return hirest_launch_status();
+}

@@ -307,7 +307,20 @@ class MomentModel(nn.Module):
                 raise NotImplementedError
 
     def train_step(self, batch):
-        raise NotImplementedError("hirest_amd.MomentModel is inference-only (training is out of scope, SURVEY 2.1 #9)")
+        """modeling.py:130-140: ``{'loss': tensor}``; ``loss.backward()`` fills ``param.grad`` through the kernels of
+        csrc/train.hip (hirest_amd/train.py).  step_captioning's decoder backward is not implemented."""
+        from . import train
+        task = batch["tasks"][0]
+        dev = self.clip_g_map.weight.device
+        with torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext():
+            if task == "moment_retrieval":
+                return train.train_moment_retrieval(self, batch)
+            elif task == "moment_segmentation":
+                return train.train_moment_segmentation(self, batch)
+            elif task == "step_captioning":
+                raise NotImplementedError("hirest_amd.MomentModel.train_step: step_captioning (caption-decoder backward) is not implemented")
+            else:
+                raise NotImplementedError
 
     @torch.no_grad()
     def forward_moment_retrieval(self, video_feats, text_feat, video_mask=None, moment_mask=None, asr_feats=None):

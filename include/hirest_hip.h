@@ -302,6 +302,53 @@ int hirest_joint_mask_add(const float* base, const int32_t* moment_mask, const i
 /* up to three Linear(D,1) heads: logits[h*rows + r] = <x[r], w_h> + bias3[h] */
 int hirest_linear_heads(const float* x, int64_t rows, int32_t D, int32_t nheads, const float* w0, const float* w1,
                         const float* w2, const float* bias3, float* logits, void* stream);
+/* ------------------------------------------------------------------------------------
+ * Joint model, training side: backward of MomentModel.train_moment_retrieval (modeling.py:155-270) in exact fp32.
+ * Matrix products of the backward pass are hirest_gemm_f32 calls on transposed operands (dX = dY W: A = dY, W-operand = W^T;
+ * dW = dY^T X: A = dY^T, W-operand = X^T over the zero-padded row count); the entries below are everything that is not a GEMM.
+ * ------------------------------------------------------------------------------------ */
+/* out[c][r] = r < R ? in[r][c] : 0 for r < Rp (Rp >= R; pad the reduction dimension of a dW GEMM to a multiple of 16) */
+int hirest_transpose_pad_f32(const float* in, int64_t ld_in, int32_t R, int32_t C, float* out, int32_t Rp, void* stream);
+/* out[c] = sum_r w(r) x[r][c], w(r) = (row_weight ? row_weight[r] : 1) * (row_select ? row_select[r] == select_value : 1):
+ * bias gradients (no weights), LayerNorm gamma / beta gradients, nn.Embedding(2, E) rows (select), Linear(D, 1) head weights and
+ * the Linear(1, E) time embedding (weights) */
+int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const float* row_weight, const int32_t* row_select,
+                               int32_t select_value, int32_t R, int32_t C, float* out, void* stream);
+/* y = act(pre) and dx = dy * act'(pre);  act: 0 identity, 1 gelu (erf form), 2 tanh; backward only: 3 = tanh given its OUTPUT
+ * in `pre` (1 - y^2) */
+int hirest_act_f32(const float* pre, float* y, int64_t n, int32_t act, void* stream);
+int hirest_act_bwd_f32(const float* pre, const float* dy, float* dx, int64_t n, int32_t act, void* stream);
+/* y[i] = (resid ? resid[i] : 0) + x[i] * keep(seed, i) / (1 - p): nn.Dropout with a counter-based mask, fused with the residual
+ * add that follows it in VisualSelfOutput / VisualOutput (p = 0: a plain add; the same call on dy is the backward) */
+int hirest_dropout_add_f32(const float* x, const float* resid, float* y, int64_t n, float p, uint32_t seed, void* stream);
+/* LayerNorm backward (biased variance, eps inside the root: until_module.py:40-53 and nn.LayerNorm alike): dx, and
+ * dyxhat = dy * xhat whose column sums are dgamma (column sums of dy are dbeta) */
+int hirest_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dyxhat,
+                             int32_t R, int32_t D, void* stream);
+/* Self-attention that keeps its probabilities (module_visual.py:150-183 in train mode): qkv f32 [B*T, 3*H*64];
+ * P f32 [B,H,T,T] = softmax(fl(fl(q.k*scale) + add_const)), ctx [B*T, H*64] = dropout(P) v.  Backward: dS workspace [B,H,T,T],
+ * dqkv [B*T, 3*H*64]. */
+int hirest_attention_train_fwd_f32(const float* qkv, float* P, float* ctx, int32_t B, int32_t T, int32_t H, int32_t dh,
+                                   float scale, float add_const, float drop_p, uint32_t seed, void* stream);
+int hirest_attention_train_bwd_f32(const float* qkv, const float* P, const float* dctx, float* dS, float* dqkv, int32_t B,
+                                   int32_t T, int32_t H, int32_t dh, float scale, float drop_p, uint32_t seed, void* stream);
+/* *loss_accum += weight * sum(mask * bce_with_logits(logits, onehot(target))) / max(sum mask, 1); dlogits = its gradient
+ * (modeling.py:249-263) */
+int hirest_bce_masked_f32(const float* logits, const int32_t* target, const int32_t* mask, int32_t B, int32_t T, float weight,
+                          float* loss_accum, float* dlogits, void* stream);
+/* backward of feats = v * tn[:, None, :] (modeling.py:163): dv = dbase * tn, dtn[b] = sum_t dbase * v */
+int hirest_joint_base_bwd_f32(const float* dbase, const float* v, const float* tn, float* dv, float* dtn, int32_t B, int32_t T,
+                              int32_t E, void* stream);
+/* backward of tn = t / |t| (modeling.py:162) */
+int hirest_l2norm_bwd_f32(const float* t, const float* dtn, float* dt, int32_t B, int32_t E, void* stream);
+/* *loss_accum += weight * mean_b CE(softmax over the frames with mask[b,t] != 0, target[b]); dlogits = its gradient, 0 on masked
+ * frames (modeling.py:343-344: logits[moment_mask == 0] = -finfo.max; F.cross_entropy) */
+int hirest_ce_masked_f32(const float* logits, const int32_t* mask, const int32_t* target, int32_t B, int32_t T, float weight,
+                         float* loss_accum, float* dlogits, void* stream);
+/* dfeats[r] = sum_h dlogits[h*rows + r] * w_h   (backward of hirest_linear_heads with respect to its input) */
+int hirest_heads_bwd_f32(const float* dlogits, int64_t rows, int32_t D, int32_t nheads, const float* w0, const float* w1,
+                         const float* w2, float* dfeats, void* stream);
+
 /* out[b] = argmax_t (mask[b,t] ? logits[b,t] : fill), first maximum (modeling.py:294-298) */
 int hirest_masked_argmax(const float* logits, const int32_t* mask, float fill, int32_t B, int32_t T, int32_t* out,
                          void* stream);

@@ -387,6 +387,30 @@ def moment_retrieval(sd: SD, vis, text, asr, vis_mask, moment_mask):
     return torch.stack([s.argmax(1), e.argmax(1)], -1).tolist(), s, e
 
 
+def moment_retrieval_loss(sd: SD, vis, text, asr, vis_mask, moment_mask, start_target, end_target) -> torch.Tensor:
+    """train_moment_retrieval (modeling.py:226-270) with dropout off: mean-over-moment-frames BCE of the start / end logits
+    against one-hot targets, averaged over the two heads.  Plain differentiable torch: autograd on it is the gradient oracle
+    of tests/ (the real reference's gradients are in tests/golden/train_*.npz)."""
+    feats = joint_features(sd, vis, text, asr, vis_mask, moment_mask)
+    s, e = head_logits(sd, feats, "start_predictor"), head_logits(sd, feats, "end_predictor")
+    m = moment_mask.float()
+    out = 0.0
+    for lg, tgt in ((s, start_target), (e, end_target)):
+        onehot = torch.zeros_like(lg).scatter_(1, tgt.unsqueeze(1), 1.0)
+        l = torch.nn.functional.binary_cross_entropy_with_logits(lg, onehot, reduction="none") * m
+        out = out + l.sum() / m.sum().clamp(min=1)
+    return out / 2
+
+
+def moment_segmentation_loss(sd: SD, vis, text, asr, vis_mask, moment_mask, prev_boundary_mask, target) -> torch.Tensor:
+    """train_moment_segmentation (modeling.py:323-351): cross-entropy over frames of the segment logits, frames outside the
+    moment filled with -finfo.max (an in-place fill: those frames get no gradient)."""
+    feats = joint_features(sd, vis, text, asr, vis_mask, moment_mask, prev_boundary_mask)
+    lg = head_logits(sd, feats, "segment_predictor")
+    lg = lg.masked_fill(moment_mask == 0, -torch.finfo(lg.dtype).max)
+    return torch.nn.functional.cross_entropy(lg, target)
+
+
 def segmentation_walk(scores: Sequence[float], max_idx: int, threshold: float):
     """The per-sample threshold walk of modeling.py:399-433.  Returns (left, right) or None when skipped."""
     max_score = scores[max_idx]

@@ -388,6 +388,72 @@ def gen_joint():
     print(out)
 
 
+TRAIN_CASES = {"a": (3, 64), "b": (2, 300)}
+
+
+def train_targets(name, B, T, seed, bounds):
+    """start / end targets inside the moment, a previous-boundary mask and a segmentation target (hirest_dataset.py:409-531 keys)."""
+    u = (synth.uniform_pm1(f"{name}.tgt", 4 * B, seed).reshape(4, B) + 1.0) * 0.5
+    lo, hi = bounds[:, 0].numpy(), bounds[:, 1].numpy()
+    st = (lo + u[0] * (hi - lo)).astype(np.int64)
+    et = np.maximum(st, (lo + u[1] * (hi - lo)).astype(np.int64))
+    seg = (lo + u[2] * (hi - lo)).astype(np.int64)
+    prev = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        prev[b, int(lo[b])] = 1
+    return torch.from_numpy(st), torch.from_numpy(et), torch.from_numpy(seg), prev
+
+
+def gen_train():
+    """MomentModel.train_moment_retrieval (modeling.py:226-270) run for real with autograd: loss value and the
+    gradient of every trainable parameter (norm, first values; small tensors in full).  The model is in eval() mode so that the
+    four dropout sites of VisualModel are the identity (their masks cannot be pinned across frameworks); everything else is the
+    training graph.  The same for train_moment_segmentation (modeling.py:323-351: boundary embedding, segment head, cross-entropy
+    over the moment's frames), stored under "seg."."""
+    model, args = build_reference_moment_model()
+    names = [k for k in model.state_dict().keys() if not k.startswith("clip_model.")]
+    shapes = {k: tuple(model.state_dict()[k].shape) for k in names}
+    model.load_state_dict(synth.joint_state_dict(shapes, 31), strict=False)
+    model.eval()
+    out = {}
+    for case, (B, T) in TRAIN_CASES.items():
+        vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"train.{case}", B, T, 53)
+        st, et, seg, prev = train_targets(f"train.{case}", B, T, 53, bounds)
+        model.clip_model.encode_text = lambda ids, _t=text: _t
+        ids = torch.zeros(B, 77, dtype=torch.long)
+        for p_ in model.parameters():
+            p_.grad = None
+        batch = {"tasks": ["moment_retrieval"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "asr_feats": asr,
+                 "clip_text_ids": ids, "moment_retrieval_start_target": st, "moment_retrieval_end_target": et}
+        res = model.train_step(batch)
+        res["loss"].backward()
+        def collect(prefix, loss_t):
+            grads = {n: p_.grad.detach().double() for n, p_ in model.named_parameters()
+                     if p_.grad is not None and not n.startswith("clip_model.")}
+            gn = sorted(grads)
+            arr = {prefix + "loss": np.float64(loss_t.item()), prefix + "names": np.array(gn),
+                   prefix + "norms": np.array([float(grads[n].norm()) for n in gn]),
+                   prefix + "heads": np.stack([np.pad(grads[n].flatten()[:8].numpy(), (0, max(0, 8 - grads[n].numel()))) for n in gn])}
+            for n in gn:
+                if grads[n].numel() <= 4096:
+                    arr[prefix + "full." + n] = grads[n].float().numpy()
+            return arr, gn
+        arrays, gn = collect("", res["loss"])
+        for p_ in model.parameters():
+            p_.grad = None
+        batch = {"tasks": ["moment_segmentation"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "asr_feats": asr,
+                 "clip_text_ids": ids, "prev_boundary_mask": prev, "moment_segmentation_target": seg}
+        seg_res = model.train_step(batch)
+        seg_res["loss"].backward()
+        seg_arrays, seg_gn = collect("seg.", seg_res["loss"])
+        arrays.update(seg_arrays)
+        arrays["seg_loss"] = arrays["seg.loss"]
+        save(f"train_{case}.npz", **arrays)
+        out[case] = {"loss": float(arrays["loss"]), "seg_loss": float(arrays["seg_loss"]), "n_grads": len(gn)}
+        unused = [n for n, p_ in model.named_parameters() if p_.grad is None and not n.startswith("clip_model.") and p_.requires_grad]
+        print(case, out[case], "params without grad:", len(unused), unused[:6])
+
+
 def gen_caption():
     """test_step_captioning (modeling.py:556-632) of the real MomentModel: trim_feats, fusion + encoder on 20
     frames, beam search over the 2-layer decoder.  The tokenizer stub maps ids to their decimal strings, so the
@@ -645,6 +711,7 @@ def main():
         "c3": lambda: gen_c3(prompts),
         "joint": gen_joint,
         "caption": gen_caption,
+        "train": gen_train,
         "preprocess": gen_preprocess,
         "features": gen_features,
         "moment_eval": gen_moment_eval,

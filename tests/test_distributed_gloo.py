@@ -73,3 +73,37 @@ def test_shard_range_covers_everything():
 def test_gather_rows_without_group_is_identity():
     x = torch.arange(12.0).reshape(4, 3)
     assert torch.equal(retrieval.gather_rows(x, 4), x)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hirest_amd import train
+        lin, other = torch.nn.Linear(5, 3), torch.nn.Linear(2, 2)
+        for p in lin.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))               # rank 0: 1, rank 1: 2 -> mean 1.5
+        other.weight.grad = torch.full_like(other.weight, 4.0) if rank == 0 else None    # a tensor only rank 0 reached
+        params = list(lin.parameters()) + list(other.parameters())
+        train.allreduce_gradients(params, bucket_bytes=32)                # several small buckets
+        ok = all(torch.equal(p.grad, torch.full_like(p, 1.5)) for p in lin.parameters())
+        ok = ok and torch.equal(other.weight.grad, torch.full_like(other.weight, 2.0)) and torch.equal(other.bias.grad, torch.zeros(2))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    """The exchange step of data-parallel training (run.py:93): gradients averaged over ranks in flat buckets."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -1,0 +1,107 @@
+"""SURVEY 8f-4 on the GPU: hirest_amd.MomentModel.train_step (csrc/train.hip + joint.hip through hirest_amd/train.py) against
+the REAL reference's loss and gradients (tests/golden/train_*.npz, made by make_golden.py gen_train with the reference's
+autograd), plus the training-loop contract of run.py:238-295 (loss.backward -> clip_grad_norm_ -> optimizer step)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from hirest_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _setup(golden_dir, case, dev):
+    import hirest_amd
+    sys.path.insert(0, golden_dir)
+    from make_golden import joint_inputs, train_targets, TRAIN_CASES
+    B, T = TRAIN_CASES[case]
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
+    model.load_state_dict(synth.joint_state_dict(shapes, 31), strict=False)
+    model = model.to(dev)
+    vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"train.{case}", B, T, 53)
+    st, et, seg, prev = train_targets(f"train.{case}", B, T, 53, bounds)
+    batch = {"tasks": ["moment_retrieval"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "asr_feats": asr,
+             "text_feat": text, "moment_retrieval_start_target": st, "moment_retrieval_end_target": et}
+    seg_batch = {"tasks": ["moment_segmentation"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "asr_feats": asr,
+                 "text_feat": text, "prev_boundary_mask": prev, "moment_segmentation_target": seg}
+    return model, batch, seg_batch, np.load(os.path.join(golden_dir, f"train_{case}.npz"))
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
+    model, batch, seg_batch, g = _setup(golden_dir, case, dev)
+    model.eval()                                   # dropout off: the arithmetic the goldens pin
+    worst = 0.0
+    for b, prefix in ((batch, ""), (seg_batch, "seg.")):
+        for p in model.parameters():
+            p.grad = None
+        loss = model.train_step(b)["loss"]
+        assert loss.requires_grad and loss.dim() == 0
+        ref = float(g[prefix + "loss"])
+        assert abs(loss.item() - ref) <= 1e-5 * abs(ref), (prefix, loss.item(), ref)
+        loss.backward()
+        names = [str(n) for n in g[prefix + "names"]]
+        with_grad = {n for n, p in model.named_parameters() if p.grad is not None}
+        assert with_grad == set(names)             # the same tensors the reference's backward reaches; the rest stay None
+        named = dict(model.named_parameters())
+        for i, n in enumerate(names):
+            gr = named[n].grad.detach().double().cpu()
+            norm = g[prefix + "norms"][i]
+            assert torch.isfinite(gr).all(), n
+            # (the key-bias gradient is identically zero in exact arithmetic — softmax ignores a constant added to every key — and
+            # ~1e-8 of rounding noise in practice: the 1e-6 floor exempts it from a relative comparison)
+            rel = max(0.0, abs(float(gr.norm()) - norm) - 1e-6) / (norm + 1e-12)
+            worst = max(worst, rel)
+            assert rel <= 1e-3, (prefix, n, rel)
+            k = min(8, gr.numel())
+            assert np.abs(gr.flatten()[:k].numpy() - g[prefix + "heads"][i][:k]).max() <= 1e-3 * norm + 1e-6, (prefix, n)
+            key = prefix + "full." + n
+            if key in g.files:
+                assert np.abs(gr.numpy().reshape(g[key].shape) - g[key]).max() <= 1e-3 * np.abs(g[key]).max() + 1e-6, (prefix, n)
+        print(f"case {case} {prefix or 'retrieval '}loss {loss.item():.7f} (reference {ref:.7f}), {len(names)} gradient tensors")
+    print(f"worst gradient-norm deviation {worst:.2e}")
+    with pytest.raises(NotImplementedError):
+        model.train_step({"tasks": ["step_captioning"]})
+
+
+def test_training_loop_contract_and_dropout(dev, golden_dir):
+    """run.py:238-295: results['loss'].backward(); clip_grad_norm_; optim.step(); grads reset.  Train mode switches the four
+    dropout sites on (counter-based masks): the loss changes from call to call, stays finite, and a few AdamW steps on one batch
+    reduce the eval-mode loss."""
+    model, batch, _, g = _setup(golden_dir, "a", dev)
+    trainable = [p for n, p in model.named_parameters() if p.requires_grad]
+    optim = torch.optim.AdamW(trainable, lr=2e-4)
+    model.eval()
+    first = model.train_step(batch)["loss"].item()
+    model.train()
+    seen = set()
+    for step in range(4):
+        loss = model.train_step(batch)["loss"]
+        assert torch.isfinite(loss)
+        seen.add(round(loss.item(), 6))
+        loss.backward()
+        total = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        assert torch.isfinite(total) and total > 0
+        optim.step()
+        for p in model.parameters():
+            p.grad = None
+    assert len(seen) == 4                          # different dropout masks / updated weights every step
+    model.eval()
+    last = model.train_step(batch)["loss"].item()
+    print(f"eval-mode loss {first:.5f} -> {last:.5f} after 4 AdamW steps")
+    assert last < first
+    # predictions still come out of the updated weights through the inference path
+    out = model.test_step(dict(batch, tasks=["moment_retrieval"]))["prediction"]
+    assert len(out) == batch["vis_feats"].shape[0]

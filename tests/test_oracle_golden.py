@@ -216,3 +216,38 @@ def test_c3_fixture_and_host_recall(golden_dir):
     got = retrieval.recall_at_k(top, nm, [d["gt"][p] for p in prompts])
     for k in ("R@1", "R@5", "R@10", "R@50"):
         assert got[k] == pytest.approx(d["recall"][k])                       # == the real evaluate_video_retrieval
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_training_loss_and_gradients_match_reference(golden_dir, case):
+    """SURVEY 8f-4 oracle: autograd on the restated train_moment_retrieval equals the REAL reference's loss.backward()
+    (tests/golden/train_*.npz: all 56 trainable tensors that receive a gradient), and the segmentation loss value."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden import joint_inputs, train_targets, TRAIN_CASES
+    g = load(golden_dir, f"train_{case}.npz")
+    B, T = TRAIN_CASES[case]
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.joint_state_dict(shapes, 31).items() if v.is_floating_point()}
+    vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"train.{case}", B, T, 53)
+    st, et, seg, prev = train_targets(f"train.{case}", B, T, 53, bounds)
+    def check(loss, prefix):
+        # (hazard H3: the uniform -10000 added to every attention score quantises them to ulp(1e4) ~ 1e-3, so fp32 summation
+        # order moves the loss in the 6th digit; gradients are compared at 5e-4 of their norm)
+        assert abs(loss.item() - float(g[prefix + "loss"])) < 1e-5 * abs(float(g[prefix + "loss"])) + 1e-7
+        for v in sd.values():
+            v.grad = None
+        loss.backward()
+        names = [str(n) for n in g[prefix + "names"]]
+        got = {k for k, v in sd.items() if v.grad is not None and float(v.grad.abs().sum()) > 0}
+        assert set(names) == got                                           # exactly the tensors the reference trains on this task
+        for i, n in enumerate(names):
+            gr = sd[n].grad.double()
+            norm = g[prefix + "norms"][i]
+            assert abs(float(gr.norm()) - norm) <= 5e-4 * norm + 1e-6, n
+            k = min(8, gr.numel())
+            assert np.abs(gr.flatten()[:k].numpy() - g[prefix + "heads"][i][:k]).max() <= 5e-4 * norm + 1e-6, n
+        return names
+    n_ret = check(O.moment_retrieval_loss(sd, vis, text, asr, vis_mask, moment_mask, st, et), "")
+    n_seg = check(O.moment_segmentation_loss(sd, vis, text, asr, vis_mask, moment_mask, prev, seg), "seg.")
+    assert len(n_ret) == 56 and "boundary_embed.weight" in n_seg and "segment_predictor.0.weight" in n_seg and "start_predictor.0.weight" not in n_seg
