@@ -16,6 +16,7 @@ struct GemmP {
     int rev;                  // walk the tile list backwards (HIREST_GEMM_REVERSE)
     void* aux0; void* aux1;   // LN-fold epilogues (see hirest_hip.h): producer = bf16 copy / row partials, consumer = row stats / column sums
     int nbm, nbn, ppx;   // tile counts, M-panels per XCD
+    int epi_dbg;         // timing experiment (hirest_gemm_debug_mode bits 12-15): LN-statistics epilogue without its bit0 residual read, bit1 f32 store, bit2 bf16 copy, bit3 row sums
     int stagger;         // timing experiment (hirest_gemm_debug_mode bits 10-11): staggered start of the CUs
     int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
 };
@@ -83,8 +84,8 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
         for (int it = 0; it < 2; ++it) {
             const int m = Mw + mi * 16 + it * 8 + rr;
             const float* row = outp + (int64_t)(m < p.M ? m : p.M - 1) * p.ldo;
-            o[0][it] = n0 < p.N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            o[1][it] = n1 < p.N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            o[0][it] = (n0 < p.N && !(p.epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            o[1][it] = (n1 < p.N && !(p.epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     f32x4 ring[RD + 1][2][2];                                        // pass mi lives in ring[mi % (RD + 1)]
@@ -112,8 +113,8 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
         for (int it = 0; it < 2; ++it) {
             const int m = Mw + mi * 16 + it * 8 + rr;
             const bool okm = m < p.M, ok0 = okm && n0 < p.N, ok1 = okm && n1 < p.N;
-            if (ok0) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
-            if (ok1) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
+            if (ok0 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
+            if (ok1 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
             union { bf16x4 v; float f[2]; } b0, b1, snd, rcv;
             float ps = 0.f, pq = 0.f;
 #pragma unroll
@@ -128,9 +129,9 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
             int col;
             if (rc & 1) { w8.f[0] = rcv.f[0]; w8.f[1] = rcv.f[1]; w8.f[2] = b1.f[0]; w8.f[3] = b1.f[1]; col = n1 - 4; }
             else        { w8.f[0] = b0.f[0]; w8.f[1] = b0.f[1]; w8.f[2] = rcv.f[0]; w8.f[3] = rcv.f[1]; col = n0; }
-            if (okm && col + 8 <= p.N) __builtin_nontemporal_store(w8.v, reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col));
+            if (okm && col + 8 <= p.N && !(p.epi_dbg & 4)) __builtin_nontemporal_store(w8.v, reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col));
             ps = sum8(ps); pq = sum8(pq);
-            if (rc == 0 && okm && Nw < p.N) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
+            if (rc == 0 && okm && Nw < p.N && !(p.epi_dbg & 8)) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
         }
     }
 }
