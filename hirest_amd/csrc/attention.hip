@@ -336,12 +336,13 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 //              DMA V(h), DMA K(h+1) | S^T + softmax of the first tile | vmcnt(#K pieces) BARRIER B (V(h) landed)
 //              P.V ... remaining tiles
 // =================================================================================================
-template <int DH, int DP, int NT, bool FAST, bool DBG>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
-__global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// NW waves per workgroup: 9 (17 query tiles = 2,2,...,2,1) or 12 (three waves on every SIMD instead of 3/2/2/2: the busiest SIMD
+// still owns 5 tiles, but every SIMD has a third instruction stream to cover softmax VALU and LDS latency with).
+template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
+__global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           int N, int H, float scale_log2e, int causal, int dbg_bits) {
     const int dbg = DBG ? dbg_bits : 0;   // timing-experiment switches fold away in the production instantiation
     using C = AttnCfg2<DH, DP, NT>;
-    constexpr int NW = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Vs = smem + 2 * C::NPAD * C::RS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -518,27 +519,27 @@ __global__ __launch_bounds__(576) void attention_kernel_v3(const bf16_t* __restr
 }
 
 int g_attn_dbg = 0;   // timing experiments only (hirest_attention_debug_mode)
+int g_attn_variant = 3;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame, 9 waves; default for N > 80), 4 = v3 with 12 waves
 
-template <int DH, int DP, int NT, bool FAST, bool DBG>
+template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9>
 int launch3_impl(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
     using C = AttnCfg2<DH, DP, NT>;
     constexpr int LDS = (2 * C::NPAD + C::KP) * C::RS;
     static_assert(LDS <= 163840, "K x2 + V must fit the CU's LDS");
     static HirestDevCfg cfg;
-    auto kern = attention_kernel_v3<DH, DP, NT, FAST, DBG>;
+    auto kern = attention_kernel_v3<DH, DP, NT, FAST, DBG, NW>;
     if (int e = hirest_configure(kern, LDS, cfg)) return e;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(576), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg);
     return hirest_launch_status();
 }
 
 template <int DH, int DP, int NT, bool FAST>
 int launch3(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
     if (g_attn_dbg && FAST) return launch3_impl<DH, DP, NT, FAST, true>(qkv, out, B, N, H, scale, causal, s);
+    if (g_attn_variant == 4) return launch3_impl<DH, DP, NT, FAST, false, 12>(qkv, out, B, N, H, scale, causal, s);
     return launch3_impl<DH, DP, NT, FAST, false>(qkv, out, B, N, H, scale, causal, s);
 }
 
-int g_attn_variant = 3;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame; default for N > 80)
-//   // 1 = v1 (register-staged, transposing stores), 2 = v2 (LDS-DMA + transpose reads)
 
 template <int DH, int DP, int NT>
 int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
@@ -555,7 +556,7 @@ int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, in
 extern "C" int hirest_attention_debug_mode(int32_t bits) { g_attn_dbg = bits; return 0; }
 
 extern "C" int hirest_attention_select_kernel(int32_t which) {
-    if (which < 1 || which > 3) return HIREST_E_BADARG;
+    if (which < 1 || which > 4) return HIREST_E_BADARG;
     g_attn_variant = which;
     return 0;
 }
@@ -567,7 +568,7 @@ extern "C" int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out, i
     const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
     bf16_t* o = reinterpret_cast<bf16_t*>(out);
     HirestProfScope prof(HIREST_PROF_ATTENTION, causal, (int64_t)B * H, N, dh, s);
-    if (g_attn_variant == 3 && N > 80 && N <= 272 && B >= 64) {
+    if (g_attn_variant >= 3 && N > 80 && N <= 272 && B >= 64) {
         const bool fast = !causal && N > 256;
         if (dh == 88) return fast ? launch3<88, 96, 17, true>(q, o, B, N, H, scale, causal, s)
                                   : launch3<88, 96, 17, false>(q, o, B, N, H, scale, causal, s);

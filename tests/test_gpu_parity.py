@@ -195,7 +195,7 @@ def _attention_ref(qkv, B, N, H, dh, causal):
                                                     (1, 257, 8, 88, False, 6.0), (2, 50, 12, 64, False, 1.0),
                                                     (1, 1, 2, 64, True, 1.0), (1, 272, 2, 64, False, 3.0),
                                                     (70, 257, 16, 88, False, 2.0), (66, 200, 4, 64, True, 1.0)])
-@pytest.mark.parametrize("variant", [1, 2, 3], ids=["v1", "v2", "v3"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["v1", "v2", "v3", "v3w12"])
 def test_attention(dev, ops, B, N, H, dh, causal, qscale, variant):
     ops.attention_select_kernel(variant)
     D = H * dh
