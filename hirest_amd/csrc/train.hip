@@ -115,98 +115,145 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// ---- attention that keeps its probabilities (training): qkv fp32 [B*T, 3*H*64] (q | k | v, each (head, 64))
-// forward, one wave per (b, h, i): P[b,h,i,:] = softmax_j(fl(fl(q_i.k_j * scale) + add_const)) (module_visual.py:165-171:
-// the reference adds its all-zeros-mask constant -10000 to every score in fp32), ctx_i = sum_j drop(P_ij) v_j
-__global__ __launch_bounds__(64) void attention_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ P,
-                                                                 float* __restrict__ ctx, int B, int T, int H, float scale,
-                                                                 float add_const, float drop_p, uint32_t seed) {
+// ---- attention that keeps its probabilities (training).  General form: q [B*Tq, ldq], k / v [B*Tk, ldkv] (head h at
+// columns 64 h ..), optional additive mask [B, Tq, Tk] (the decoder's -10000 on future / padded keys, module_decoder.py:394-397)
+// on top of the uniform add_const (the -10000 the all-zeros encoder masks turn into).
+// forward, one wave per (b, h, i): P[b,h,i,:] = softmax_j(fl(fl(q_i.k_j * scale) + m_ij)), ctx_i = sum_j drop(P_ij) v_j
+struct AttnT {
+    const float* q; int64_t ldq;
+    const float* k; const float* v; int64_t ldkv;
+    const float* mask;
+    int B, Tq, Tk, H;
+    float scale, addc, drop;
+    uint32_t seed;
+};
+
+__global__ __launch_bounds__(64) void attention_train_fwd_kernel(AttnT a, float* __restrict__ P, float* __restrict__ ctx, int64_t ldctx) {
     const int lane = threadIdx.x;
-    const int64_t row = blockIdx.x;                       // (b*H + h)*T + i
-    const int i = row % T, bh = row / T, h = bh % H, b = bh / H;
-    const int D = H * 64;
-    const float* qi = qkv + ((int64_t)(b * T + i) * 3 * D) + h * 64;
-    float* prow = P + row * T;
+    const int64_t row = blockIdx.x;                       // (b*H + h)*Tq + i
+    const int i = row % a.Tq, bh = row / a.Tq, h = bh % a.H, b = bh / a.H;
+    const float* qi = a.q + (int64_t)(b * a.Tq + i) * a.ldq + h * 64;
+    const float* mrow = a.mask ? a.mask + (int64_t)(b * a.Tq + i) * a.Tk : nullptr;
+    float* prow = P + row * a.Tk;
     __shared__ float qs[64];
     qs[lane] = qi[lane];
     __syncthreads();
     float mx = -3.0e38f;
-    for (int j = lane; j < T; j += 64) {
-        const float* kj = qkv + ((int64_t)(b * T + j) * 3 * D) + D + h * 64;
+    for (int j = lane; j < a.Tk; j += 64) {
+        const float* kj = a.k + (int64_t)(b * a.Tk + j) * a.ldkv + h * 64;
         float s = 0.f;
 #pragma unroll 8
         for (int d = 0; d < 64; ++d) s = fmaf(qs[d], kj[d], s);
-        s = s * scale + add_const;
+        s = s * a.scale + (a.addc + (mrow ? mrow[j] : 0.f));
         prow[j] = s;
         mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int j = lane; j < T; j += 64) { const float e = __expf(prow[j] - mx); prow[j] = e; sum += e; }
+    for (int j = lane; j < a.Tk; j += 64) { const float e = __expf(prow[j] - mx); prow[j] = e; sum += e; }
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
-    for (int j = lane; j < T; j += 64) prow[j] *= inv;
+    for (int j = lane; j < a.Tk; j += 64) prow[j] *= inv;
     __syncthreads();                                      // one wave: orders the row's global writes before the re-reads below
     float acc = 0.f;                                      // lane = output dim d
-    for (int j = 0; j < T; ++j) {
-        const float p = prow[j] * keep_scale(seed, (uint64_t)row * T + j, drop_p);
-        acc = fmaf(p, qkv[((int64_t)(b * T + j) * 3 * D) + 2 * D + h * 64 + lane], acc);
+    for (int j = 0; j < a.Tk; ++j) {
+        const float p = prow[j] * keep_scale(a.seed, (uint64_t)row * a.Tk + j, a.drop);
+        acc = fmaf(p, a.v[(int64_t)(b * a.Tk + j) * a.ldkv + h * 64 + lane], acc);
     }
-    ctx[(int64_t)(b * T + i) * D + h * 64 + lane] = acc;
+    ctx[(int64_t)(b * a.Tq + i) * ldctx + h * 64 + lane] = acc;
 }
 
 // backward A, one wave per (b, h, i): dP~_j = dctx_i . v_j, dP_j = dP~_j keep_j, dS_j = P_j (dP_j - sum_j P_j dP_j);
 // writes dS[b,h,i,:] and dq_i = scale sum_j dS_j k_j
-__global__ __launch_bounds__(64) void attention_train_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
-                                                                   const float* __restrict__ dctx, float* __restrict__ dS,
-                                                                   float* __restrict__ dqkv, int B, int T, int H, float scale,
-                                                                   float drop_p, uint32_t seed) {
+__global__ __launch_bounds__(64) void attention_train_bwd_q_kernel(AttnT a, const float* __restrict__ P, const float* __restrict__ dctx,
+                                                                   int64_t ldctx, float* __restrict__ dS, float* __restrict__ dq,
+                                                                   int64_t lddq) {
     const int lane = threadIdx.x;
     const int64_t row = blockIdx.x;
-    const int i = row % T, bh = row / T, h = bh % H, b = bh / H;
-    const int D = H * 64;
+    const int i = row % a.Tq, bh = row / a.Tq, h = bh % a.H, b = bh / a.H;
     __shared__ float dc[64];
-    dc[lane] = dctx[(int64_t)(b * T + i) * D + h * 64 + lane];
+    dc[lane] = dctx[(int64_t)(b * a.Tq + i) * ldctx + h * 64 + lane];
     __syncthreads();
-    const float* prow = P + row * T;
-    float* dsrow = dS + row * T;
+    const float* prow = P + row * a.Tk;
+    float* dsrow = dS + row * a.Tk;
     float delta = 0.f;
-    for (int j = lane; j < T; j += 64) {
-        const float* vj = qkv + ((int64_t)(b * T + j) * 3 * D) + 2 * D + h * 64;
+    for (int j = lane; j < a.Tk; j += 64) {
+        const float* vj = a.v + (int64_t)(b * a.Tk + j) * a.ldkv + h * 64;
         float dp = 0.f;
 #pragma unroll 8
         for (int d = 0; d < 64; ++d) dp = fmaf(dc[d], vj[d], dp);
-        dp *= keep_scale(seed, (uint64_t)row * T + j, drop_p);
+        dp *= keep_scale(a.seed, (uint64_t)row * a.Tk + j, a.drop);
         dsrow[j] = dp;
         delta = fmaf(prow[j], dp, delta);
     }
     delta = wave_sum(delta);
-    for (int j = lane; j < T; j += 64) dsrow[j] = prow[j] * (dsrow[j] - delta);
+    for (int j = lane; j < a.Tk; j += 64) dsrow[j] = prow[j] * (dsrow[j] - delta);
     __syncthreads();
     float acc = 0.f;
-    for (int j = 0; j < T; ++j) acc = fmaf(dsrow[j], qkv[((int64_t)(b * T + j) * 3 * D) + D + h * 64 + lane], acc);
-    dqkv[(int64_t)(b * T + i) * 3 * D + h * 64 + lane] = acc * scale;
+    for (int j = 0; j < a.Tk; ++j) acc = fmaf(dsrow[j], a.k[(int64_t)(b * a.Tk + j) * a.ldkv + h * 64 + lane], acc);
+    dq[(int64_t)(b * a.Tq + i) * lddq + h * 64 + lane] = acc * a.scale;
 }
 
 // backward B, one wave per (b, h, j): dk_j = scale sum_i dS_ij q_i,  dv_j = sum_i drop(P_ij) dctx_i   (lane = dim)
-__global__ __launch_bounds__(64) void attention_train_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
-                                                                    const float* __restrict__ dctx, const float* __restrict__ dS,
-                                                                    float* __restrict__ dqkv, int B, int T, int H, float scale,
-                                                                    float drop_p, uint32_t seed) {
+__global__ __launch_bounds__(64) void attention_train_bwd_kv_kernel(AttnT a, const float* __restrict__ P, const float* __restrict__ dctx,
+                                                                    int64_t ldctx, const float* __restrict__ dS, float* __restrict__ dk,
+                                                                    float* __restrict__ dv, int64_t lddkv) {
     const int lane = threadIdx.x;
-    const int64_t row = blockIdx.x;
-    const int j = row % T, bh = row / T, h = bh % H, b = bh / H;
-    const int D = H * 64;
-    float dk = 0.f, dv = 0.f;
-    for (int i = 0; i < T; ++i) {
-        const int64_t pi = ((int64_t)bh * T + i) * T + j;
+    const int64_t row = blockIdx.x;                       // (b*H + h)*Tk + j
+    const int j = row % a.Tk, bh = row / a.Tk, h = bh % a.H, b = bh / a.H;
+    float gk = 0.f, gv = 0.f;
+    for (int i = 0; i < a.Tq; ++i) {
+        const int64_t pi = ((int64_t)bh * a.Tq + i) * a.Tk + j;
         const float ds = dS[pi];
-        const float p = P[pi] * keep_scale(seed, (uint64_t)pi, drop_p);
-        dk = fmaf(ds, qkv[((int64_t)(b * T + i) * 3 * D) + h * 64 + lane], dk);
-        dv = fmaf(p, dctx[(int64_t)(b * T + i) * D + h * 64 + lane], dv);
+        const float p = P[pi] * keep_scale(a.seed, (uint64_t)pi, a.drop);
+        gk = fmaf(ds, a.q[(int64_t)(b * a.Tq + i) * a.ldq + h * 64 + lane], gk);
+        gv = fmaf(p, dctx[(int64_t)(b * a.Tq + i) * ldctx + h * 64 + lane], gv);
     }
-    dqkv[(int64_t)(b * T + j) * 3 * D + D + h * 64 + lane] = dk * scale;
-    dqkv[(int64_t)(b * T + j) * 3 * D + 2 * D + h * 64 + lane] = dv;
+    dk[(int64_t)(b * a.Tk + j) * lddkv + h * 64 + lane] = gk * a.scale;
+    dv[(int64_t)(b * a.Tk + j) * lddkv + h * 64 + lane] = gv;
+}
+
+// x[r] = table[ids[r]] + pos[r % T]   (DecoderEmbeddings, module_decoder.py:309-321) and its scatter-add backward
+__global__ void embedding_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table, const float* __restrict__ pos,
+                                     float* __restrict__ out, int64_t rows, int T, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int64_t r = i / D;
+    const int c = i - r * D;
+    out[i] = table[(int64_t)ids[r] * D + c] + pos[(int64_t)(r % T) * D + c];
+}
+__global__ void embedding_bwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dx, float* __restrict__ dtable,
+                                     int64_t rows, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int64_t r = i / D;
+    const int c = i - r * D;
+    atomicAdd(dtable + (int64_t)ids[r] * D + c, dx[i]);
+}
+
+// CrossEntropyLoss(ignore_index = -1) over vocabulary rows (modeling.py:140, modeling.py:519): one workgroup per row;
+// *loss += weight * (lse - logit[target]) / n_valid, dlogits = weight (softmax - onehot) / n_valid, rows with target < 0: zero
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ target,
+                                                      int V, float weight, float inv_valid, float* __restrict__ loss,
+                                                      float* __restrict__ dlogits) {
+    __shared__ float red[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* lr = logits + (int64_t)r * ld;
+    float* dr = dlogits + (int64_t)r * ld;
+    const int tg = target[r];
+    if (tg < 0) { for (int c = tid; c < V; c += 256) dr[c] = 0.f; return; }
+    float mx = -3.0e38f;
+    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, lr[c]);
+    red[tid] = mx; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0]; __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < V; c += 256) s += __expf(lr[c] - mx);
+    red[tid] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float lse = mx + __logf(red[0]);
+    for (int c = tid; c < V; c += 256) dr[c] = weight * inv_valid * (__expf(lr[c] - lse) - (c == tg ? 1.f : 0.f));
+    if (tid == 0) atomicAdd(loss, weight * inv_valid * (lse - lr[tg]));
 }
 
 // masked BCE-with-logits of one head against a one-hot target (modeling.py:249-263):
@@ -355,22 +402,65 @@ extern "C" int hirest_layernorm_bwd_f32(const float* x, const float* dy, const f
     return hirest_launch_status();
 }
 
+extern "C" int hirest_attention_train_fwd_qkv_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                                  const float* mask_add, float* P, float* ctx, int64_t ldctx, int32_t B, int32_t Tq,
+                                                  int32_t Tk, int32_t H, int32_t dh, float scale, float add_const, float drop_p,
+                                                  uint32_t seed, void* stream) {
+    if (!q || !k || !v || !P || !ctx || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
+    const AttnT a{q, ldq, k, v, ldkv, mask_add, B, Tq, Tk, H, scale, add_const, drop_p, seed};
+    hipLaunchKernelGGL(attention_train_fwd_kernel, dim3((unsigned)((int64_t)B * H * Tq)), dim3(64), 0, S_(stream), a, P, ctx, ldctx);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_train_bwd_qkv_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                                  const float* P, const float* dctx, int64_t ldctx, float* dS, float* dq, int64_t lddq,
+                                                  float* dk, float* dv, int64_t lddkv, int32_t B, int32_t Tq, int32_t Tk, int32_t H,
+                                                  int32_t dh, float scale, float drop_p, uint32_t seed, void* stream) {
+    if (!q || !k || !v || !P || !dctx || !dS || !dq || !dk || !dv || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
+    const AttnT a{q, ldq, k, v, ldkv, nullptr, B, Tq, Tk, H, scale, 0.f, drop_p, seed};
+    hipLaunchKernelGGL(attention_train_bwd_q_kernel, dim3((unsigned)((int64_t)B * H * Tq)), dim3(64), 0, S_(stream), a, P, dctx, ldctx, dS, dq, lddq);
+    hipLaunchKernelGGL(attention_train_bwd_kv_kernel, dim3((unsigned)((int64_t)B * H * Tk)), dim3(64), 0, S_(stream), a, P, dctx, ldctx, dS, dk, dv,
+                       lddkv);
+    return hirest_launch_status();
+}
+
+// packed self-attention forms (q | k | v in one [B*T, 3*H*64] activation)
 extern "C" int hirest_attention_train_fwd_f32(const float* qkv, float* P, float* ctx, int32_t B, int32_t T, int32_t H, int32_t dh,
                                               float scale, float add_const, float drop_p, uint32_t seed, void* stream) {
-    if (!qkv || !P || !ctx || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
-    if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
-    hipLaunchKernelGGL(attention_train_fwd_kernel, dim3((unsigned)((int64_t)B * H * T)), dim3(64), 0, S_(stream), qkv, P, ctx, B, T, H,
-                       scale, add_const, drop_p, seed);
-    return hirest_launch_status();
+    if (!qkv) return HIREST_E_BADARG;
+    const int64_t D = (int64_t)H * 64;
+    return hirest_attention_train_fwd_qkv_f32(qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, nullptr, P, ctx, D, B, T, T, H, dh, scale, add_const,
+                                              drop_p, seed, stream);
 }
 
 extern "C" int hirest_attention_train_bwd_f32(const float* qkv, const float* P, const float* dctx, float* dS, float* dqkv, int32_t B,
                                               int32_t T, int32_t H, int32_t dh, float scale, float drop_p, uint32_t seed, void* stream) {
-    if (!qkv || !P || !dctx || !dS || !dqkv || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
-    if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
-    const dim3 grid((unsigned)((int64_t)B * H * T));
-    hipLaunchKernelGGL(attention_train_bwd_q_kernel, grid, dim3(64), 0, S_(stream), qkv, P, dctx, dS, dqkv, B, T, H, scale, drop_p, seed);
-    hipLaunchKernelGGL(attention_train_bwd_kv_kernel, grid, dim3(64), 0, S_(stream), qkv, P, dctx, dS, dqkv, B, T, H, scale, drop_p, seed);
+    if (!qkv || !dqkv) return HIREST_E_BADARG;
+    const int64_t D = (int64_t)H * 64;
+    return hirest_attention_train_bwd_qkv_f32(qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, P, dctx, D, dS, dqkv, 3 * D, dqkv + D, dqkv + 2 * D,
+                                              3 * D, B, T, T, H, dh, scale, drop_p, seed, stream);
+}
+
+extern "C" int hirest_embedding_fwd_f32(const int32_t* ids, const float* table, const float* pos, float* out, int64_t rows, int32_t T,
+                                        int32_t D, void* stream) {
+    if (!ids || !table || !pos || !out || rows <= 0 || T <= 0 || D <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(embedding_fwd_kernel, grid1(rows * D), dim3(256), 0, S_(stream), ids, table, pos, out, rows, T, D);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_embedding_bwd_f32(const int32_t* ids, const float* dx, float* dtable_accum, int64_t rows, int32_t D, void* stream) {
+    if (!ids || !dx || !dtable_accum || rows <= 0 || D <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(embedding_bwd_kernel, grid1(rows * D), dim3(256), 0, S_(stream), ids, dx, dtable_accum, rows, D);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_ce_rows_f32(const float* logits, int64_t ld, const int32_t* target, int32_t R, int32_t V, float weight,
+                                  int32_t n_valid, float* loss_accum, float* dlogits, void* stream) {
+    if (!logits || !target || !loss_accum || !dlogits || R <= 0 || V <= 0 || ld < V) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(R), dim3(256), 0, S_(stream), logits, ld, target, V, weight, 1.0f / (float)(n_valid > 0 ? n_valid : 1),
+                       loss_accum, dlogits);
     return hirest_launch_status();
 }
 

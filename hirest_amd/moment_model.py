@@ -308,7 +308,7 @@ class MomentModel(nn.Module):
 
     def train_step(self, batch):
         """modeling.py:130-140: ``{'loss': tensor}``; ``loss.backward()`` fills ``param.grad`` through the kernels of
-        csrc/train.hip (hirest_amd/train.py).  step_captioning's decoder backward is not implemented."""
+        csrc/train.hip (hirest_amd/train.py), for all three tasks."""
         from . import train
         task = batch["tasks"][0]
         dev = self.clip_g_map.weight.device
@@ -318,7 +318,7 @@ class MomentModel(nn.Module):
             elif task == "moment_segmentation":
                 return train.train_moment_segmentation(self, batch)
             elif task == "step_captioning":
-                raise NotImplementedError("hirest_amd.MomentModel.train_step: step_captioning (caption-decoder backward) is not implemented")
+                return train.train_step_captioning(self, batch)
             else:
                 raise NotImplementedError
 

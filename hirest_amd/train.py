@@ -10,7 +10,8 @@ forward and backward are sequences of C-ABI kernel calls (csrc/joint.hip forward
 * moment_retrieval: fusion -> VisualModel (2 post-LN layers) -> start / end heads -> masked BCE, full backward.
 * moment_segmentation: the same graph plus the boundary embedding, the segment head and the cross-entropy over the moment's
   frames (modeling.py:310-351), full backward.
-* step_captioning: not implemented (decoder backward), raises.
+* step_captioning: trim_feats -> fusion -> VisualModel on 20 frames -> 2-layer caption decoder (masked self-attention,
+  cross-attention, tied LM head) -> CrossEntropyLoss(ignore_index=-1) over the vocabulary (modeling.py:476-527), full backward.
 
 Dropout (VisualEmbeddings / attention probabilities / VisualSelfOutput / VisualOutput, p = 0.1 in train mode:
 module_visual.py:116-183) uses a counter-based mask; ``model.eval()`` switches it off, which is also how the gradient parity
@@ -117,14 +118,17 @@ def _f32(t):
 
 
 # parameters on a task's graph, in the order the Function receives them / returns gradients for
-def task_param_names(model, task: str) -> List[str]:
+_D = "clip4cap_model.decoder."
+
+
+def encoder_param_names(model, boundary: bool) -> List[str]:
     names = ["clip_g_map.weight", "clip_g_map.bias",
              "clip4cap_model.normalize_video.visual_norm2d.weight", "clip4cap_model.normalize_video.visual_norm2d.bias",
              "clip_g_map_text.weight", "clip_g_map_text.bias"]
     if model.use_asr:
         names += ["asr_enc_layer.0.weight", "asr_enc_layer.0.bias", "asr_enc_layer.1.weight", "asr_enc_layer.1.bias"]
     names += ["temporal_embed.0.weight", "temporal_embed.0.bias", "temporal_embed.2.weight", "temporal_embed.2.bias",
-              "mask_embed.weight"] + (["boundary_embed.weight"] if task == "moment_segmentation" else []) + [
+              "mask_embed.weight"] + (["boundary_embed.weight"] if boundary else []) + [
               _V + "embeddings.word_embeddings.weight", _V + "embeddings.word_embeddings.bias",
               _V + "embeddings.position_embeddings.weight", _V + "embeddings.LayerNorm.weight", _V + "embeddings.LayerNorm.bias"]
     for i in range(len(model.clip4cap_model.visual.encoder.layer)):
@@ -132,11 +136,175 @@ def task_param_names(model, task: str) -> List[str]:
         for leaf in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense",
                      "attention.output.LayerNorm", "intermediate.dense", "output.dense", "output.LayerNorm"):
             names += [p + leaf + ".weight", p + leaf + ".bias"]
+    return names
+
+
+def task_param_names(model, task: str) -> List[str]:
+    names = encoder_param_names(model, task == "moment_segmentation")
     if task == "moment_segmentation":
         names += ["segment_predictor.0.weight", "segment_predictor.0.bias"]
-    else:
+    elif task == "moment_retrieval":
         names += ["start_predictor.0.weight", "start_predictor.0.bias", "end_predictor.0.weight", "end_predictor.0.bias"]
+    else:   # step_captioning: the caption decoder (its input embedding is tied to the LM head: one parameter)
+        names += [_D + "embeddings.word_embeddings.weight", _D + "embeddings.position_embeddings.weight",
+                  _D + "embeddings.LayerNorm.weight", _D + "embeddings.LayerNorm.bias"]
+        for i in range(len(model.clip4cap_model.decoder.decoder.layer)):
+            p = _D + f"decoder.layer.{i}."
+            for att in ("slf_attn", "enc_attn"):
+                for leaf in ("att.query", "att.key", "att.value", "output.dense", "output.LayerNorm"):
+                    names += [p + f"{att}.{leaf}.weight", p + f"{att}.{leaf}.bias"]
+            for leaf in ("intermediate.dense", "output.dense", "output.LayerNorm"):
+                names += [p + leaf + ".weight", p + leaf + ".bias"]
+        cp = _D + "classifier.cls.predictions."
+        names += [cp + "transform.dense.weight", cp + "transform.dense.bias", cp + "transform.LayerNorm.weight",
+                  cp + "transform.LayerNorm.bias", cp + "bias"]
     return names
+
+
+def _encoder_forward(model, P, inp, S):
+    """Fusion + VisualModel (modeling.py:155-210) keeping what the backward needs in S.  Returns feats [B*T, 768]."""
+    lib = _lib.load()
+    vis, text, asr = inp["vis"], inp["text"], inp.get("asr")
+    vmask, mmask = inp["vis_mask"], inp["moment_mask"]
+    B, T, _ = vis.shape
+    R, E, Hd = B * T, 512, 768
+    heads = model.heads
+    drop, seed = S["drop"], S["seed"]
+    boundary = inp.get("boundary_mask") is not None
+    vis2 = vis.reshape(R, -1).float().contiguous()
+    v0 = _K.gemm(vis2, P["clip_g_map.weight"], P["clip_g_map.bias"])
+    gnv, bnv = P["clip4cap_model.normalize_video.visual_norm2d.weight"], P["clip4cap_model.normalize_video.visual_norm2d.bias"]
+    v = _K.layernorm(v0, gnv, bnv, 1e-12)
+    t = _K.gemm(text.float().contiguous(), P["clip_g_map_text.weight"], P["clip_g_map_text.bias"])
+    tn = ops.pool_l2norm(t.unsqueeze(1).contiguous())
+    if model.use_asr:
+        asr2 = asr.reshape(R, -1).float().contiguous()
+        a0 = _K.layernorm(asr2, P["asr_enc_layer.0.weight"], P["asr_enc_layer.0.bias"], 1e-5)
+        a = _K.gemm(a0, P["asr_enc_layer.1.weight"], P["asr_enc_layer.1.bias"])
+        S.update(asr2=asr2, a0=a0)
+    else:
+        a = torch.zeros((R, E), dtype=torch.float32, device=vis.device)
+    n_valid = vmask.sum(dim=-1).to(torch.int32).contiguous()
+    tin = torch.empty((R, E), dtype=torch.float32, device=vis.device)
+    _chk(lib.hirest_joint_time_features(n_valid.data_ptr(), P["temporal_embed.0.weight"].data_ptr(), P["temporal_embed.0.bias"].data_ptr(),
+                                        tin.data_ptr(), B, T, E, ops.stream_ptr()), "time_features")
+    temporal = _K.gemm(tin, P["temporal_embed.2.weight"], P["temporal_embed.2.bias"])
+    base = torch.empty((R, E), dtype=torch.float32, device=vis.device)
+    _chk(lib.hirest_joint_base(v.data_ptr(), t.data_ptr(), a.data_ptr(), temporal.data_ptr(), base.data_ptr(), B, T, E, ops.stream_ptr()),
+         "joint_base")
+    mm32 = mmask.to(torch.int32).contiguous()
+    bm32 = inp["boundary_mask"].to(torch.int32).contiguous() if boundary else None
+    bemb = P["boundary_embed.weight"] if boundary else _f32(model.boundary_embed.weight)
+    f = torch.empty_like(base)
+    _chk(lib.hirest_joint_mask_add(base.data_ptr(), mm32.data_ptr(), bm32.data_ptr() if boundary else None, P["mask_embed.weight"].data_ptr(),
+                                   bemb.data_ptr(), f.data_ptr(), R, E, ops.stream_ptr()), "mask_add")
+    x0 = _K.gemm(f, P[_V + "embeddings.word_embeddings.weight"], P[_V + "embeddings.word_embeddings.bias"],
+                 periodic=P[_V + "embeddings.position_embeddings.weight"], period=T)
+    xe = _K.layernorm(x0, P[_V + "embeddings.LayerNorm.weight"], P[_V + "embeddings.LayerNorm.bias"], 1e-12)
+    x = _K.dropout_add(xe, None, drop, seed + 1)
+    S.update(B=B, T=T, vis2=vis2, v0=v0, v=v, t=t, tn=tn, tin=tin, f=f, x0=x0, mm32=mm32, bm32=bm32, n_valid=n_valid,
+             text=text.float().contiguous(), boundary=boundary)
+    layers = []
+    for i in range(len(model.clip4cap_model.visual.encoder.layer)):
+        p = _V + f"encoder.layer.{i}."
+        wqkv = torch.cat([P[p + "attention.self.query.weight"], P[p + "attention.self.key.weight"], P[p + "attention.self.value.weight"]], 0).contiguous()
+        bqkv = torch.cat([P[p + "attention.self.query.bias"], P[p + "attention.self.key.bias"], P[p + "attention.self.value.bias"]], 0).contiguous()
+        qkv = _K.gemm(x, wqkv, bqkv)
+        Pm = torch.empty((B, heads, T, T), dtype=torch.float32, device=vis.device)
+        cx = torch.empty((R, Hd), dtype=torch.float32, device=vis.device)
+        _chk(lib.hirest_attention_train_fwd_f32(qkv.data_ptr(), Pm.data_ptr(), cx.data_ptr(), B, T, heads, Hd // heads,
+                                                (Hd // heads) ** -0.5, -10000.0, drop, (seed + 10 + 4 * i) & 0xFFFFFFFF, ops.stream_ptr()),
+             "attention_train_fwd")
+        o = _K.gemm(cx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"])
+        a_pre = _K.dropout_add(o, x, drop, seed + 11 + 4 * i)
+        aa = _K.layernorm(a_pre, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], 1e-12)
+        hpre = _K.gemm(aa, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
+        hh = _K.act(hpre, 1)
+        y = _K.gemm(hh, P[p + "output.dense.weight"], P[p + "output.dense.bias"])
+        x_pre = _K.dropout_add(y, aa, drop, seed + 12 + 4 * i)
+        xn = _K.layernorm(x_pre, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], 1e-12)
+        layers.append(dict(x=x, wqkv=wqkv, qkv=qkv, Pm=Pm, cx=cx, a_pre=a_pre, aa=aa, hpre=hpre, hh=hh, x_pre=x_pre))
+        x = xn
+    S["layers"] = layers
+    return x
+
+
+def _encoder_backward(model, P, S, dx, G):
+    """Backward of _encoder_forward: dx = d loss / d feats [B*T, 768]; parameter gradients go into G."""
+    lib = _lib.load()
+    B, T, drop, seed = S["B"], S["T"], S["drop"], S["seed"]
+    R, E, Hd = B * T, 512, 768
+    heads = model.heads
+    dev = dx.device
+    mm32 = S["mm32"]
+    for i in reversed(range(len(S["layers"]))):
+        p = _V + f"encoder.layer.{i}."
+        Ly = S["layers"][i]
+        dxp, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = _K.layernorm_bwd(Ly["x_pre"], dx, P[p + "output.LayerNorm.weight"], 1e-12)
+        dy = _K.dropout_add(dxp, None, drop, seed + 12 + 4 * i)           # through dropout(y); the residual branch gets dxp as is
+        G[p + "output.dense.weight"] = _K.grad_weight(dy, Ly["hh"])
+        G[p + "output.dense.bias"] = _K.colsum(dy)
+        dh = _K.grad_input(dy, P[p + "output.dense.weight"])
+        dhp = _K.act_bwd(Ly["hpre"], dh, 1)
+        G[p + "intermediate.dense.weight"] = _K.grad_weight(dhp, Ly["aa"])
+        G[p + "intermediate.dense.bias"] = _K.colsum(dhp)
+        da = _K.dropout_add(_K.grad_input(dhp, P[p + "intermediate.dense.weight"]), dxp, 0.0, 0)      # + residual path
+        dap, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
+            _K.layernorm_bwd(Ly["a_pre"], da, P[p + "attention.output.LayerNorm.weight"], 1e-12)
+        do = _K.dropout_add(dap, None, drop, seed + 11 + 4 * i)
+        G[p + "attention.output.dense.weight"] = _K.grad_weight(do, Ly["cx"])
+        G[p + "attention.output.dense.bias"] = _K.colsum(do)
+        dcx = _K.grad_input(do, P[p + "attention.output.dense.weight"])
+        dS = torch.empty_like(Ly["Pm"])
+        dqkv = torch.empty_like(Ly["qkv"])
+        _chk(lib.hirest_attention_train_bwd_f32(Ly["qkv"].data_ptr(), Ly["Pm"].data_ptr(), dcx.data_ptr(), dS.data_ptr(), dqkv.data_ptr(),
+                                                B, T, heads, Hd // heads, (Hd // heads) ** -0.5, drop, (seed + 10 + 4 * i) & 0xFFFFFFFF,
+                                                ops.stream_ptr()), "attention_train_bwd")
+        dwqkv = _K.grad_weight(dqkv, Ly["x"])
+        dbqkv = _K.colsum(dqkv)
+        for k, nm in enumerate(("query", "key", "value")):
+            G[p + f"attention.self.{nm}.weight"] = dwqkv[k * Hd:(k + 1) * Hd]
+            G[p + f"attention.self.{nm}.bias"] = dbqkv[k * Hd:(k + 1) * Hd]
+        dx = _K.dropout_add(_K.grad_input(dqkv, Ly["wqkv"]), dap, 0.0, 0)                               # + residual path
+    # ---- embeddings
+    dxe = _K.dropout_add(dx, None, drop, seed + 1)
+    dx0, G[_V + "embeddings.LayerNorm.weight"], G[_V + "embeddings.LayerNorm.bias"] = \
+        _K.layernorm_bwd(S["x0"], dxe, P[_V + "embeddings.LayerNorm.weight"], 1e-12)
+    pos = P[_V + "embeddings.position_embeddings.weight"]
+    dpos = torch.zeros_like(pos)
+    dpos[:T] = _K.colsum(dx0.reshape(B, T * Hd)).reshape(T, Hd)
+    G[_V + "embeddings.position_embeddings.weight"] = dpos
+    G[_V + "embeddings.word_embeddings.weight"] = _K.grad_weight(dx0, S["f"])
+    G[_V + "embeddings.word_embeddings.bias"] = _K.colsum(dx0)
+    df = _K.grad_input(dx0, P[_V + "embeddings.word_embeddings.weight"])
+    # ---- fusion
+    G["mask_embed.weight"] = torch.stack([_K.colsum(df, select=mm32.reshape(-1), value=k) for k in (0, 1)])
+    if S["boundary"]:
+        G["boundary_embed.weight"] = torch.stack([_K.colsum(df, select=S["bm32"].reshape(-1), value=k) for k in (0, 1)])
+    dv = torch.empty_like(df)
+    dtn = torch.empty((B, E), dtype=torch.float32, device=dev)
+    _chk(lib.hirest_joint_base_bwd_f32(df.data_ptr(), S["v"].data_ptr(), S["tn"].data_ptr(), dv.data_ptr(), dtn.data_ptr(), B, T, E,
+                                       ops.stream_ptr()), "joint_base_bwd")
+    # temporal embedding: Linear(1, E) -> tanh -> Linear(E, E) over the normalised time grid
+    G["temporal_embed.2.weight"] = _K.grad_weight(df, S["tin"])
+    G["temporal_embed.2.bias"] = _K.colsum(df)
+    dpre = _K.act_bwd(S["tin"], _K.grad_input(df, P["temporal_embed.2.weight"]), 3)
+    time = time_grid(S["n_valid"], T).reshape(R).contiguous()
+    G["temporal_embed.0.weight"] = _K.colsum(dpre, weight=time).reshape(E, 1)
+    G["temporal_embed.0.bias"] = _K.colsum(dpre)
+    if model.use_asr:
+        G["asr_enc_layer.1.weight"] = _K.grad_weight(df, S["a0"])
+        G["asr_enc_layer.1.bias"] = _K.colsum(df)
+        da0 = _K.grad_input(df, P["asr_enc_layer.1.weight"])
+        _, G["asr_enc_layer.0.weight"], G["asr_enc_layer.0.bias"] = _K.layernorm_bwd(S["asr2"], da0, P["asr_enc_layer.0.weight"], 1e-5)
+    dv0, G["clip4cap_model.normalize_video.visual_norm2d.weight"], G["clip4cap_model.normalize_video.visual_norm2d.bias"] = \
+        _K.layernorm_bwd(S["v0"], dv, P["clip4cap_model.normalize_video.visual_norm2d.weight"], 1e-12)
+    G["clip_g_map.weight"] = _K.grad_weight(dv0, S["vis2"])
+    G["clip_g_map.bias"] = _K.colsum(dv0)
+    dt = torch.empty_like(dtn)
+    _chk(lib.hirest_l2norm_bwd_f32(S["t"].data_ptr(), dtn.data_ptr(), dt.data_ptr(), B, E, ops.stream_ptr()), "l2norm_bwd")
+    G["clip_g_map_text.weight"] = _K.grad_weight(dt, S["text"])
+    G["clip_g_map_text.bias"] = _K.colsum(dt)
 
 
 class MomentLoss(torch.autograd.Function):
@@ -147,79 +315,17 @@ class MomentLoss(torch.autograd.Function):
     def forward(ctx, model, inp: Dict[str, torch.Tensor], names: List[str], *params):
         lib = _lib.load()
         P = {n: _f32(p) for n, p in zip(names, params)}
-        vis, text, asr = inp["vis"], inp["text"], inp.get("asr")
-        vmask, mmask = inp["vis_mask"], inp["moment_mask"]
-        B, T, _ = vis.shape
-        R, E, Hd = B * T, 512, 768
-        heads = model.heads
-        drop = float(inp.get("dropout", 0.0))
-        seed = int(inp.get("seed", 0))
         seg = inp["task"] == "moment_segmentation"
-        S = {"B": B, "T": T, "drop": drop, "seed": seed, "seg": seg}
-        vis2 = vis.reshape(R, -1).float().contiguous()
-        # ---- fusion (modeling.py:158-199)
-        v0 = _K.gemm(vis2, P["clip_g_map.weight"], P["clip_g_map.bias"])
-        gnv, bnv = P["clip4cap_model.normalize_video.visual_norm2d.weight"], P["clip4cap_model.normalize_video.visual_norm2d.bias"]
-        v = _K.layernorm(v0, gnv, bnv, 1e-12)
-        t = _K.gemm(text.float().contiguous(), P["clip_g_map_text.weight"], P["clip_g_map_text.bias"])
-        tn = ops.pool_l2norm(t.unsqueeze(1).contiguous())
-        if model.use_asr:
-            asr2 = asr.reshape(R, -1).float().contiguous()
-            a0 = _K.layernorm(asr2, P["asr_enc_layer.0.weight"], P["asr_enc_layer.0.bias"], 1e-5)
-            a = _K.gemm(a0, P["asr_enc_layer.1.weight"], P["asr_enc_layer.1.bias"])
-            S.update(asr2=asr2, a0=a0)
-        else:
-            a = torch.zeros((R, E), dtype=torch.float32, device=vis.device)
-        n_valid = vmask.sum(dim=-1).to(torch.int32).contiguous()
-        tin = torch.empty((R, E), dtype=torch.float32, device=vis.device)
-        _chk(lib.hirest_joint_time_features(n_valid.data_ptr(), P["temporal_embed.0.weight"].data_ptr(), P["temporal_embed.0.bias"].data_ptr(),
-                                            tin.data_ptr(), B, T, E, ops.stream_ptr()), "time_features")
-        temporal = _K.gemm(tin, P["temporal_embed.2.weight"], P["temporal_embed.2.bias"])
-        base = torch.empty((R, E), dtype=torch.float32, device=vis.device)
-        _chk(lib.hirest_joint_base(v.data_ptr(), t.data_ptr(), a.data_ptr(), temporal.data_ptr(), base.data_ptr(), B, T, E, ops.stream_ptr()),
-             "joint_base")
-        mm32 = mmask.to(torch.int32).contiguous()
-        f = torch.empty_like(base)
-        bm32 = inp["boundary_mask"].to(torch.int32).contiguous() if seg else None
-        bemb = P["boundary_embed.weight"] if seg else _f32(model.boundary_embed.weight)
-        _chk(lib.hirest_joint_mask_add(base.data_ptr(), mm32.data_ptr(), bm32.data_ptr() if seg else None, P["mask_embed.weight"].data_ptr(),
-                                       bemb.data_ptr(), f.data_ptr(), R, E, ops.stream_ptr()), "mask_add")
-        S["bm32"] = bm32
-        # ---- VisualModel (module_visual.py:104-264, 396-424)
-        x0 = _K.gemm(f, P[_V + "embeddings.word_embeddings.weight"], P[_V + "embeddings.word_embeddings.bias"],
-                     periodic=P[_V + "embeddings.position_embeddings.weight"], period=T)
-        xe = _K.layernorm(x0, P[_V + "embeddings.LayerNorm.weight"], P[_V + "embeddings.LayerNorm.bias"], 1e-12)
-        x = _K.dropout_add(xe, None, drop, seed + 1)
-        S.update(vis2=vis2, v0=v0, v=v, t=t, tn=tn, tin=tin, f=f, x0=x0, mm32=mm32, n_valid=n_valid, text=text.float().contiguous())
-        layers = []
-        L = len(model.clip4cap_model.visual.encoder.layer)
-        for i in range(L):
-            p = _V + f"encoder.layer.{i}."
-            wqkv = torch.cat([P[p + "attention.self.query.weight"], P[p + "attention.self.key.weight"], P[p + "attention.self.value.weight"]], 0).contiguous()
-            bqkv = torch.cat([P[p + "attention.self.query.bias"], P[p + "attention.self.key.bias"], P[p + "attention.self.value.bias"]], 0).contiguous()
-            qkv = _K.gemm(x, wqkv, bqkv)
-            Pm = torch.empty((B, heads, T, T), dtype=torch.float32, device=vis.device)
-            cx = torch.empty((R, Hd), dtype=torch.float32, device=vis.device)
-            _chk(lib.hirest_attention_train_fwd_f32(qkv.data_ptr(), Pm.data_ptr(), cx.data_ptr(), B, T, heads, Hd // heads,
-                                                    (Hd // heads) ** -0.5, -10000.0, drop, (seed + 10 + 4 * i) & 0xFFFFFFFF, ops.stream_ptr()),
-                 "attention_train_fwd")
-            o = _K.gemm(cx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"])
-            a_pre = _K.dropout_add(o, x, drop, seed + 11 + 4 * i)
-            aa = _K.layernorm(a_pre, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], 1e-12)
-            hpre = _K.gemm(aa, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
-            hh = _K.act(hpre, 1)
-            y = _K.gemm(hh, P[p + "output.dense.weight"], P[p + "output.dense.bias"])
-            x_pre = _K.dropout_add(y, aa, drop, seed + 12 + 4 * i)
-            xn = _K.layernorm(x_pre, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], 1e-12)
-            layers.append(dict(x=x, wqkv=wqkv, qkv=qkv, Pm=Pm, cx=cx, a_pre=a_pre, aa=aa, hpre=hpre, hh=hh, x_pre=x_pre))
-            x = xn
-        feats = x
-        # ---- heads + loss (modeling.py:218-219, 249-263 / 319, 343-344)
-        loss = torch.zeros((1,), dtype=torch.float32, device=vis.device)
-        if seg:
+        S = {"drop": float(inp.get("dropout", 0.0)), "seed": int(inp.get("seed", 0)), "seg": seg}
+        feats = _encoder_forward(model, P, inp, S)
+        B, T, mm32 = S["B"], S["T"], S["mm32"]
+        R, Hd = B * T, 768
+        dev = feats.device
+        loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+        if seg:   # modeling.py:319, 343-344
             wsg = P["segment_predictor.0.weight"]
-            bias3 = torch.cat([P["segment_predictor.0.bias"], torch.zeros(2, device=vis.device)]).contiguous()
-            logits = torch.empty((1, R), dtype=torch.float32, device=vis.device)
+            bias3 = torch.cat([P["segment_predictor.0.bias"], torch.zeros(2, device=dev)]).contiguous()
+            logits = torch.empty((1, R), dtype=torch.float32, device=dev)
             _chk(lib.hirest_linear_heads(feats.data_ptr(), R, Hd, 1, wsg.data_ptr(), None, None, bias3.data_ptr(), logits.data_ptr(),
                                          ops.stream_ptr()), "linear_heads")
             st = inp["segment_target"].to(torch.int32).contiguous()
@@ -227,10 +333,10 @@ class MomentLoss(torch.autograd.Function):
             dl = torch.empty_like(logits)
             _chk(lib.hirest_ce_masked_f32(logits.data_ptr(), mm32.data_ptr(), st.data_ptr(), B, T, 1.0, loss.data_ptr(), dl.data_ptr(),
                                           ops.stream_ptr()), "ce_masked")
-        else:
+        else:     # modeling.py:218-219, 249-263
             ws, we = P["start_predictor.0.weight"], P["end_predictor.0.weight"]
-            bias3 = torch.cat([P["start_predictor.0.bias"], P["end_predictor.0.bias"], torch.zeros(1, device=vis.device)]).contiguous()
-            logits = torch.empty((2, R), dtype=torch.float32, device=vis.device)
+            bias3 = torch.cat([P["start_predictor.0.bias"], P["end_predictor.0.bias"], torch.zeros(1, device=dev)]).contiguous()
+            logits = torch.empty((2, R), dtype=torch.float32, device=dev)
             _chk(lib.hirest_linear_heads(feats.data_ptr(), R, Hd, 2, ws.data_ptr(), we.data_ptr(), None, bias3.data_ptr(), logits.data_ptr(),
                                          ops.stream_ptr()), "linear_heads")
             st = inp["start_target"].to(torch.int32).contiguous()
@@ -239,7 +345,7 @@ class MomentLoss(torch.autograd.Function):
             for h_i, tgt in enumerate((st, et)):
                 _chk(lib.hirest_bce_masked_f32(logits[h_i].data_ptr(), tgt.data_ptr(), mm32.data_ptr(), B, T, 0.5, loss.data_ptr(),
                                                dl[h_i].data_ptr(), ops.stream_ptr()), "bce_masked")
-        S.update(layers=layers, feats=feats, logits=logits, st=st, et=et, P=P, names=names, model=model)
+        S.update(feats=feats, logits=logits, st=st, et=et, P=P, names=names, model=model)
         ctx.S = S
         ctx.set_materialize_grads(False)
         return loss.reshape(())
@@ -249,16 +355,14 @@ class MomentLoss(torch.autograd.Function):
         S = ctx.S
         lib = _lib.load()
         P, names, model = S["P"], S["names"], S["model"]
-        B, T, drop, seed = S["B"], S["T"], S["drop"], S["seed"]
-        R, E, Hd = B * T, 512, 768
-        heads = model.heads
-        dev = S["feats"].device
+        B, T = S["B"], S["T"]
+        R, Hd = B * T, 768
+        feats, logits, mm32 = S["feats"], S["logits"], S["mm32"]
+        dev = feats.device
         G: Dict[str, torch.Tensor] = {}
         g = float(gloss.item()) if gloss is not None else 1.0       # upstream scale (GradScaler / accumulation); a host scalar
-        logits, mm32 = S["logits"], S["mm32"]
         dl = torch.empty_like(logits)
         scratch = torch.zeros((1,), dtype=torch.float32, device=dev)
-        feats = S["feats"]
         dx = torch.empty((R, Hd), dtype=torch.float32, device=dev)
         if S["seg"]:
             _chk(lib.hirest_ce_masked_f32(logits.data_ptr(), mm32.data_ptr(), S["st"].data_ptr(), B, T, g, scratch.data_ptr(), dl.data_ptr(),
@@ -277,76 +381,186 @@ class MomentLoss(torch.autograd.Function):
             G["start_predictor.0.bias"] = _K.colsum(dl[0].reshape(R, 1))
             G["end_predictor.0.bias"] = _K.colsum(dl[1].reshape(R, 1))
             _chk(lib.hirest_heads_bwd_f32(dl.data_ptr(), R, Hd, 2, ws.data_ptr(), we.data_ptr(), None, dx.data_ptr(), ops.stream_ptr()), "heads_bwd")
-        # ---- encoder layers, last to first
-        L = len(S["layers"])
-        for i in reversed(range(L)):
-            p = _V + f"encoder.layer.{i}."
-            Ly = S["layers"][i]
+        _encoder_backward(model, P, S, dx, G)
+        ctx.S = None
+        return (None, None, None) + tuple(G[n].reshape(P[n].shape) for n in names)
+
+
+def _attn_fwd(q, ldq, k, v, ldkv, mask, B, Tq, Tk, heads, addc, drop, seed):
+    lib = _lib.load()
+    Pm = torch.empty((B, heads, Tq, Tk), dtype=torch.float32, device=q.device)
+    cx = torch.empty((B * Tq, heads * 64), dtype=torch.float32, device=q.device)
+    _chk(lib.hirest_attention_train_fwd_qkv_f32(q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(), ldkv, mask.data_ptr() if mask is not None else None,
+                                                Pm.data_ptr(), cx.data_ptr(), heads * 64, B, Tq, Tk, heads, 64, 0.125, addc, drop,
+                                                seed & 0xFFFFFFFF, ops.stream_ptr()), "attention_train_fwd_qkv")
+    return Pm, cx
+
+
+class CaptionLoss(torch.autograd.Function):
+    """train_step_captioning (modeling.py:476-527): trimmed 20-frame encoder -> teacher-forced 2-layer decoder
+    (module_decoder.py:279-420) -> CrossEntropyLoss(ignore_index=-1) over the vocabulary, with its backward."""
+
+    @staticmethod
+    def forward(ctx, model, inp, names: List[str], *params):
+        P = {n: _f32(p) for n, p in zip(names, params)}
+        drop, seed = float(inp.get("dropout", 0.0)), int(inp.get("seed", 0))
+        S = {"drop": drop, "seed": seed}
+        enc = _encoder_forward(model, P, inp, S)                       # [B*F, 768]
+        B, F = S["B"], S["T"]
+        ids, amask, target = inp["input_ids"], inp["decoder_mask"], inp["output_ids"]
+        L = ids.shape[1]
+        R, Hd, heads = B * L, 768, model.heads
+        dev = enc.device
+        lib = _lib.load()
+        ids32 = ids.to(torch.int32).to(dev).contiguous()
+        We, pos = P[_D + "embeddings.word_embeddings.weight"], P[_D + "embeddings.position_embeddings.weight"]
+        e0 = torch.empty((R, Hd), dtype=torch.float32, device=dev)
+        _chk(lib.hirest_embedding_fwd_f32(ids32.data_ptr(), We.data_ptr(), pos.data_ptr(), e0.data_ptr(), R, L, Hd, ops.stream_ptr()), "embedding_fwd")
+        e1 = _K.layernorm(e0, P[_D + "embeddings.LayerNorm.weight"], P[_D + "embeddings.LayerNorm.bias"], 1e-12)
+        x = _K.dropout_add(e1, None, drop, seed + 101)
+        # self-attention mask (module_decoder.py:388-397): -10000 on future keys and on padded keys; host index arithmetic
+        future = torch.triu(torch.ones((L, L), dtype=torch.bool), diagonal=1)
+        blocked = future.unsqueeze(0) | (amask.cpu() == 0).unsqueeze(1)
+        smask = torch.where(blocked, torch.tensor(-10000.0), torch.tensor(0.0)).to(dev).contiguous()
+        dl_layers = []
+        for i in range(len(model.clip4cap_model.decoder.decoder.layer)):
+            p = _D + f"decoder.layer.{i}."
+            sa, ea = p + "slf_attn.", p + "enc_attn."
+            wqkv = torch.cat([P[sa + "att.query.weight"], P[sa + "att.key.weight"], P[sa + "att.value.weight"]], 0).contiguous()
+            bqkv = torch.cat([P[sa + "att.query.bias"], P[sa + "att.key.bias"], P[sa + "att.value.bias"]], 0).contiguous()
+            qkv = _K.gemm(x, wqkv, bqkv)
+            P1, c1 = _attn_fwd(qkv, 3 * Hd, qkv[:, Hd:], qkv[:, 2 * Hd:], 3 * Hd, smask, B, L, L, heads, 0.0, drop, seed + 110 + 8 * i)
+            o1 = _K.gemm(c1, P[sa + "output.dense.weight"], P[sa + "output.dense.bias"])
+            s_pre = _K.dropout_add(o1, x, drop, seed + 111 + 8 * i)
+            sx = _K.layernorm(s_pre, P[sa + "output.LayerNorm.weight"], P[sa + "output.LayerNorm.bias"], 1e-12)
+            q2 = _K.gemm(sx, P[ea + "att.query.weight"], P[ea + "att.query.bias"])
+            wkv = torch.cat([P[ea + "att.key.weight"], P[ea + "att.value.weight"]], 0).contiguous()
+            bkv = torch.cat([P[ea + "att.key.bias"], P[ea + "att.value.bias"]], 0).contiguous()
+            kv = _K.gemm(enc, wkv, bkv)
+            P2, c2 = _attn_fwd(q2, Hd, kv, kv[:, Hd:], 2 * Hd, None, B, L, F, heads, -10000.0, drop, seed + 112 + 8 * i)
+            o2 = _K.gemm(c2, P[ea + "output.dense.weight"], P[ea + "output.dense.bias"])
+            d_pre = _K.dropout_add(o2, sx, drop, seed + 113 + 8 * i)
+            dx_ = _K.layernorm(d_pre, P[ea + "output.LayerNorm.weight"], P[ea + "output.LayerNorm.bias"], 1e-12)
+            hpre = _K.gemm(dx_, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
+            hh = _K.act(hpre, 1)
+            y = _K.gemm(hh, P[p + "output.dense.weight"], P[p + "output.dense.bias"])
+            x_pre = _K.dropout_add(y, dx_, drop, seed + 114 + 8 * i)
+            xn = _K.layernorm(x_pre, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], 1e-12)
+            dl_layers.append(dict(x=x, wqkv=wqkv, qkv=qkv, P1=P1, c1=c1, s_pre=s_pre, sx=sx, q2=q2, wkv=wkv, kv=kv, P2=P2, c2=c2, d_pre=d_pre,
+                                  d=dx_, hpre=hpre, hh=hh, x_pre=x_pre))
+            x = xn
+        cp = _D + "classifier.cls.predictions."
+        tpre = _K.gemm(x, P[cp + "transform.dense.weight"], P[cp + "transform.dense.bias"])
+        tg = _K.act(tpre, 1)
+        tnorm = _K.layernorm(tg, P[cp + "transform.LayerNorm.weight"], P[cp + "transform.LayerNorm.bias"], 1e-12)
+        V = We.shape[0]
+        Vp = (V + 15) // 16 * 16                                       # reduction-dim granule of the dX GEMM; pad logits can never win
+        Wp = torch.zeros((Vp, Hd), dtype=torch.float32, device=dev)
+        Wp[:V] = We
+        bp = torch.full((Vp,), -3.0e38, dtype=torch.float32, device=dev)
+        bp[:V] = P[cp + "bias"]
+        logits = _K.gemm(tnorm, Wp, bp)
+        tgt32 = target.to(torch.int32).reshape(-1).contiguous().to(dev)
+        n_valid = int((target >= 0).sum().item())
+        loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+        dlog = torch.empty_like(logits)
+        _chk(lib.hirest_ce_rows_f32(logits.data_ptr(), Vp, tgt32.data_ptr(), R, Vp, 1.0, n_valid, loss.data_ptr(), dlog.data_ptr(), ops.stream_ptr()),
+             "ce_rows")
+        del dlog
+        S.update(enc=enc, L=L, ids32=ids32, e0=e0, dl=dl_layers, xlast=x, tpre=tpre, tg=tg, tnorm=tnorm, Wp=Wp, logits=logits, tgt32=tgt32,
+                 n_tok=n_valid, V=V, Vp=Vp, P=P, names=names, model=model)
+        ctx.S = S
+        ctx.set_materialize_grads(False)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        S = ctx.S
+        lib = _lib.load()
+        P, names, model = S["P"], S["names"], S["model"]
+        B, F, L, drop, seed = S["B"], S["T"], S["L"], S["drop"], S["seed"]
+        R, Hd, heads, V, Vp = B * L, 768, model.heads, S["V"], S["Vp"]
+        dev = S["enc"].device
+        G: Dict[str, torch.Tensor] = {}
+        g = float(gloss.item()) if gloss is not None else 1.0
+        cp = _D + "classifier.cls.predictions."
+        logits = S["logits"]
+        dlog = torch.empty_like(logits)
+        scratch = torch.zeros((1,), dtype=torch.float32, device=dev)
+        _chk(lib.hirest_ce_rows_f32(logits.data_ptr(), Vp, S["tgt32"].data_ptr(), R, Vp, g, S["n_tok"], scratch.data_ptr(), dlog.data_ptr(),
+                                    ops.stream_ptr()), "ce_rows")
+        dWe = _K.grad_weight(dlog, S["tnorm"])                          # [Vp, 768]: the LM head's share of the tied matrix
+        G[cp + "bias"] = _K.colsum(dlog)[:V]
+        dtn = _K.grad_input(dlog, S["Wp"])
+        dtg, G[cp + "transform.LayerNorm.weight"], G[cp + "transform.LayerNorm.bias"] = _K.layernorm_bwd(S["tg"], dtn, P[cp + "transform.LayerNorm.weight"], 1e-12)
+        dtpre = _K.act_bwd(S["tpre"], dtg, 1)
+        G[cp + "transform.dense.weight"] = _K.grad_weight(dtpre, S["xlast"])
+        G[cp + "transform.dense.bias"] = _K.colsum(dtpre)
+        dx = _K.grad_input(dtpre, P[cp + "transform.dense.weight"])
+        denc = None
+        for i in reversed(range(len(S["dl"]))):
+            p = _D + f"decoder.layer.{i}."
+            sa, ea = p + "slf_attn.", p + "enc_attn."
+            Ly = S["dl"][i]
             dxp, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = _K.layernorm_bwd(Ly["x_pre"], dx, P[p + "output.LayerNorm.weight"], 1e-12)
-            dy = _K.dropout_add(dxp, None, drop, seed + 12 + 4 * i)           # through dropout(y); the residual branch gets dxp as is
+            dy = _K.dropout_add(dxp, None, drop, seed + 114 + 8 * i)
             G[p + "output.dense.weight"] = _K.grad_weight(dy, Ly["hh"])
             G[p + "output.dense.bias"] = _K.colsum(dy)
-            dh = _K.grad_input(dy, P[p + "output.dense.weight"])
-            dhp = _K.act_bwd(Ly["hpre"], dh, 1)
-            G[p + "intermediate.dense.weight"] = _K.grad_weight(dhp, Ly["aa"])
+            dhp = _K.act_bwd(Ly["hpre"], _K.grad_input(dy, P[p + "output.dense.weight"]), 1)
+            G[p + "intermediate.dense.weight"] = _K.grad_weight(dhp, Ly["d"])
             G[p + "intermediate.dense.bias"] = _K.colsum(dhp)
-            da = _K.dropout_add(_K.grad_input(dhp, P[p + "intermediate.dense.weight"]), dxp, 0.0, 0)      # + residual path
-            dap, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
-                _K.layernorm_bwd(Ly["a_pre"], da, P[p + "attention.output.LayerNorm.weight"], 1e-12)
-            do = _K.dropout_add(dap, None, drop, seed + 11 + 4 * i)
-            G[p + "attention.output.dense.weight"] = _K.grad_weight(do, Ly["cx"])
-            G[p + "attention.output.dense.bias"] = _K.colsum(do)
-            dcx = _K.grad_input(do, P[p + "attention.output.dense.weight"])
-            dS = torch.empty_like(Ly["Pm"])
+            dd = _K.dropout_add(_K.grad_input(dhp, P[p + "intermediate.dense.weight"]), dxp, 0.0, 0)
+            # cross-attention block
+            ddp, G[ea + "output.LayerNorm.weight"], G[ea + "output.LayerNorm.bias"] = _K.layernorm_bwd(Ly["d_pre"], dd, P[ea + "output.LayerNorm.weight"], 1e-12)
+            do2 = _K.dropout_add(ddp, None, drop, seed + 113 + 8 * i)
+            G[ea + "output.dense.weight"] = _K.grad_weight(do2, Ly["c2"])
+            G[ea + "output.dense.bias"] = _K.colsum(do2)
+            dc2 = _K.grad_input(do2, P[ea + "output.dense.weight"])
+            dS2 = torch.empty_like(Ly["P2"])
+            dq2 = torch.empty_like(Ly["q2"])
+            dkv = torch.empty_like(Ly["kv"])
+            kv = Ly["kv"]
+            _chk(lib.hirest_attention_train_bwd_qkv_f32(Ly["q2"].data_ptr(), Hd, kv.data_ptr(), kv[:, Hd:].data_ptr(), 2 * Hd, Ly["P2"].data_ptr(),
+                                                        dc2.data_ptr(), Hd, dS2.data_ptr(), dq2.data_ptr(), Hd, dkv.data_ptr(),
+                                                        dkv[:, Hd:].data_ptr(), 2 * Hd, B, L, F, heads, 64, 0.125, drop,
+                                                        (seed + 112 + 8 * i) & 0xFFFFFFFF, ops.stream_ptr()), "attention_train_bwd_qkv")
+            G[ea + "att.query.weight"] = _K.grad_weight(dq2, Ly["sx"])
+            G[ea + "att.query.bias"] = _K.colsum(dq2)
+            dwkv, dbkv = _K.grad_weight(dkv, S["enc"]), _K.colsum(dkv)
+            G[ea + "att.key.weight"], G[ea + "att.value.weight"] = dwkv[:Hd], dwkv[Hd:]
+            G[ea + "att.key.bias"], G[ea + "att.value.bias"] = dbkv[:Hd], dbkv[Hd:]
+            de = _K.grad_input(dkv, Ly["wkv"])
+            denc = de if denc is None else _K.dropout_add(de, denc, 0.0, 0)
+            ds = _K.dropout_add(_K.grad_input(dq2, P[ea + "att.query.weight"]), ddp, 0.0, 0)
+            # self-attention block
+            dsp, G[sa + "output.LayerNorm.weight"], G[sa + "output.LayerNorm.bias"] = _K.layernorm_bwd(Ly["s_pre"], ds, P[sa + "output.LayerNorm.weight"], 1e-12)
+            do1 = _K.dropout_add(dsp, None, drop, seed + 111 + 8 * i)
+            G[sa + "output.dense.weight"] = _K.grad_weight(do1, Ly["c1"])
+            G[sa + "output.dense.bias"] = _K.colsum(do1)
+            dc1 = _K.grad_input(do1, P[sa + "output.dense.weight"])
+            dS1 = torch.empty_like(Ly["P1"])
             dqkv = torch.empty_like(Ly["qkv"])
-            _chk(lib.hirest_attention_train_bwd_f32(Ly["qkv"].data_ptr(), Ly["Pm"].data_ptr(), dcx.data_ptr(), dS.data_ptr(), dqkv.data_ptr(),
-                                                    B, T, heads, Hd // heads, (Hd // heads) ** -0.5, drop, (seed + 10 + 4 * i) & 0xFFFFFFFF,
-                                                    ops.stream_ptr()), "attention_train_bwd")
-            dwqkv = _K.grad_weight(dqkv, Ly["x"])
-            dbqkv = _K.colsum(dqkv)
+            qkv = Ly["qkv"]
+            _chk(lib.hirest_attention_train_bwd_qkv_f32(qkv.data_ptr(), 3 * Hd, qkv[:, Hd:].data_ptr(), qkv[:, 2 * Hd:].data_ptr(), 3 * Hd,
+                                                        Ly["P1"].data_ptr(), dc1.data_ptr(), Hd, dS1.data_ptr(), dqkv.data_ptr(), 3 * Hd,
+                                                        dqkv[:, Hd:].data_ptr(), dqkv[:, 2 * Hd:].data_ptr(), 3 * Hd, B, L, L, heads, 64, 0.125,
+                                                        drop, (seed + 110 + 8 * i) & 0xFFFFFFFF, ops.stream_ptr()), "attention_train_bwd_qkv")
+            dwqkv, dbqkv = _K.grad_weight(dqkv, Ly["x"]), _K.colsum(dqkv)
             for k, nm in enumerate(("query", "key", "value")):
-                G[p + f"attention.self.{nm}.weight"] = dwqkv[k * Hd:(k + 1) * Hd]
-                G[p + f"attention.self.{nm}.bias"] = dbqkv[k * Hd:(k + 1) * Hd]
-            dx = _K.dropout_add(_K.grad_input(dqkv, Ly["wqkv"]), dap, 0.0, 0)                               # + residual path
-        # ---- embeddings
-        dxe = _K.dropout_add(dx, None, drop, seed + 1)
-        dx0, G[_V + "embeddings.LayerNorm.weight"], G[_V + "embeddings.LayerNorm.bias"] = \
-            _K.layernorm_bwd(S["x0"], dxe, P[_V + "embeddings.LayerNorm.weight"], 1e-12)
-        pos = P[_V + "embeddings.position_embeddings.weight"]
+                G[sa + f"att.{nm}.weight"] = dwqkv[k * Hd:(k + 1) * Hd]
+                G[sa + f"att.{nm}.bias"] = dbqkv[k * Hd:(k + 1) * Hd]
+            dx = _K.dropout_add(_K.grad_input(dqkv, Ly["wqkv"]), dsp, 0.0, 0)
+        # decoder embeddings: LayerNorm, position table, and the input-embedding share of the tied matrix
+        dxe = _K.dropout_add(dx, None, drop, seed + 101)
+        de0, G[_D + "embeddings.LayerNorm.weight"], G[_D + "embeddings.LayerNorm.bias"] = \
+            _K.layernorm_bwd(S["e0"], dxe, P[_D + "embeddings.LayerNorm.weight"], 1e-12)
+        pos = P[_D + "embeddings.position_embeddings.weight"]
         dpos = torch.zeros_like(pos)
-        dpos[:T] = _K.colsum(dx0.reshape(B, T * Hd)).reshape(T, Hd)
-        G[_V + "embeddings.position_embeddings.weight"] = dpos
-        G[_V + "embeddings.word_embeddings.weight"] = _K.grad_weight(dx0, S["f"])
-        G[_V + "embeddings.word_embeddings.bias"] = _K.colsum(dx0)
-        df = _K.grad_input(dx0, P[_V + "embeddings.word_embeddings.weight"])
-        # ---- fusion
-        G["mask_embed.weight"] = torch.stack([_K.colsum(df, select=mm32.reshape(-1), value=k) for k in (0, 1)])
-        if S["seg"]:
-            G["boundary_embed.weight"] = torch.stack([_K.colsum(df, select=S["bm32"].reshape(-1), value=k) for k in (0, 1)])
-        dv = torch.empty_like(df)
-        dtn = torch.empty((B, E), dtype=torch.float32, device=dev)
-        _chk(lib.hirest_joint_base_bwd_f32(df.data_ptr(), S["v"].data_ptr(), S["tn"].data_ptr(), dv.data_ptr(), dtn.data_ptr(), B, T, E,
-                                           ops.stream_ptr()), "joint_base_bwd")
-        # temporal embedding: Linear(1, E) -> tanh -> Linear(E, E) over the normalised time grid
-        G["temporal_embed.2.weight"] = _K.grad_weight(df, S["tin"])
-        G["temporal_embed.2.bias"] = _K.colsum(df)
-        dpre = _K.act_bwd(S["tin"], _K.grad_input(df, P["temporal_embed.2.weight"]), 3)
-        time = time_grid(S["n_valid"], T).reshape(R).contiguous()
-        G["temporal_embed.0.weight"] = _K.colsum(dpre, weight=time).reshape(E, 1)
-        G["temporal_embed.0.bias"] = _K.colsum(dpre)
-        if model.use_asr:
-            G["asr_enc_layer.1.weight"] = _K.grad_weight(df, S["a0"])
-            G["asr_enc_layer.1.bias"] = _K.colsum(df)
-            da0 = _K.grad_input(df, P["asr_enc_layer.1.weight"])
-            _, G["asr_enc_layer.0.weight"], G["asr_enc_layer.0.bias"] = _K.layernorm_bwd(S["asr2"], da0, P["asr_enc_layer.0.weight"], 1e-5)
-        dv0, G["clip4cap_model.normalize_video.visual_norm2d.weight"], G["clip4cap_model.normalize_video.visual_norm2d.bias"] = \
-            _K.layernorm_bwd(S["v0"], dv, P["clip4cap_model.normalize_video.visual_norm2d.weight"], 1e-12)
-        G["clip_g_map.weight"] = _K.grad_weight(dv0, S["vis2"])
-        G["clip_g_map.bias"] = _K.colsum(dv0)
-        dt = torch.empty_like(dtn)
-        _chk(lib.hirest_l2norm_bwd_f32(S["t"].data_ptr(), dtn.data_ptr(), dt.data_ptr(), B, E, ops.stream_ptr()), "l2norm_bwd")
-        G["clip_g_map_text.weight"] = _K.grad_weight(dt, S["text"])
-        G["clip_g_map_text.bias"] = _K.colsum(dt)
+        dpos[:L] = _K.colsum(de0.reshape(B, L * Hd)).reshape(L, Hd)
+        G[_D + "embeddings.position_embeddings.weight"] = dpos
+        _chk(lib.hirest_embedding_bwd_f32(S["ids32"].data_ptr(), de0.data_ptr(), dWe.data_ptr(), R, Hd, ops.stream_ptr()), "embedding_bwd")
+        G[_D + "embeddings.word_embeddings.weight"] = dWe[:V]
+        _encoder_backward(model, P, S, denc, G)
         ctx.S = None
         return (None, None, None) + tuple(G[n].reshape(P[n].shape) for n in names)
 
@@ -368,18 +582,34 @@ def _train(model, batch, task) -> Dict[str, torch.Tensor]:
         text = model._text_feat(batch, dev)
     inp = {"task": task, "vis": batch["vis_feats"].to(dev), "text": text, "vis_mask": batch["vis_mask"].to(dev),
            "moment_mask": batch["moment_mask"].to(dev),
-           "dropout": 0.1 if model.training else 0.0, "seed": int(torch.randint(0, 2 ** 31 - 64, (1,)).item())}
+           "dropout": 0.1 if model.training else 0.0, "seed": int(torch.randint(0, 2 ** 31 - 1024, (1,)).item())}
+    if model.use_asr:
+        inp["asr"] = batch["asr_feats"].to(dev)
+    fn = MomentLoss
     if task == "moment_segmentation":
         inp["boundary_mask"] = batch["prev_boundary_mask"].to(dev)
         inp["segment_target"] = batch["moment_segmentation_target"].to(dev)
-    else:
+    elif task == "moment_retrieval":
         inp["start_target"] = batch["moment_retrieval_start_target"].to(dev)
         inp["end_target"] = batch["moment_retrieval_end_target"].to(dev)
-    if model.use_asr:
-        inp["asr"] = batch["asr_feats"].to(dev)
+    else:   # step_captioning (modeling.py:476-527): trimmed moment frames, all-ones masks, teacher-forcing triples of target_text
+        args = model.args
+        max_frames = int(getattr(args, "max_frames_step_captioning", 20)) if args is not None else 20
+        B = inp["vis"].shape[0]
+        mm = inp["moment_mask"]
+        inp["vis"] = model._trim(inp["vis"].float(), mm, max_frames)
+        if model.use_asr:
+            inp["asr"] = model._trim(inp["asr"].float(), mm, max_frames)
+        ones = torch.ones((B, max_frames), dtype=torch.long, device=dev)
+        inp["vis_mask"], inp["moment_mask"] = ones, ones
+        tt = batch["target_text"]
+        inp["input_ids"] = torch.tensor([list(t[5]) for t in tt], dtype=torch.long)
+        inp["decoder_mask"] = torch.tensor([list(t[6]) for t in tt], dtype=torch.long)
+        inp["output_ids"] = torch.tensor([list(t[7]) for t in tt], dtype=torch.long)
+        fn = CaptionLoss
     names = task_param_names(model, task)
     named = dict(model.named_parameters())
-    return {"loss": MomentLoss.apply(model, inp, names, *[named[n] for n in names])}
+    return {"loss": fn.apply(model, inp, names, *[named[n] for n in names])}
 
 
 def train_moment_retrieval(model, batch) -> Dict[str, torch.Tensor]:
@@ -390,6 +620,12 @@ def train_moment_retrieval(model, batch) -> Dict[str, torch.Tensor]:
 def train_moment_segmentation(model, batch) -> Dict[str, torch.Tensor]:
     """modeling.py:323-351: one teacher-forced step of the iterative segmentation (previous boundary -> next boundary)."""
     return _train(model, batch, "moment_segmentation")
+
+
+def train_step_captioning(model, batch) -> Dict[str, torch.Tensor]:
+    """modeling.py:476-527: ``batch['target_text'][i]`` = the reference's 9-tuple whose fields 5, 6, 7 are the decoder input
+    ids, the decoder mask and the output ids (-1 = ignored) of one caption."""
+    return _train(model, batch, "step_captioning")
 
 
 def allreduce_gradients(parameters, group=None, bucket_bytes: int = 64 << 20) -> None:

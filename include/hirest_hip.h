@@ -332,6 +332,24 @@ int hirest_attention_train_fwd_f32(const float* qkv, float* P, float* ctx, int32
                                    float scale, float add_const, float drop_p, uint32_t seed, void* stream);
 int hirest_attention_train_bwd_f32(const float* qkv, const float* P, const float* dctx, float* dS, float* dqkv, int32_t B,
                                    int32_t T, int32_t H, int32_t dh, float scale, float drop_p, uint32_t seed, void* stream);
+/* General forms (caption decoder, module_decoder.py:192-262): separate q [B*Tq, ldq] and k / v [B*Tk, ldkv], an optional
+ * additive mask [B, Tq, Tk] (the decoder's -10000 on future and padded keys) on top of add_const. */
+int hirest_attention_train_fwd_qkv_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                       const float* mask_add, float* P, float* ctx, int64_t ldctx, int32_t B, int32_t Tq, int32_t Tk,
+                                       int32_t H, int32_t dh, float scale, float add_const, float drop_p, uint32_t seed, void* stream);
+int hirest_attention_train_bwd_qkv_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* P,
+                                       const float* dctx, int64_t ldctx, float* dS, float* dq, int64_t lddq, float* dk, float* dv,
+                                       int64_t lddkv, int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale,
+                                       float drop_p, uint32_t seed, void* stream);
+/* DecoderEmbeddings (module_decoder.py:309-321): out[r] = table[ids[r]] + pos[r % T]; backward: dtable_accum[ids[r]] += dx[r]
+ * (atomic adds into a zeroed or pre-filled [vocab, D] buffer: the table is tied to the LM head, whose dW is already there) */
+int hirest_embedding_fwd_f32(const int32_t* ids, const float* table, const float* pos, float* out, int64_t rows, int32_t T,
+                             int32_t D, void* stream);
+int hirest_embedding_bwd_f32(const int32_t* ids, const float* dx, float* dtable_accum, int64_t rows, int32_t D, void* stream);
+/* CrossEntropyLoss(ignore_index = -1) over R rows of V logits (row stride ld): *loss_accum += weight * mean over the n_valid rows
+ * with target >= 0; dlogits = its gradient (ignored rows: zeros).  modeling.py:140, 519 */
+int hirest_ce_rows_f32(const float* logits, int64_t ld, const int32_t* target, int32_t R, int32_t V, float weight, int32_t n_valid,
+                       float* loss_accum, float* dlogits, void* stream);
 /* *loss_accum += weight * sum(mask * bce_with_logits(logits, onehot(target))) / max(sum mask, 1); dlogits = its gradient
  * (modeling.py:249-263) */
 int hirest_bce_masked_f32(const float* logits, const int32_t* target, const int32_t* mask, int32_t B, int32_t T, float weight,

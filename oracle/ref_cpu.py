@@ -527,7 +527,7 @@ def _mha(sd: SD, p: str, q_in, kv_in, add_mask, heads: int = 12):
                       sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
 
 
-def decoder_logits(sd: SD, input_ids: torch.Tensor, enc: torch.Tensor, layers: int = 2) -> torch.Tensor:
+def decoder_logits(sd: SD, input_ids: torch.Tensor, enc: torch.Tensor, layers: int = 2, answer_mask=None) -> torch.Tensor:
     """DecoderModel.forward (module_decoder.py:372-406) with answer_mask = ones and encoder_mask = ZEROS
     (modeling.py:591), i.e. a uniform -10000 on every cross-attention score and -10000 above the diagonal of the
     self-attention (not -inf).  Returns [R, t, vocab]."""
@@ -535,6 +535,9 @@ def decoder_logits(sd: SD, input_ids: torch.Tensor, enc: torch.Tensor, layers: i
     x = sd[_DEC + "embeddings.word_embeddings.weight"][input_ids] + sd[_DEC + "embeddings.position_embeddings.weight"][:t]
     x = layer_norm(x, sd[_DEC + "embeddings.LayerNorm.weight"], sd[_DEC + "embeddings.LayerNorm.bias"], 1e-12)
     self_mask = torch.triu(torch.ones(t, t), diagonal=1) * -10000.0
+    if answer_mask is not None:   # training (module_decoder.py:388-397): padded keys are blocked as well, per sample
+        blocked = (torch.triu(torch.ones(t, t), diagonal=1).unsqueeze(0) + (1.0 - answer_mask.float()).unsqueeze(1)).gt(0)
+        self_mask = (blocked.float() * -10000.0).unsqueeze(1)               # [R, 1, t, t]
     for i in range(layers):
         p = _DEC + f"decoder.layer.{i}."
         s = _mha(sd, p + "slf_attn.", x, x, self_mask)
@@ -546,6 +549,18 @@ def decoder_logits(sd: SD, input_ids: torch.Tensor, enc: torch.Tensor, layers: i
     h = gelu_erf(x @ sd[c + "transform.dense.weight"].t() + sd[c + "transform.dense.bias"])
     h = layer_norm(h, sd[c + "transform.LayerNorm.weight"], sd[c + "transform.LayerNorm.bias"], 1e-12)
     return h @ sd[c + "decoder.weight"].t() + sd[c + "bias"]
+
+
+def step_captioning_loss(sd: SD, vis, text, asr, moment_mask, input_ids, decoder_mask, output_ids, max_frames: int = 20) -> torch.Tensor:
+    """train_step_captioning (modeling.py:476-527) with dropout off: trim_feats, fusion + encoder on max_frames frames with all-ones
+    masks, teacher-forced decoder, CrossEntropyLoss(ignore_index=-1) over the vocabulary."""
+    B = vis.shape[0]
+    v = trim_feats(vis, moment_mask, max_frames)
+    a = trim_feats(asr, moment_mask, max_frames)
+    ones = torch.ones((B, max_frames), dtype=torch.long)
+    enc = joint_features(sd, v, text, a, ones, ones)
+    logits = decoder_logits(sd, input_ids, enc, answer_mask=decoder_mask)
+    return torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), output_ids.reshape(-1), ignore_index=-1)
 
 
 class RefBeam:

@@ -404,6 +404,21 @@ def train_targets(name, B, T, seed, bounds):
     return torch.from_numpy(st), torch.from_numpy(et), torch.from_numpy(seg), prev
 
 
+def caption_targets(name, B, max_words, seed):
+    """Teacher-forcing triples in the reference's target_text 9-tuple layout (fields 5, 6, 7: decoder input ids, decoder mask,
+    output ids with -1 on the padding): [CLS] w1 .. wn  /  w1 .. wn [SEP]."""
+    u = (synth.uniform_pm1(f"{name}.cap", B * (max_words + 1), seed).reshape(B, max_words + 1) + 1.0) * 0.5
+    out = []
+    for b in range(B):
+        n = 3 + int(u[b, 0] * (max_words - 8))
+        words = (1000 + (u[b, 1:1 + n] * 29000)).astype(np.int64).tolist()
+        inp = [101] + words + [0] * (max_words - 1 - n)
+        mask = [1] * (n + 1) + [0] * (max_words - 1 - n)
+        outp = words + [102] + [-1] * (max_words - 1 - n)
+        out.append((None, None, None, None, None, inp, mask, outp, None))
+    return out
+
+
 def gen_train():
     """MomentModel.train_moment_retrieval (modeling.py:226-270) run for real with autograd: loss value and the
     gradient of every trainable parameter (norm, first values; small tensors in full).  The model is in eval() mode so that the
@@ -448,6 +463,23 @@ def gen_train():
         seg_arrays, seg_gn = collect("seg.", seg_res["loss"])
         arrays.update(seg_arrays)
         arrays["seg_loss"] = arrays["seg.loss"]
+        # step captioning (modeling.py:476-527): moments of 7 / 20 / 37 frames -> all three trim_feats branches
+        for p_ in model.parameters():
+            p_.grad = None
+        cap_mask = torch.zeros(B, T, dtype=torch.long)
+        for b_, n_ in enumerate([7, 20, 37][:B]):
+            cap_mask[b_, 5 + b_:5 + b_ + n_] = 1
+        tt = caption_targets(f"train.{case}", B, args.max_words, 53)
+        batch = {"tasks": ["step_captioning"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": cap_mask, "asr_feats": asr,
+                 "clip_text_ids": ids, "target_text": tt}
+        cap_res = model.train_step(batch)
+        cap_res["loss"].backward()
+        cap_arrays, cap_gn = collect("cap.", cap_res["loss"])
+        for k in list(cap_arrays):
+            if k.startswith("cap.full.") and cap_arrays[k].size > 1024:          # keep the fixture small: biases / LayerNorms only
+                del cap_arrays[k]
+        arrays.update(cap_arrays)
+        print(case, "captioning loss", float(cap_arrays["cap.loss"]), "grads", len(cap_gn))
         save(f"train_{case}.npz", **arrays)
         out[case] = {"loss": float(arrays["loss"]), "seg_loss": float(arrays["seg_loss"]), "n_grads": len(gn)}
         unused = [n for n, p_ in model.named_parameters() if p_.grad is None and not n.startswith("clip_model.") and p_.requires_grad]

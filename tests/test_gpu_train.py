@@ -24,7 +24,7 @@ def dev():
 def _setup(golden_dir, case, dev):
     import hirest_amd
     sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs, train_targets, TRAIN_CASES
+    from make_golden import joint_inputs, train_targets, caption_targets, TRAIN_CASES
     B, T = TRAIN_CASES[case]
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
     model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
@@ -36,15 +36,20 @@ def _setup(golden_dir, case, dev):
              "text_feat": text, "moment_retrieval_start_target": st, "moment_retrieval_end_target": et}
     seg_batch = {"tasks": ["moment_segmentation"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "asr_feats": asr,
                  "text_feat": text, "prev_boundary_mask": prev, "moment_segmentation_target": seg}
-    return model, batch, seg_batch, np.load(os.path.join(golden_dir, f"train_{case}.npz"))
+    cap_mask = torch.zeros(B, T, dtype=torch.long)
+    for b_, n_ in enumerate([7, 20, 37][:B]):
+        cap_mask[b_, 5 + b_:5 + b_ + n_] = 1
+    cap_batch = {"tasks": ["step_captioning"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": cap_mask, "asr_feats": asr,
+                 "text_feat": text, "target_text": caption_targets(f"train.{case}", B, 48, 53)}
+    return model, batch, seg_batch, cap_batch, np.load(os.path.join(golden_dir, f"train_{case}.npz"))
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
 def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
-    model, batch, seg_batch, g = _setup(golden_dir, case, dev)
+    model, batch, seg_batch, cap_batch, g = _setup(golden_dir, case, dev)
     model.eval()                                   # dropout off: the arithmetic the goldens pin
     worst = 0.0
-    for b, prefix in ((batch, ""), (seg_batch, "seg.")):
+    for b, prefix in ((batch, ""), (seg_batch, "seg."), (cap_batch, "cap.")):
         for p in model.parameters():
             p.grad = None
         loss = model.train_step(b)["loss"]
@@ -73,14 +78,14 @@ def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
         print(f"case {case} {prefix or 'retrieval '}loss {loss.item():.7f} (reference {ref:.7f}), {len(names)} gradient tensors")
     print(f"worst gradient-norm deviation {worst:.2e}")
     with pytest.raises(NotImplementedError):
-        model.train_step({"tasks": ["step_captioning"]})
+        model.train_step({"tasks": ["something_else"]})
 
 
 def test_training_loop_contract_and_dropout(dev, golden_dir):
     """run.py:238-295: results['loss'].backward(); clip_grad_norm_; optim.step(); grads reset.  Train mode switches the four
     dropout sites on (counter-based masks): the loss changes from call to call, stays finite, and a few AdamW steps on one batch
     reduce the eval-mode loss."""
-    model, batch, _, g = _setup(golden_dir, "a", dev)
+    model, batch, _, cap_batch, g = _setup(golden_dir, "a", dev)
     trainable = [p for n, p in model.named_parameters() if p.requires_grad]
     optim = torch.optim.AdamW(trainable, lr=2e-4)
     model.eval()
@@ -102,6 +107,20 @@ def test_training_loop_contract_and_dropout(dev, golden_dir):
     last = model.train_step(batch)["loss"].item()
     print(f"eval-mode loss {first:.5f} -> {last:.5f} after 4 AdamW steps")
     assert last < first
+    # the captioning task through the same loop (train mode: dropout in the decoder as well)
+    model.train()
+    c0 = None
+    for step in range(3):
+        loss = model.train_step(cap_batch)["loss"]
+        assert torch.isfinite(loss)
+        c0 = loss.item() if c0 is None else c0
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        optim.step()
+        for p in model.parameters():
+            p.grad = None
+    model.eval()
+    assert model.train_step(cap_batch)["loss"].item() < c0
     # predictions still come out of the updated weights through the inference path
     out = model.test_step(dict(batch, tasks=["moment_retrieval"]))["prediction"]
     assert len(out) == batch["vis_feats"].shape[0]

@@ -239,7 +239,7 @@ def test_training_loss_and_gradients_match_reference(golden_dir, case):
             v.grad = None
         loss.backward()
         names = [str(n) for n in g[prefix + "names"]]
-        got = {k for k, v in sd.items() if v.grad is not None and float(v.grad.abs().sum()) > 0}
+        got = {k for k, v in sd.items() if v.grad is not None and float(v.grad.abs().sum()) > 0 and not k.endswith("predictions.decoder.weight")}
         assert set(names) == got                                           # exactly the tensors the reference trains on this task
         for i, n in enumerate(names):
             gr = sd[n].grad.double()
@@ -250,4 +250,16 @@ def test_training_loss_and_gradients_match_reference(golden_dir, case):
         return names
     n_ret = check(O.moment_retrieval_loss(sd, vis, text, asr, vis_mask, moment_mask, st, et), "")
     n_seg = check(O.moment_segmentation_loss(sd, vis, text, asr, vis_mask, moment_mask, prev, seg), "seg.")
+    # step captioning: the tied LM-head / input-embedding matrix is ONE parameter in the reference (first registered name)
+    from make_golden import caption_targets
+    tied_a, tied_b = "clip4cap_model.decoder.embeddings.word_embeddings.weight", "clip4cap_model.decoder.classifier.cls.predictions.decoder.weight"
+    tied = sd[tied_a]
+    sd[tied_b] = tied
+    cap_mask = torch.zeros(B, T, dtype=torch.long)
+    for b_, n_ in enumerate([7, 20, 37][:B]):
+        cap_mask[b_, 5 + b_:5 + b_ + n_] = 1
+    tt = caption_targets(f"train.{case}", B, 48, 53)
+    ids_in = torch.tensor([t_[5] for t_ in tt]); dmask = torch.tensor([t_[6] for t_ in tt]); ids_out = torch.tensor([t_[7] for t_ in tt])
+    n_cap = check(O.step_captioning_loss(sd, vis, text, asr, cap_mask, ids_in, dmask, ids_out), "cap.")
+    assert tied_a in n_cap and "clip4cap_model.decoder.decoder.layer.1.enc_attn.att.key.weight" in n_cap
     assert len(n_ret) == 56 and "boundary_embed.weight" in n_seg and "segment_predictor.0.weight" in n_seg and "start_predictor.0.weight" not in n_seg
