@@ -5,5 +5,6 @@ from .eva_clip import (EVA_CLIP, build_eva_model_and_transforms, create_model, i
                        get_model_config, list_models)
 from .tokenizer import tokenize  # noqa: F401
 from .moment_model import MomentModel  # noqa: F401
+from .sentence_encoder import SentenceTransformer  # noqa: F401
 
 __version__ = "0.1.0"

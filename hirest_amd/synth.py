@@ -319,3 +319,51 @@ def joint_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str,
     if tied_a in out and tied_b in out:
         out[tied_a] = out[tied_b]
     return out
+
+
+# ----------------------------------------------------------------------------------
+# ASR sentence encoder: sentence-transformers/all-MiniLM-L6-v2 = a 6-layer BERT (extraction/whisper_ASR/extract_ASR_embedding.py:14)
+# in the Hugging Face BertModel checkpoint schema (the file sentence-transformers loads with AutoModel)
+# ----------------------------------------------------------------------------------
+
+MINILM_L6 = {"vocab_size": 30522, "hidden_size": 384, "num_hidden_layers": 6, "num_attention_heads": 12,
+             "intermediate_size": 1536, "max_position_embeddings": 512, "type_vocab_size": 2, "layer_norm_eps": 1e-12}
+MINILM_TINY = {"vocab_size": 700, "hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 2,
+               "intermediate_size": 128, "max_position_embeddings": 64, "type_vocab_size": 2, "layer_norm_eps": 1e-12}
+
+
+def bert_shapes(c: dict) -> Dict[str, Tuple[int, ...]]:
+    D, I = c["hidden_size"], c["intermediate_size"]
+    s = {"embeddings.word_embeddings.weight": (c["vocab_size"], D),
+         "embeddings.position_embeddings.weight": (c["max_position_embeddings"], D),
+         "embeddings.token_type_embeddings.weight": (c["type_vocab_size"], D),
+         "embeddings.LayerNorm.weight": (D,), "embeddings.LayerNorm.bias": (D,)}
+    for i in range(c["num_hidden_layers"]):
+        p = f"encoder.layer.{i}."
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            s[p + n + ".weight"] = (D, D)
+            s[p + n + ".bias"] = (D,)
+        s.update({p + "attention.output.LayerNorm.weight": (D,), p + "attention.output.LayerNorm.bias": (D,),
+                  p + "intermediate.dense.weight": (I, D), p + "intermediate.dense.bias": (I,),
+                  p + "output.dense.weight": (D, I), p + "output.dense.bias": (D,),
+                  p + "output.LayerNorm.weight": (D,), p + "output.LayerNorm.bias": (D,)})
+    s.update({"pooler.dense.weight": (D, D), "pooler.dense.bias": (D,)})   # in the checkpoint, unused by mean pooling
+    return s
+
+
+def bert_state_dict(c: dict, seed: int) -> Dict[str, torch.Tensor]:
+    return joint_state_dict(bert_shapes(c), seed)
+
+
+def sentence_ids(name: str, n: int, seed: int, vocab_size: int, min_len: int = 2, max_len: int = 40,
+                 cls_id: int = 101, sep_id: int = 102) -> list:
+    """n ragged rows [CLS] w.. [SEP] with lengths spread over [min_len, max_len] (min_len 2 = an empty subtitle)"""
+    u = (uniform_pm1(name + ".len", n, seed) + 1.0) * 0.5
+    rows = []
+    for r in range(n):
+        L = min_len + int(u[r] * (max_len - min_len + 1))
+        L = min(max(L, 2), max_len)
+        body = ((uniform_pm1(f"{name}.row{r}", L - 2, seed) + 1.0) * 0.5 * (vocab_size - 200)).astype(np.int64) + 200 if L > 2 \
+            else np.zeros(0, np.int64)
+        rows.append([cls_id] + [int(x) for x in body] + [sep_id])
+    return rows

@@ -563,6 +563,46 @@ def step_captioning_loss(sd: SD, vis, text, asr, moment_mask, input_ids, decoder
     return torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), output_ids.reshape(-1), ignore_index=-1)
 
 
+def sentence_embedding(sd: SD, ids: Sequence[int], heads: int, eps: float = 1e-12) -> torch.Tensor:
+    """One sentence through sentence-transformers/all-MiniLM-L6-v2 as extraction/whisper_ASR/extract_ASR_embedding.py:25,54 runs
+    it (``SentenceTransformer(...).encode``).  The model code is not under /root/reference: it is sentence-transformers==2.3.0
+    (requirements.txt:6) = transformers' BertModel -> mean pooling over the attention mask -> L2 normalise
+    (modules.json of the model: Transformer, Pooling(mean tokens), Normalize).  Restated from the published BERT equations
+    (post-LN encoder, erf GELU, scores / sqrt(dh), token type 0, absolute positions); pinned by tests/golden/minilm_*.npz, which
+    make_golden.py produced with the installed ``transformers.BertModel`` on padded batches (so the fixture also shows that the
+    padding + additive mask of a batch does not change a sentence's row).  ids: [CLS] ... [SEP] of ONE sentence -> [D]."""
+    E = "embeddings."
+    t = torch.as_tensor(ids, dtype=torch.int64)
+    L = t.numel()
+    x = sd[E + "word_embeddings.weight"][t] + sd[E + "token_type_embeddings.weight"][0] + sd[E + "position_embeddings.weight"][:L]
+    x = layer_norm(x, sd[E + "LayerNorm.weight"], sd[E + "LayerNorm.bias"], eps)
+    D = x.shape[1]
+    dh = D // heads
+    i = 0
+    while f"encoder.layer.{i}.attention.self.query.weight" in sd:
+        p = f"encoder.layer.{i}."
+        lin = lambda n, v: F.linear(v, sd[p + n + ".weight"], sd[p + n + ".bias"])
+        q = lin("attention.self.query", x).view(L, heads, dh).transpose(0, 1)
+        k = lin("attention.self.key", x).view(L, heads, dh).transpose(0, 1)
+        v = lin("attention.self.value", x).view(L, heads, dh).transpose(0, 1)
+        pr = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(dh), dim=-1)
+        ctx = (pr @ v).transpose(0, 1).reshape(L, D)
+        a = layer_norm(lin("attention.output.dense", ctx) + x, sd[p + "attention.output.LayerNorm.weight"],
+                       sd[p + "attention.output.LayerNorm.bias"], eps)
+        h = gelu_erf(lin("intermediate.dense", a))
+        x = layer_norm(lin("output.dense", h) + a, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
+        i += 1
+    pooled = x.sum(0) / max(float(L), 1e-9)
+    return pooled / pooled.norm().clamp_min(1e-12)
+
+
+def sentence_embeddings(sd: SD, rows: Sequence[Sequence[int]], heads: int) -> torch.Tensor:
+    D = sd["embeddings.LayerNorm.weight"].numel()
+    if not len(rows):
+        return torch.zeros((0, D))
+    return torch.stack([sentence_embedding(sd, r, heads) for r in rows])
+
+
 class RefBeam:
     """beam.py:31-123 restated on plain Python lists (scores are fp32 values)."""
 

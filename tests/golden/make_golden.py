@@ -525,6 +525,98 @@ PREPROCESS_CASES = [  # (name, H, W, size): 360p/720p/1080p video, portrait, 4:3
 ]
 
 
+def _import_transformers():
+    """transformers probes `torchvision` on import; the stub package that install_stubs() put first on sys.path (for the
+    reference's own `from torchvision.transforms import ...`) would answer that probe, so step around it while importing"""
+    stubs = [p for p in sys.path if os.path.basename(p).startswith("hirest_stubs_")]
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "torchvision" or k.startswith("torchvision.")}
+    for p in stubs:
+        sys.path.remove(p)
+    try:
+        from transformers import BertConfig, BertModel, BertTokenizer
+        BertModel(BertConfig(vocab_size=8, hidden_size=8, num_hidden_layers=1, num_attention_heads=1, intermediate_size=8))
+    finally:
+        for p in reversed(stubs):
+            sys.path.insert(0, p)
+        sys.modules.update(saved)
+    return BertConfig, BertModel, BertTokenizer
+
+
+def gen_minilm():
+    """ASR sentence encoder (extraction/whisper_ASR/extract_ASR_embedding.py:25,54).  sentence-transformers is not installed
+    offline, so the pipeline is driven by hand exactly as its three modules do: ``transformers.BertModel`` (the class its
+    Transformer module instantiates through AutoModel) on a padded batch with the attention mask, mean pooling over the mask,
+    L2 normalise.  Batches are the library's: sorted by length (longest first), 32 at a time, padded to the longest."""
+    BertConfig, BertModel, _ = _import_transformers()
+    for name, cfg, seed, n, max_len in (("minilm_tiny", synth.MINILM_TINY, 51, 40, 24), ("minilm_l6", synth.MINILM_L6, 52, 48, 256)):
+        sd = synth.bert_state_dict(cfg, seed)
+        model = BertModel(BertConfig(**cfg, hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0),
+                          add_pooling_layer=True).eval()
+        missing = model.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys and all("position_ids" in k or "token_type_ids" in k for k in missing.missing_keys), missing
+        rows = synth.sentence_ids(name, n, seed, cfg["vocab_size"], 2, max_len)
+        rows[0] = rows[0][:1] + rows[0][-1:]                    # an empty subtitle: [CLS] [SEP]
+        if max_len == 256:
+            rows[1] = synth.sentence_ids(name + ".long", 1, seed, cfg["vocab_size"], 256, 256)[0]   # the truncation length
+        order = sorted(range(n), key=lambda i: -len(rows[i]))
+        out = torch.zeros((n, cfg["hidden_size"]))
+        with torch.no_grad():
+            for s in range(0, n, 32):
+                idx = order[s:s + 32]
+                L = max(len(rows[i]) for i in idx)
+                ids = torch.zeros((len(idx), L), dtype=torch.int64)
+                mask = torch.zeros((len(idx), L), dtype=torch.int64)
+                for j, i in enumerate(idx):
+                    ids[j, :len(rows[i])] = torch.tensor(rows[i]); mask[j, :len(rows[i])] = 1
+                tok = model(input_ids=ids, attention_mask=mask).last_hidden_state
+                m = mask.unsqueeze(-1).float()
+                emb = (tok * m).sum(1) / m.sum(1).clamp(min=1e-9)
+                out[idx] = torch.nn.functional.normalize(emb, p=2, dim=1)
+        flat = np.concatenate([np.asarray(r, np.int64) for r in rows])
+        save(name + ".npz", ids=flat, lens=np.asarray([len(r) for r in rows], np.int64), seed=seed, emb=np32(out))
+
+
+WORDPIECE_TEXTS = [
+    "", "   ", "Hello, World!", "don't stop -- believin'", "Café déjà vu: naïve façade", "ÀÉÎÕÜ İstanbul straße",
+    "你好 world 世界", "tab\tand\nnewline\r\nmix", "ctrl\x00\x01char\ufffdgone", "e\u0301 combining", "price: $12.50 (approx.)",
+    "a" * 101, "b" * 100, "unknownword zzzqqq", "MiXeD CaSe ToKeNs", "emoji \U0001F600 here", "#hashtag @user 100%",
+    "so we're going to add the eggs, and then whisk", "[SEP] literal brackets [CLS]", "end.", "multiple     spaces",
+    "hyphen-ated words and under_score", "\u00a0nbsp\u2003emspace", "numbers 12345 67x89",
+]
+
+
+def gen_wordpiece(prompts):
+    """WordPiece ids of the installed transformers BERT tokenizer (do_lower_case=True) over a SYNTHETIC vocabulary (the real
+    30 522-entry vocab.txt is not available offline; the algorithm does not depend on which vocabulary it is given)."""
+    BertTokenizer = _import_transformers()[2]
+    words = {}
+    for t in prompts:
+        for w in t.lower().replace(",", " ").replace(".", " ").split():
+            words[w] = words.get(w, 0) + 1
+    common = [w for w, _ in sorted(words.items(), key=lambda kv: (-kv[1], kv[0])) if w.isalpha()][:400]
+    chars = [chr(c) for c in range(33, 127)] + list("àéîõüßıçñ") + ["你", "好", "世"]
+    chars = [c for c in chars if not ("A" <= c <= "Z")]
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    vocab += chars + ["##" + c for c in chars if c.isalnum()]
+    vocab += common + ["##ing", "##s", "##ed", "##er", "##ly", "##tion", "##es", "##re", "##ve", "##ll", "##n", "##t", "hello", "world",
+                       "cafe", "deja", "vu", "naive", "facade", "istanbul", "stra", "##sse", "mixed", "case", "token", "whisk",
+                       "eggs", "add", "going", "price", "approx", "b" * 100, "12", "##34", "##5", "hash", "##tag", "user", "100"]
+    seen, uniq = set(), []
+    for v in vocab:
+        if v not in seen:
+            seen.add(v); uniq.append(v)
+    # transformers >= 5: the BERT tokenizer is the tokenizers-library pipeline (BertNormalizer, BertPreTokenizer, WordPiece), i.e.
+    # what AutoTokenizer hands sentence-transformers under the reference's transformers==4.32.0 as BertTokenizerFast
+    tok = BertTokenizer(vocab={t: i for i, t in enumerate(uniq)}, do_lower_case=True)
+    texts = WORDPIECE_TEXTS + prompts[:60]
+    ids = [tok(t, truncation=True, max_length=256)["input_ids"] for t in texts]
+    short = [tok(t, truncation=True, max_length=8)["input_ids"] for t in texts]
+    with open(os.path.join(HERE, "wordpiece.json"), "w", encoding="utf-8") as f:
+        json.dump({"vocab": uniq, "texts": texts, "ids": ids, "ids_max8": short, "tokenizer": type(tok).__name__,
+                   "transformers": __import__("transformers").__version__}, f, ensure_ascii=True)
+    print("wrote wordpiece.json", len(texts), "texts", len(uniq), "vocab entries")
+
+
 def gen_preprocess():
     """image_transform(size) of eva_clip.py:125-153 executed with the real Pillow resampler and torchvision's
     Resize/CenterCrop/ToTensor/Normalize rules (torchvision itself is not installed; its size bookkeeping is restated
@@ -744,6 +836,8 @@ def main():
         "joint": gen_joint,
         "caption": gen_caption,
         "train": gen_train,
+        "minilm": gen_minilm,
+        "wordpiece": lambda: gen_wordpiece(prompts),
         "preprocess": gen_preprocess,
         "features": gen_features,
         "moment_eval": gen_moment_eval,

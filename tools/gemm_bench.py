@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--reverse", action="store_true", help="HIREST_GEMM_REVERSE: walk the tile list backwards")
     ap.add_argument("--a-scale", type=float, default=1.0, help="A = randn * scale + offset (does operand distribution move the time?)")
     ap.add_argument("--a-offset", type=float, default=0.0)
+    ap.add_argument("--w-scale", type=float, default=0.02, help="W = randn * scale; --a-scale 0 --w-scale 0 = all-zero operands: the "
+                    "same instruction stream with (almost) no switching activity in the matrix pipe, i.e. how far the power cap is "
+                    "from the kernel's own limit")
     a = ap.parse_args()
     for n, k, e in a.nk:
         SHAPES[f"n{n}k{k}e{e}"] = (n, k, e)
@@ -47,7 +50,7 @@ def main():
     for name in a.shapes:
         N, K, epi = SHAPES[name]
         A = (torch.randn((M, K + a.lda_pad), device=dev, generator=g) * a.a_scale + a.a_offset).to(torch.bfloat16)
-        W = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        W = (torch.randn((N, K), device=dev, generator=g) * a.w_scale).to(torch.bfloat16)
         bias = torch.randn((N,), device=dev, generator=g)
         out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32, _lib.EPI_BIAS_RESID_LNSTATS_F32) else torch.bfloat16)
         aux0 = aux1 = None
