@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
  EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16) = range(9)
 
 TOWER_NO_LNFOLD = 1
+GEMM_REVERSE = 1
 ABI_VERSION = 3   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
 
 ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}

@@ -776,8 +776,8 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     // ---- this block's tile list: XCD (bid & 7) owns M panels [p_lo, p_lo+np); its CUs take every nslot-th tile
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3, nslot = gridDim.x >> 3;
-    const int p_lo = xcd * p.ppx;
-    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    int p_lo, np;
+    xcd_panels(p, xcd, p_lo, np);
     if (np <= 0) return;
     // Work list of the XCD = units, unit j goes to CU slot j % nslot.  The ~32 tiles in flight form a patch (a panels x
     // b column tiles) whose operand lines are shared through the XCD's L2:
@@ -1003,8 +1003,8 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3, nslot = gridDim.x >> 3;
-    const int p_lo = xcd * p.ppx;
-    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    int p_lo, np;
+    xcd_panels(p, xcd, p_lo, np);
     if (np <= 0) return;
     const bool panel_major = p.nbn <= 8;
     const int nunit = np * p.nbn;
@@ -1389,7 +1389,8 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.pos = a->pos; p.P = a->patches_per_frame;
     p.aux0 = a->aux0; p.aux1 = a->aux1;
     p.rev = ((a->flags & HIREST_GEMM_REVERSE) && !(g_gemm_dbg & 512)) ? 1 : 0;   // debug bit 9: ignore the direction flags (A/B)
-    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000);
+    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x10000);
+    p.sched = (g_gemm_dbg >> 16) & 1;
     p.stagger = (g_gemm_dbg >> 10) & 3;
     p.epi_dbg = (g_gemm_dbg >> 12) & 15;   // A/B experiment: start the CUs of an XCD 0..3 quarter tiles apart (bits 10-11 = mode)
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;

@@ -18,10 +18,17 @@ struct GemmP {
     int nbm, nbn, ppx;   // tile counts, M-panels per XCD
     int epi_dbg;         // timing experiment (hirest_gemm_debug_mode bits 12-15): LN-statistics epilogue without its bit0 residual read, bit1 f32 store, bit2 bf16 copy, bit3 row sums
     int stagger;         // timing experiment (hirest_gemm_debug_mode bits 10-11): staggered start of the CUs
+    int sched;           // A/B switches of the tile schedule (hirest_gemm_debug_mode bit 16): uneven XCD split (ceil(nbm / 8) panels each)
     int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
 };
 
 constexpr int GROUP_M = 8;                        // M-panels walked together inside one XCD
+// M panels of XCD x: an even split, [x nbm / 8, (x + 1) nbm / 8) (1028 panels = 4 x 129 + 4 x 128, not 7 x 129 + 125)
+__device__ __forceinline__ void xcd_panels(const GemmP& p, int xcd, int& p_lo, int& np) {
+    if (p.sched & 1) { p_lo = xcd * p.ppx; np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np; return; }   // A/B: the old split
+    p_lo = (int)(((long long)xcd * p.nbm) >> 3);
+    np = (int)(((long long)(xcd + 1) * p.nbm) >> 3) - p_lo;
+}
 constexpr int T_BM = 256, T_BN = 256;
 #define HX_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define HX_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

@@ -30,6 +30,7 @@ def main():
                     "kernel-structure ceiling without the memory system")
     ap.add_argument("--hipblaslt", action="store_true", help="also time torch.mm (hipBLASLt, no epilogue) as a yardstick")
     ap.add_argument("--lda-pad", type=int, default=0, help="extra elements in A's row stride (L2 set-conflict experiment)")
+    ap.add_argument("--ldw-pad", type=int, default=0, help="extra elements in W's row stride")
     ap.add_argument("--dbg", type=int, default=0, help="hirest_gemm_debug_mode bits (timing experiments)")
     ap.add_argument("--nk", type=int, nargs=3, action="append", default=[], metavar=("N", "K", "EPI"),
                     help="extra shape (repeatable), named n<N>k<K>e<EPI>")
@@ -50,7 +51,7 @@ def main():
     for name in a.shapes:
         N, K, epi = SHAPES[name]
         A = (torch.randn((M, K + a.lda_pad), device=dev, generator=g) * a.a_scale + a.a_offset).to(torch.bfloat16)
-        W = (torch.randn((N, K), device=dev, generator=g) * a.w_scale).to(torch.bfloat16)
+        W = (torch.randn((N, K + a.ldw_pad), device=dev, generator=g) * a.w_scale).to(torch.bfloat16)
         bias = torch.randn((N,), device=dev, generator=g)
         out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32, _lib.EPI_BIAS_RESID_LNSTATS_F32) else torch.bfloat16)
         aux0 = aux1 = None
@@ -65,10 +66,10 @@ def main():
         lib = _lib.load()
 
         def run():
-            if not a.alias and not a.lda_pad:
+            if not a.alias and not a.lda_pad and not a.ldw_pad:
                 return ops.gemm(A, W, bias, out, epi, aux0=aux0, aux1=aux1, flags=1 if a.reverse else 0)
             lda = 0 if a.alias else K + a.lda_pad
-            args = _lib.GemmArgs.make(A.data_ptr(), lda, W.data_ptr(), 0 if a.alias else K, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
+            args = _lib.GemmArgs.make(A.data_ptr(), lda, W.data_ptr(), 0 if a.alias else K + a.ldw_pad, bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, None, 0)
             _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "gemm")
         for v in a.variants:
             ops.gemm_select_kernel(v)
@@ -81,9 +82,10 @@ def main():
                 run()
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
-            print(f"{'[alias] ' if a.alias else ''}{'[dbg%d] ' % a.dbg if a.dbg else ''}{'[lda+%d] ' % a.lda_pad if a.lda_pad else ''}{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+            print(f"{'[alias] ' if a.alias else ''}{'[dbg%d] ' % a.dbg if a.dbg else ''}{'[lda+%d ldw+%d] ' % (a.lda_pad, a.ldw_pad) if a.lda_pad or a.ldw_pad else ''}{name:11s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
         if a.hipblaslt:
-            Wt = W.t()
+            Wt = W[:N, :K].t()
+            A = A[:, :K] if a.lda_pad else A
             for _ in range(2):
                 torch.mm(A, Wt)
             torch.cuda.synchronize()
