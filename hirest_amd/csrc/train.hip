@@ -37,24 +37,39 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     }
 }
 
-// out[c] = sum_r w(r) x[r][c],  w(r) = (wt ? wt[r] : 1) * (sel ? sel[r] == sel_value : 1).  grid.x covers columns in
-// blocks of 64, 4 waves split the rows, LDS reduce.
-__global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
-                                                              const int32_t* __restrict__ sel, int sel_value, int R, int C,
-                                                              float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < C)
-        for (int r = wave; r < R; r += 4) {
-            float w = wt ? wt[r] : 1.f;
-            if (sel && sel[r] != sel_value) w = 0.f;
-            s = fmaf(w, x[(int64_t)r * ldx + c], s);
+// out[c] = sum_r w(r) x[r][c],  w(r) = (wt ? wt[r] : 1) * (sel ? sel[r] == sel_value : 1).  One block per 32 columns (a row
+// segment = one 128-B line), 32 row lanes of 32 threads, four independent partial sums per thread so that four rows are in
+// flight per lane, then a fixed-order LDS reduction over the row lanes (deterministic: no atomics).
+__global__ __launch_bounds__(1024) void weighted_colsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
+                                                               const int32_t* __restrict__ sel, int sel_value, int R, int C,
+                                                               float* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    auto wgt = [&](int r) -> float {
+        float w = wt ? wt[r] : 1.f;
+        if (sel && sel[r] != sel_value) w = 0.f;
+        return w;
+    };
+    if (c < C) {
+        int r = rl;
+        for (; r + 96 < R; r += 128) {
+            const float x0 = x[(int64_t)r * ldx + c], x1 = x[(int64_t)(r + 32) * ldx + c];
+            const float x2 = x[(int64_t)(r + 64) * ldx + c], x3 = x[(int64_t)(r + 96) * ldx + c];
+            s0 = fmaf(wgt(r), x0, s0); s1 = fmaf(wgt(r + 32), x1, s1);
+            s2 = fmaf(wgt(r + 64), x2, s2); s3 = fmaf(wgt(r + 96), x3, s3);
         }
-    red[wave][lane] = s;
+        for (; r < R; r += 32) s0 = fmaf(wgt(r), x[(int64_t)r * ldx + c], s0);
+    }
+    red[rl][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && c < C) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (rl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][col];
+        out[c] = t;
+    }
 }
 
 __device__ __forceinline__ float gelu_grad(float x) {      // d/dx [x Phi(x)] = Phi(x) + x phi(x)
@@ -372,7 +387,7 @@ extern "C" int hirest_transpose_pad_f32(const float* in, int64_t ld_in, int32_t 
 extern "C" int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const float* row_weight, const int32_t* row_select,
                                           int32_t select_value, int32_t R, int32_t C, float* out, void* stream) {
     if (!x || !out || R <= 0 || C <= 0) return HIREST_E_BADARG;
-    hipLaunchKernelGGL(weighted_colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, S_(stream), x, ldx, row_weight, row_select,
+    hipLaunchKernelGGL(weighted_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, S_(stream), x, ldx, row_weight, row_select,
                        select_value, R, C, out);
     return hirest_launch_status();
 }

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Joint-model training step timing: train_step -> backward -> clip_grad_norm_ -> AdamW at B = 5 (args.py default
+batch) and the C4 frame counts, per task, next to the fp32 CPU oracle under torch autograd (the same loss restated in
+oracle/ref_cpu.py, 32 threads).   python tools/train_bench.py [--frames 120 300 571]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import hirest_amd  # noqa: E402
+from hirest_amd import synth  # noqa: E402
+from make_golden import joint_inputs, train_targets, caption_targets  # noqa: E402
+from oracle import ref_cpu as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, nargs="*", default=[120, 300, 571])
+    ap.add_argument("--batch", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", "joint_schema.json"))).items()}
+    sd = synth.joint_state_dict(shapes, 31)
+    dev = torch.device("cuda:0")
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    B = a.batch
+    for T in a.frames:
+        vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"tb.{T}", B, T, 61)
+        st, et, seg, prev = train_targets(f"tb.{T}", B, T, 61, bounds)
+        cap_mask = torch.zeros(B, T, dtype=torch.long)
+        for b_ in range(B):
+            cap_mask[b_, 10 + b_:10 + b_ + 15 + 3 * b_] = 1
+        common = {"vis_feats": vis, "vis_mask": vis_mask, "asr_feats": asr, "text_feat": text}
+        batches = {
+            "moment_retrieval": dict(common, tasks=["moment_retrieval"], moment_mask=moment_mask, moment_retrieval_start_target=st,
+                                     moment_retrieval_end_target=et),
+            "moment_segmentation": dict(common, tasks=["moment_segmentation"], moment_mask=moment_mask, prev_boundary_mask=prev,
+                                        moment_segmentation_target=seg),
+            "step_captioning": dict(common, tasks=["step_captioning"], moment_mask=cap_mask,
+                                    target_text=caption_targets(f"tb.{T}", B, 48, 61)),
+        }
+        line = f"T={T:4d} B={B}:"
+        for task, batch in batches.items():
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = model.train_step(batch)["loss"]
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+                return loss
+            step(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.reps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / a.reps
+            line += f"  {task} {dt * 1e3:6.1f} ms/step ({B / dt:6.0f} videos/s)"
+        print(line, flush=True)
+        if T <= 300:   # CPU oracle under autograd, retrieval loss only (the other two scale alike)
+            psd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+            t0 = time.perf_counter()
+            loss = O.moment_retrieval_loss(psd, vis, text, asr, vis_mask, moment_mask, st, et)
+            loss.backward()
+            dt = time.perf_counter() - t0
+            print(f"        CPU oracle + torch autograd ({torch.get_num_threads()} threads), moment_retrieval forward + backward: "
+                  f"{dt * 1e3:.0f} ms ({B / dt:.1f} videos/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
