@@ -340,6 +340,9 @@ def test_eva_g14_full_size_vs_reference(dev, golden_dir):
     assert (of[spots[:2]] - out).abs().max().item() < 2e-2 * out.abs().max().item()
     model.visual.max_frames_per_call = 384                      # 384 + 384 + 256: ragged micro-batches
     assert torch.equal(model.encode_image(full), of)
+    # a call twice the bench size (activations past 2^32 bytes: 64-bit addressing everywhere) reproduces the same rows
+    model.visual.max_frames_per_call = 2048
+    assert torch.equal(model.encode_image(torch.cat([full, full.flip(0)], 0)), torch.cat([of, of.flip(0)], 0))
     # calls of >= 64 frames fold both LayerNorms of a block into its GEMMs (HIREST_EPI_LNFOLD_*); the plain path
     # (LayerNorm kernel + plain epilogues) on the same batch agrees within the bf16 rounding of the LayerNorm output
     # and meets the same bar against the reference's outputs; both are deterministic
