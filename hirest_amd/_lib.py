@@ -90,6 +90,7 @@ _SIGNATURES = {
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hirest_pool_l2norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_pool_l2norm_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_similarity_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_topk_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "hirest_topk_f32_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -102,6 +103,8 @@ _SIGNATURES = {
                                        C.c_float, C.c_void_p]),
     "hirest_attention_f32_qkv": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hirest_attention_f32_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                              C.c_float, C.c_void_p]),
     "hirest_log_softmax_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_joint_time_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_void_p]),
@@ -126,6 +129,7 @@ _SIGNATURES = {
                                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                                      C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "hirest_embedding_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_embedding_pos_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "hirest_embedding_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "hirest_ce_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hirest_bce_masked_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -103,7 +103,8 @@ constexpr int ADH = 64, ALD = ADH + 1;
 
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
                                                            const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
-                                                           int Tq, int T, int H, float scale, float add_const, float causal_penalty) {
+                                                           int Tq, int T, int H, float scale, float add_const, float causal_penalty,
+                                                           const int32_t* __restrict__ seq_off) {
     __shared__ float Ks[32 * ALD];
     __shared__ float Vs[32 * ALD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,9 +113,15 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
     const int b = bh / H, h = bh - b * H;
     const int D = H * ADH;
-    const float* qbase = qp + (int64_t)b * Tq * ldq + h * ADH;
-    const float* kbase = kp + (int64_t)b * T * ldkv + h * ADH;
-    const float* vbase = vp + (int64_t)b * T * ldkv + h * ADH;
+    int64_t qrow0 = (int64_t)b * Tq, krow0 = (int64_t)b * T;
+    if (seq_off) {   // packed ragged self-attention: sequence b = rows seq_off[b] .. seq_off[b+1]; Tq was only the longest one
+        qrow0 = krow0 = seq_off[b];
+        Tq = T = seq_off[b + 1] - seq_off[b];
+        if (qb * 128 >= Tq) return;                       // (block-uniform)
+    }
+    const float* qbase = qp + qrow0 * ldq + h * ADH;
+    const float* kbase = kp + krow0 * ldkv + h * ADH;
+    const float* vbase = vp + krow0 * ldkv + h * ADH;
     const int q = qb * 128 + wave * 32 + l31;
     const bool qvalid = q < Tq;
     // Q^T fragments: B operand [k = d][j = query]: lane holds Q[q][2s + half] for s = 0..31
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     }
     if (!qvalid) return;
     const float inv = 1.0f / lrun;
-    float* orow = out + ((int64_t)b * Tq + q) * D + h * ADH;
+    float* orow = out + (qrow0 + q) * D + h * ADH;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {   // O^T rows (reg&3) + 8*(reg>>2) + 4*half = d
         const int d = 8 * g + 4 * half;
@@ -404,7 +411,18 @@ extern "C" int hirest_attention_f32(const float* qkv, float* out, int32_t B, int
     const int64_t ld = 3 * (int64_t)H * ADH;
     const int qblocks = (T + 127) / 128;
     hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, ld,
-                       qkv + H * ADH, qkv + 2 * H * ADH, ld, out, T, T, H, scale, add_const, 0.f);
+                       qkv + H * ADH, qkv + 2 * H * ADH, ld, out, T, T, H, scale, add_const, 0.f, nullptr);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_f32_varlen(const float* qkv, float* out, const int32_t* seq_off, int32_t B, int32_t max_len, int32_t H,
+                                           int32_t dh, float scale, float add_const, void* stream) {
+    if (!qkv || !out || !seq_off || B <= 0 || max_len <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh != ADH) return HIREST_E_SHAPE;
+    const int64_t ld = 3 * (int64_t)H * ADH;
+    const int qblocks = (max_len + 127) / 128;
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, ld,
+                       qkv + H * ADH, qkv + 2 * H * ADH, ld, out, max_len, max_len, H, scale, add_const, 0.f, seq_off);
     return hirest_launch_status();
 }
 
@@ -415,7 +433,7 @@ extern "C" int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float
     if (dh != ADH || ldq % 4 != 0 || ldkv % 4 != 0) return HIREST_E_SHAPE;
     const int qblocks = (Tq + 127) / 128;
     hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
-                       ldkv, out, Tq, Tk, H, scale, add_const, causal_penalty);
+                       ldkv, out, Tq, Tk, H, scale, add_const, causal_penalty, nullptr);
     return hirest_launch_status();
 }
 

@@ -18,12 +18,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // one block per video
 __global__ __launch_bounds__(256) void pool_l2_kernel(const float* __restrict__ fe, float* __restrict__ out, int F, int E,
-                                                     int norm_first) {
+                                                     int norm_first, const int32_t* __restrict__ seg_off) {
     extern __shared__ float sm[];          // [F] per-frame norms, then [8] reduction scratch
     float* fnorm = sm;
-    float* red = sm + F;
+    float* red = sm + (seg_off ? 0 : F);
     const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* base = fe + (int64_t)v * F * E;
+    if (seg_off) {                         // ragged segments of a packed [rows, E] matrix (never with norm_first)
+        base = fe + (int64_t)seg_off[v] * E;
+        F = seg_off[v + 1] - seg_off[v];
+        if (F <= 0) {                      // an empty segment has no mean: zeros
+            for (int c = tid; c < E; c += 256) out[(int64_t)v * E + c] = 0.f;
+            return;
+        }
+    }
     if (norm_first) {
         for (int f = wave; f < F; f += 4) {
             float s = 0.f;
@@ -236,7 +244,15 @@ extern "C" int hirest_pool_l2norm(const float* frame_embeds, float* out, int32_t
     if (E % 4 != 0 || F > 8192) return HIREST_E_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(pool_l2_kernel, dim3(V), dim3(256), (F + 8) * sizeof(float), s, frame_embeds, out, F, E,
-                       normalize_frames_first);
+                       normalize_frames_first, nullptr);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_pool_l2norm_varlen(const float* rows, const int32_t* seg_off, float* out, int32_t V, int32_t E, void* stream) {
+    if (!rows || !seg_off || !out || V <= 0 || E <= 0) return HIREST_E_BADARG;
+    if (E % 4 != 0) return HIREST_E_SHAPE;
+    hipLaunchKernelGGL(pool_l2_kernel, dim3(V), dim3(256), 8 * sizeof(float), reinterpret_cast<hipStream_t>(stream), rows, out, 0, E, 0,
+                       seg_off);
     return hirest_launch_status();
 }
 

@@ -230,12 +230,13 @@ __global__ __launch_bounds__(64) void attention_train_bwd_kv_kernel(AttnT a, con
 
 // x[r] = table[ids[r]] + pos[r % T]   (DecoderEmbeddings, module_decoder.py:309-321) and its scatter-add backward
 __global__ void embedding_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table, const float* __restrict__ pos,
-                                     float* __restrict__ out, int64_t rows, int T, int D) {
+                                     float* __restrict__ out, int64_t rows, int T, int D, const int32_t* __restrict__ pos_ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * D) return;
     const int64_t r = i / D;
     const int c = i - r * D;
-    out[i] = table[(int64_t)ids[r] * D + c] + pos[(int64_t)(r % T) * D + c];
+    const int64_t pr = pos_ids ? pos_ids[r] : r % T;     // explicit positions: packed ragged sequences
+    out[i] = table[(int64_t)ids[r] * D + c] + pos[pr * D + c];
 }
 __global__ void embedding_bwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dx, float* __restrict__ dtable,
                                      int64_t rows, int D) {
@@ -461,7 +462,14 @@ extern "C" int hirest_attention_train_bwd_f32(const float* qkv, const float* P, 
 extern "C" int hirest_embedding_fwd_f32(const int32_t* ids, const float* table, const float* pos, float* out, int64_t rows, int32_t T,
                                         int32_t D, void* stream) {
     if (!ids || !table || !pos || !out || rows <= 0 || T <= 0 || D <= 0) return HIREST_E_BADARG;
-    hipLaunchKernelGGL(embedding_fwd_kernel, grid1(rows * D), dim3(256), 0, S_(stream), ids, table, pos, out, rows, T, D);
+    hipLaunchKernelGGL(embedding_fwd_kernel, grid1(rows * D), dim3(256), 0, S_(stream), ids, table, pos, out, rows, T, D, nullptr);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_embedding_pos_fwd_f32(const int32_t* ids, const int32_t* pos_ids, const float* table, const float* pos, float* out,
+                                            int64_t rows, int32_t D, void* stream) {
+    if (!ids || !pos_ids || !table || !pos || !out || rows <= 0 || D <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(embedding_fwd_kernel, grid1(rows * D), dim3(256), 0, S_(stream), ids, table, pos, out, rows, 1, D, pos_ids);
     return hirest_launch_status();
 }
 

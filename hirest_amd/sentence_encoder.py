@@ -14,9 +14,11 @@ sentence's tokens -> L2 normalise, i.e. sentence-transformers==2.3.0's Transform
 ``transformers.BertModel``: tests/golden/minilm_*.npz).
 
 MI355X side: exact fp32 on the joint model's kernels (`hirest_gemm_f32` = v_mfma_f32_32x32x2_f32 with fused bias / GELU / residual
-epilogues, `hirest_attention_f32`, `hirest_layernorm`, `hirest_embedding_fwd_f32`, `hirest_pool_l2norm`).  Sentences are grouped
-by token count, so no padding, no attention mask and no wasted rows exist: the library pads a batch to its longest sentence and
-masks the pad keys with an additive -inf-like constant, which gives pad keys probability exactly 0 — the same numbers.  Heads
+epilogues, `hirest_layernorm`, and the ragged forms `hirest_attention_f32_varlen`, `hirest_embedding_pos_fwd_f32`,
+`hirest_pool_l2norm_varlen`).  All sentences of a call are packed row after row into one [tokens, hidden] activation: every GEMM and
+LayerNorm is a single launch over all tokens, attention and pooling follow a prefix-offset table — no padding, no attention mask and
+no wasted rows exist.  The library pads a batch to its longest sentence and masks the pad keys with an additive -inf-like constant,
+which gives pad keys probability exactly 0 — the same numbers.  Heads
 narrower than the attention kernel's 64 lanes are zero-padded inside the fused QKV / output weights (exact: the pad lanes add 0).
 There is no CPU path: `encode` raises off-GPU.
 """
@@ -159,46 +161,57 @@ class SentenceTransformer(nn.Module):
     def _ln(self, x, w, b):
         return ops.layernorm(x, w, b, self.eps, torch.empty_like(x))
 
-    def _encode_group(self, ids: torch.Tensor, B: int, L: int) -> torch.Tensor:
-        """B sentences of exactly L tokens (ids int32 [B*L] on the device) -> [B, hidden] unit rows"""
+    def _encode_packed(self, ids: torch.Tensor, pos_ids: torch.Tensor, seq_off: torch.Tensor, n: int, max_len: int) -> torch.Tensor:
+        """n ragged sentences packed row after row (ids / pos_ids int32 [tokens], seq_off int32 [n + 1], all on the device)
+        -> [n, hidden] unit rows.  Every GEMM / LayerNorm runs once over all tokens; only attention and pooling know sentences."""
         c, lib = self._w(), _lib.load()
-        D, H = self.hidden, self.heads
-        x = torch.empty((B * L, D), dtype=torch.float32, device=ids.device)
-        _lib.check(lib.hirest_embedding_fwd_f32(ids.data_ptr(), c["word"].data_ptr(), c["pos"].data_ptr(), x.data_ptr(), B * L, L, D,
-                                                ops.stream_ptr()), "hirest_embedding_fwd_f32")
+        D, H, rows = self.hidden, self.heads, ids.numel()
+        x = torch.empty((rows, D), dtype=torch.float32, device=ids.device)
+        _lib.check(lib.hirest_embedding_pos_fwd_f32(ids.data_ptr(), pos_ids.data_ptr(), c["word"].data_ptr(), c["pos"].data_ptr(),
+                                                    x.data_ptr(), rows, D, ops.stream_ptr()), "hirest_embedding_pos_fwd_f32")
         x = self._ln(x, c["eln_w"], c["eln_b"])
         for i in range(self.layers):
             p = f"encoder.layer.{i}."
             qkv = self._gemm(x, c[f"qkv_w.{i}"], c[f"qkv_b.{i}"])
-            ctx = torch.empty((B * L, H * _AH), dtype=torch.float32, device=x.device)
-            _lib.check(lib.hirest_attention_f32(qkv.data_ptr(), ctx.data_ptr(), B, L, H, _AH, self.dh ** -0.5, 0.0, ops.stream_ptr()),
-                       "hirest_attention_f32")
+            ctx = torch.empty((rows, H * _AH), dtype=torch.float32, device=x.device)
+            _lib.check(lib.hirest_attention_f32_varlen(qkv.data_ptr(), ctx.data_ptr(), seq_off.data_ptr(), n, max_len, H, _AH,
+                                                       self.dh ** -0.5, 0.0, ops.stream_ptr()), "hirest_attention_f32_varlen")
             a = self._gemm(ctx, c[f"o_w.{i}"], c[p + "attention.output.dense.bias"], resid=x)
             a = self._ln(a, c[p + "attention.output.LayerNorm.weight"], c[p + "attention.output.LayerNorm.bias"])
             h = self._gemm(a, c[p + "intermediate.dense.weight"], c[p + "intermediate.dense.bias"], act=1)
             y = self._gemm(h, c[p + "output.dense.weight"], c[p + "output.dense.bias"], resid=a)
             x = self._ln(y, c[p + "output.LayerNorm.weight"], c[p + "output.LayerNorm.bias"])
-        return ops.pool_l2norm(x.view(B, L, D))           # mean over the L tokens, then L2: Pooling(mean) + Normalize
+        out = torch.empty((n, D), dtype=torch.float32, device=x.device)   # mean over a sentence's tokens, then L2: Pooling + Normalize
+        _lib.check(lib.hirest_pool_l2norm_varlen(x.data_ptr(), seq_off.data_ptr(), out.data_ptr(), n, D, ops.stream_ptr()),
+                   "hirest_pool_l2norm_varlen")
+        return out
 
     @torch.no_grad()
-    def encode_ids(self, rows: Sequence[Sequence[int]]) -> torch.Tensor:
+    def encode_ids(self, rows: Sequence[Sequence[int]], max_tokens_per_pass: int = 1 << 18) -> torch.Tensor:
         """Ragged token-id rows ([CLS] ... [SEP] each, already truncated) -> [N, hidden] fp32 on the model's device."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("hirest_amd.SentenceTransformer runs on MI355X only (no CPU fallback); move the model to a GPU")
+        maxpos, vocab = self.config["max_position_embeddings"], self.config["vocab_size"]
         out = torch.empty((len(rows), self.hidden), dtype=torch.float32, device=dev)
-        by_len: Dict[int, List[int]] = {}
-        for i, r in enumerate(rows):
-            if not 1 <= len(r) <= self.config["max_position_embeddings"]:
-                raise ValueError(f"sentence {i}: {len(r)} tokens (1 .. {self.config['max_position_embeddings']})")
-            by_len.setdefault(len(r), []).append(i)
         with torch.cuda.device(dev):
-            for L, idx in sorted(by_len.items()):
-                ids = torch.tensor([rows[i] for i in idx], dtype=torch.int32).reshape(-1)
-                if int(ids.min()) < 0 or int(ids.max()) >= self.config["vocab_size"]:
+            s = 0
+            while s < len(rows):
+                e, tokens = s, 0
+                while e < len(rows) and (e == s or tokens + len(rows[e]) <= max_tokens_per_pass):
+                    if not 1 <= len(rows[e]) <= maxpos:
+                        raise ValueError(f"sentence {e}: {len(rows[e])} tokens (1 .. {maxpos})")
+                    tokens += len(rows[e]); e += 1
+                lens = torch.tensor([len(r) for r in rows[s:e]], dtype=torch.int64)
+                ids = torch.tensor([t for r in rows[s:e] for t in r], dtype=torch.int32)
+                if int(ids.min()) < 0 or int(ids.max()) >= vocab:
                     raise ValueError("token id outside the vocabulary")
-                emb = self._encode_group(ids.to(dev), len(idx), L)
-                out[torch.tensor(idx, device=dev)] = emb
+                off = torch.zeros(e - s + 1, dtype=torch.int64)
+                off[1:] = torch.cumsum(lens, 0)
+                pos = torch.arange(tokens, dtype=torch.int64) - torch.repeat_interleave(off[:-1], lens)
+                out[s:e] = self._encode_packed(ids.to(dev), pos.to(torch.int32).to(dev), off.to(torch.int32).to(dev), e - s,
+                                               int(lens.max()))
+                s = e
         return out
 
     def tokenize(self, sentences: Sequence[str]) -> List[List[int]]:

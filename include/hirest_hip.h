@@ -185,6 +185,9 @@ int hirest_f32_to_bf16(const float* in, hirest_bf16* out, int64_t n, void* strea
 /* [V,F,E] f32 -> [V,E] f32: (optional per-frame L2) -> mean over F -> L2.  F==1 is plain L2. */
 int hirest_pool_l2norm(const float* frame_embeds, float* out, int32_t V, int32_t F, int32_t E,
                        int32_t normalize_frames_first, void* stream);
+/* ragged form: out[v] = L2-normalised mean of rows seg_off[v] .. seg_off[v+1] of a packed [rows, E] matrix (seg_off: V + 1 device
+ * ints; an empty segment gives zeros).  sentence-transformers' Pooling(mean over the attention mask) + Normalize. */
+int hirest_pool_l2norm_varlen(const float* rows, const int32_t* seg_off, float* out, int32_t V, int32_t E, void* stream);
 
 /* scores[q][v] = <T[q], Vn[v]> in fp32 FMA arithmetic. */
 int hirest_similarity_f32(const float* text_n, const float* video_n, float* scores,
@@ -286,6 +289,11 @@ int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int
 int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out,
                              int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, float add_const,
                              float causal_penalty, void* stream);
+/* Packed ragged self-attention: sequence b occupies rows seq_off[b] .. seq_off[b+1] of qkv / out (seq_off: B + 1 device ints,
+ * max_len >= the longest sequence).  No padding rows and no key mask exist; a library that pads to the longest sequence and adds a
+ * -inf-like mask on the pad keys computes the same numbers (the ASR sentence encoder, hirest_amd/sentence_encoder.py). */
+int hirest_attention_f32_varlen(const float* qkv, float* out, const int32_t* seq_off, int32_t B, int32_t max_len, int32_t H,
+                                int32_t dh, float scale, float add_const, void* stream);
 /* out[r][:] = log_softmax(x[r][:]) + row_add[r]  (train.py:563-564 + the beam score add of beam.py:76); row_add may be NULL */
 int hirest_log_softmax_f32(const float* x, int64_t ldx, const float* row_add, float* out, int64_t ldo, int32_t rows,
                            int32_t V, void* stream);
@@ -345,6 +353,9 @@ int hirest_attention_train_bwd_qkv_f32(const float* q, int64_t ldq, const float*
  * (atomic adds into a zeroed or pre-filled [vocab, D] buffer: the table is tied to the LM head, whose dW is already there) */
 int hirest_embedding_fwd_f32(const int32_t* ids, const float* table, const float* pos, float* out, int64_t rows, int32_t T,
                              int32_t D, void* stream);
+/* the same with explicit position rows: out[r] = table[ids[r]] + pos[pos_ids[r]]  (packed ragged sequences) */
+int hirest_embedding_pos_fwd_f32(const int32_t* ids, const int32_t* pos_ids, const float* table, const float* pos, float* out,
+                                 int64_t rows, int32_t D, void* stream);
 int hirest_embedding_bwd_f32(const int32_t* ids, const float* dx, float* dtable_accum, int64_t rows, int32_t D, void* stream);
 /* CrossEntropyLoss(ignore_index = -1) over R rows of V logits (row stride ld): *loss_accum += weight * mean over the n_valid rows
  * with target >= 0; dlogits = its gradient (ignored rows: zeros).  modeling.py:140, 519 */

@@ -29,7 +29,7 @@ def main():
     for _ in range(3):
         t0 = time.perf_counter(); out = m.encode_ids(rows); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     toks = sum(map(len, rows))
-    print(f"GPU: {a.sentences} sentences ({toks} tokens, {len(set(map(len, rows)))} length groups) in {best * 1e3:.1f} ms = "
+    print(f"GPU: {a.sentences} sentences ({toks} tokens, lengths {min(map(len, rows))}..{max(map(len, rows))}) in {best * 1e3:.1f} ms = "
           f"{a.sentences / best:.0f} sentences/s, {toks / best / 1e3:.0f} k tokens/s")
     from oracle import ref_cpu
     torch.set_num_threads(min(32, os.cpu_count() or 1))
