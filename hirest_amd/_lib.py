@@ -103,6 +103,7 @@ _SIGNATURES = {
                                        C.c_float, C.c_void_p]),
     "hirest_attention_f32_qkv": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hirest_gemm_f32_select_kernel": (C.c_int, [C.c_int32]),
     "hirest_attention_f32_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                               C.c_float, C.c_void_p]),
     "hirest_log_softmax_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

@@ -41,11 +41,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     int gn = N0 + srow; gn = gn < p.N ? gn : p.N - 1;
     const float* ap = p.A + (int64_t)gm * p.lda + sk;
     const float* wp = p.W + (int64_t)gn * p.ldw + sk;
-    f32x16 acc;
+    // Summation order (shared with gemm_f32_skinny_kernel below, so that a row's result does not depend on how many rows the call
+    // has): slab s = k0 / 32 goes to partial sum s & 3; inside a slab MFMA step j pairs k0 + j (lanes < 32) with k0 + 16 + j
+    // (lanes >= 32); the four partial sums are added as ((p0 + p1) + p2) + p3.
+    f32x16 part[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int arow = (wm * 32 + (lane & 31)) * FLD + (lane >> 5);
-    const int wrow = (wn * 32 + (lane & 31)) * FLD + (lane >> 5);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[u][e] = 0.f;
+    const int arow = (wm * 32 + (lane & 31)) * FLD + 16 * (lane >> 5);
+    const int wrow = (wn * 32 + (lane & 31)) * FLD + 16 * (lane >> 5);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int k0, f32x4 (&av)[2], f32x4 (&wv)[2]) {
 #pragma unroll
@@ -57,23 +62,103 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     };
     f32x4 av[2], wv[2];
     fetch(0, av, wv);
-    for (int k0 = 0; k0 < p.K; k0 += FK) {
-        __syncthreads();
+    for (int kb = 0; kb < p.K; kb += 4 * FK) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int u = 0; u < 4; ++u) {
+            const int k0 = kb + u * FK;
+            if (k0 >= p.K) break;                              // (block-uniform)
+            __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { As[srow * FLD + sk + 4 * h + e] = av[h][e]; Ws[srow * FLD + sk + 4 * h + e] = wv[h][e]; }
-        __syncthreads();
-        if (k0 + FK < p.K) fetch(k0 + FK, av, wv);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int kk = 0; kk < FK; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + kk], As[arow + kk], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) { As[srow * FLD + sk + 4 * h + e] = av[h][e]; Ws[srow * FLD + sk + 4 * h + e] = wv[h][e]; }
+            __syncthreads();
+            if (k0 + FK < p.K) fetch(k0 + FK, av, wv);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                part[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + j], As[arow + j], part[u], 0, 0, 0);
+        }
     }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
     const int m = M0 + wm * 32 + (lane & 31);
     if (m >= p.M) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int n = N0 + wn * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= p.N) continue;
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        }
+        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+        if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
+        *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+    }
+}
+
+// Few rows (M <= 256: beam-search decoding, 5-25 rows per step): the 64x64 kernel above runs as a handful of blocks whose K loop
+// is a chain of global-load latencies.  Here a block owns a 32x32 output tile and its four waves split K (wave w multiplies the
+// 32-deep slabs w, w + 4, ...), so 24-954 blocks x 4 waves work on a problem at once; operands go straight from global memory
+// into registers (lane = row, 16 consecutive k per half-wave, three slabs in flight — no LDS, no barrier in the loop).  MFMA step
+// j of a slab pairs k0 + j (lanes < 32) with k0 + 16 + j (lanes >= 32).  The four partial tiles are added in wave order through
+// LDS, so the result does not depend on timing.
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF p) {
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, khalf = lane >> 5;
+    const int M0 = blockIdx.y * 32, N0 = blockIdx.x * 32;
+    int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1;
+    int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1;
+    const float* ap = p.A + (int64_t)gm * p.lda + 16 * khalf;
+    const float* wp = p.W + (int64_t)gn * p.ldw + 16 * khalf;
+    const int nslab = (p.K + FK - 1) / FK;
+    const int cnt = (nslab - wave + 3) >> 2;                // slabs of this wave
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int s, f32x4 (&a)[4], f32x4 (&w)[4]) {
+        const int k0 = (wave + 4 * s) * FK;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const bool in = s < cnt && k0 + 16 * khalf + 4 * h < p.K;     // K % 4 == 0: whole 4-vectors
+            a[h] = in ? *reinterpret_cast<const f32x4*>(ap + k0 + 4 * h) : zero;
+            w[h] = in ? *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h) : zero;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto mm = [&](const f32x4 (&a)[4], const f32x4 (&w)[4]) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[h][e], a[h][e], acc, 0, 0, 0);
+    };
+    f32x4 a0[4], w0[4], a1[4], w1[4], a2[4], w2[4];
+    load(0, a0, w0); load(1, a1, w1); load(2, a2, w2);
+    for (int s = 0; s < cnt; s += 3) {
+        mm(a0, w0); load(s + 3, a0, w0);
+        if (s + 1 < cnt) { mm(a1, w1); load(s + 4, a1, w1); }
+        if (s + 2 < cnt) { mm(a2, w2); load(s + 5, a2, w2); }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = ((acc[e] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
+    const int m = M0 + row;
+    if (m >= p.M) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = N0 + 8 * g + 4 * khalf;
         if (n >= p.N) continue;
         f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -394,12 +479,23 @@ inline int grid1d(int64_t total, int cap = 4096) { int64_t g = (total + 255) / 2
 
 }  // namespace
 
+static bool g_f32_skinny = true;   // hirest_gemm_f32_select_kernel: A/B and tests
+extern "C" int hirest_gemm_f32_select_kernel(int32_t which) {   // 0 automatic (skinny for M <= 256), 1 always the 64x64 kernel
+    if (which < 0 || which > 1) return HIREST_E_BADARG;
+    g_f32_skinny = which == 0;
+    return 0;
+}
+
 extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                                const float* resid, int64_t ldr, const float* periodic, int32_t period,
                                float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return HIREST_E_BADARG;
     if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
+    if (M <= 256 && g_f32_skinny) {
+        hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+        return hirest_launch_status();
+    }
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     return hirest_launch_status();
 }

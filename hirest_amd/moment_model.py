@@ -145,6 +145,7 @@ class MomentModel(nn.Module):
         self.clip_model = clip_model
         self.freeze_clip()
         self.heads = 12
+        self.caption_kv_cache = True   # step captioning keeps the decoder's self-attention K / V per beam (False: full-prefix recompute)
         self._cache = None
 
     # ------------------------------------------------------------------ nn.Module plumbing
@@ -466,6 +467,63 @@ class MomentModel(nn.Module):
                    "hirest_log_softmax_f32")
         return out
 
+    def _decoder_step_cached(self, last_ids: torch.Tensor, position: int, parent_rows: Optional[torch.Tensor], cache: list,
+                             enc_kv: List[torch.Tensor], row_add: torch.Tensor):
+        """The same arithmetic for the LAST position only, with the self-attention keys / values of the earlier positions kept
+        from the previous steps (rows re-gathered by each beam's parent).  Valid because the reference's "causal" penalty of
+        -10000 (module_decoder.py:394-397) makes exp() of every future key exactly 0 in fp32: a position's hidden state never
+        depends on later tokens, so recomputing the prefix (train.py:547-566 does, every step) reproduces the rows kept here
+        bit for bit.  last_ids int32 [R] = the newest token of every beam, position = its index.  Returns ([R, vocab], cache)."""
+        c, lib = self._w(), _lib.load()
+        Dp = "clip4cap_model.decoder."
+        R = last_ids.numel()
+        H, Dm = self.heads, 768
+        dev = last_ids.device
+        x = torch.empty((R, Dm), dtype=torch.float32, device=dev)
+        pos_ids = torch.full((R,), position, dtype=torch.int32, device=dev)
+        _lib.check(lib.hirest_embedding_pos_fwd_f32(last_ids.data_ptr(), pos_ids.data_ptr(),
+                                                    c[Dp + "embeddings.word_embeddings.weight"].data_ptr(),
+                                                    c[Dp + "embeddings.position_embeddings.weight"].data_ptr(), x.data_ptr(), R, Dm,
+                                                    ops.stream_ptr()), "hirest_embedding_pos_fwd_f32")
+        x = self._ln(x, c[Dp + "embeddings.LayerNorm.weight"], c[Dp + "embeddings.LayerNorm.bias"], 1e-12)
+        scale = (Dm // H) ** -0.5
+        new_cache = []
+        for i in range(len(self.clip4cap_model.decoder.decoder.layer)):
+            p = Dp + f"decoder.layer.{i}."
+            qkv = self._gemm(x, c[f"dec_qkv_w.{i}"], c[f"dec_qkv_b.{i}"])
+            k_new, v_new = qkv[:, Dm:2 * Dm].unsqueeze(1), qkv[:, 2 * Dm:].unsqueeze(1)
+            if parent_rows is None:
+                K, V = k_new.contiguous(), v_new.contiguous()
+            else:
+                K = torch.cat([cache[i][0].index_select(0, parent_rows), k_new], 1)
+                V = torch.cat([cache[i][1].index_select(0, parent_rows), v_new], 1)
+            new_cache.append((K, V))
+            Tk = K.shape[1]
+            ctx = torch.empty_like(x)
+            _lib.check(lib.hirest_attention_f32_qkv(qkv.data_ptr(), 3 * Dm, K.data_ptr(), V.data_ptr(), Dm, ctx.data_ptr(),
+                                                    R, 1, Tk, H, Dm // H, scale, 0.0, 0.0, ops.stream_ptr()), "self attention")
+            s1 = self._gemm(ctx, c[p + "slf_attn.output.dense.weight"], c[p + "slf_attn.output.dense.bias"], resid=x)
+            s1 = self._ln(s1, c[p + "slf_attn.output.LayerNorm.weight"], c[p + "slf_attn.output.LayerNorm.bias"], 1e-12)
+            q2 = self._gemm(s1, c[p + "enc_attn.att.query.weight"], c[p + "enc_attn.att.query.bias"])
+            kv = enc_kv[i]
+            _lib.check(lib.hirest_attention_f32_qkv(q2.data_ptr(), Dm, kv.data_ptr(), kv.data_ptr() + 4 * Dm, 2 * Dm, ctx.data_ptr(),
+                                                    R, 1, kv.shape[1], H, Dm // H, scale, -10000.0, 0.0, ops.stream_ptr()),
+                       "cross attention")
+            d = self._gemm(ctx, c[p + "enc_attn.output.dense.weight"], c[p + "enc_attn.output.dense.bias"], resid=s1)
+            d = self._ln(d, c[p + "enc_attn.output.LayerNorm.weight"], c[p + "enc_attn.output.LayerNorm.bias"], 1e-12)
+            hmid = self._gemm(d, c[p + "intermediate.dense.weight"], c[p + "intermediate.dense.bias"], act=1)
+            y = self._gemm(hmid, c[p + "output.dense.weight"], c[p + "output.dense.bias"], resid=d)
+            x = self._ln(y, c[p + "output.LayerNorm.weight"], c[p + "output.LayerNorm.bias"], 1e-12)
+        cp = Dp + "classifier.cls.predictions."
+        hh = self._gemm(x, c[cp + "transform.dense.weight"], c[cp + "transform.dense.bias"], act=1)
+        hh = self._ln(hh, c[cp + "transform.LayerNorm.weight"], c[cp + "transform.LayerNorm.bias"], 1e-12)
+        logits = self._gemm(hh, c["lm_w"], c["lm_b"])
+        V_ = logits.shape[1]
+        out = torch.empty_like(logits)
+        _lib.check(lib.hirest_log_softmax_f32(logits.data_ptr(), V_, row_add.data_ptr(), out.data_ptr(), V_, R, V_, ops.stream_ptr()),
+                   "hirest_log_softmax_f32")
+        return out, new_cache
+
     @torch.no_grad()
     def test_step_captioning(self, batch, num_beams=5, return_ids=False, **kwargs):
         """modeling.py:556-632.  Returns {'prediction': [str]} (token strings joined like the reference; ids are
@@ -490,15 +548,33 @@ class MomentModel(nn.Module):
                       for i in range(len(self.clip4cap_model.decoder.decoder.layer))]
         beams = [BeamState(num_beams) for _ in range(B)]
         active = list(range(B))
+        use_cache = bool(getattr(self, "caption_kv_cache", True))
+        cache, rowmap = None, {}
         for t in range(1, max_words + 1):
-            seqs = [s for b in active for s in beams[b].current_state()]
-            ids = torch.tensor(seqs, dtype=torch.long, device=dev)
             sel = torch.tensor([b for b in active for _ in range(num_beams)], dtype=torch.long, device=dev)
             enc_kv = [kv.index_select(0, sel).contiguous() for kv in enc_kv_all]
             # row_add = running beam scores (beam.py:76); on the first step only beam 0 competes (beam.py:78)
             add = torch.tensor([(x if (t > 1 or k == 0) else -3.0e38) for b in active
                                 for k, x in enumerate(beams[b].scores)], dtype=torch.float32, device=dev)
-            logp = self._decoder_last_logprob(ids, enc_kv, add)                                     # [n*beam, V]
+            if use_cache:
+                # rows of this step in the reference's order (get_tentative_hypothesis: beams by score); each brings its newest
+                # token and the row its parent beam had in the previous step
+                last, parents, new_map = [], [], {}
+                for b in active:
+                    for k in beams[b]._order():
+                        new_map[(b, k)] = len(last)
+                        if t == 1:
+                            last.append(BOS_ID)
+                        else:
+                            last.append(beams[b].tokens[-1][k])
+                            parents.append(rowmap[(b, beams[b].backptr[-1][k])])
+                logp, cache = self._decoder_step_cached(
+                    torch.tensor(last, dtype=torch.int32, device=dev), t - 1,
+                    torch.tensor(parents, dtype=torch.long, device=dev) if t > 1 else None, cache, enc_kv, add)
+                rowmap = new_map
+            else:                                                                                   # full-prefix recompute
+                seqs = [s for b in active for s in beams[b].current_state()]
+                logp = self._decoder_last_logprob(torch.tensor(seqs, dtype=torch.long, device=dev), enc_kv, add)   # [n*beam, V]
             n, V = len(active), logp.shape[1]
             val, idx = ops.topk(logp.reshape(n, num_beams * V), num_beams)
             val_h, idx_h = val.cpu().tolist(), idx.cpu().tolist()

@@ -280,6 +280,9 @@ int hirest_text_forward(const hirest_text_tower* t, const int64_t* tokens, int32
 int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                     const float* resid, int64_t ldr, const float* periodic, int32_t period,
                     float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+/* 0 = automatic (problems of M <= 256 rows take the split-K "skinny" kernel: 32x32 tiles, four waves share K), 1 = always the
+ * 64x64 kernel.  Both are exact fp32 MFMA; they differ in summation order only (tests / A-B timing). */
+int hirest_gemm_f32_select_kernel(int32_t which);
 /* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*64]; no key masking (the
  * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3). */
 int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,

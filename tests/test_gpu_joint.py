@@ -21,9 +21,43 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("M,N,K,act", [(64, 64, 16, 0), (193, 768, 768, 1), (300, 2304, 768, 0), (77, 512, 1024, 2), (130, 768, 3072, 0)])
-def test_gemm_f32(dev, M, N, K, act):
+@pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "64x64"])
+@pytest.mark.parametrize("M,N,K,act", [(64, 64, 16, 0), (193, 768, 768, 1), (300, 2304, 768, 0), (77, 512, 1024, 2), (130, 768, 3072, 0),
+                                       (25, 30528, 768, 0), (5, 768, 768, 1), (256, 100, 1504, 0), (33, 36, 48, 2)])
+def test_gemm_f32(dev, M, N, K, act, kernel):
+    """M <= 256 takes the split-K 32x32 kernel in automatic mode, the 64x64 kernel otherwise / when forced"""
+    from hirest_amd import _lib
     from hirest_amd.moment_model import MomentModel
+    _lib.check(_lib.load().hirest_gemm_f32_select_kernel(kernel), "select")
+    try:
+        _gemm_f32_case(dev, M, N, K, act, MomentModel)
+    finally:
+        _lib.load().hirest_gemm_f32_select_kernel(0)
+
+
+def test_gemm_f32_kernels_share_their_summation_order(dev):
+    """A row's result must not depend on how many rows the call has (batch invariance of every fp32 path: a sentence embedded
+    alone or in a batch, a beam's hidden state recomputed or cached): the split-K kernel for M <= 256 and the 64x64 kernel add the
+    same products in the same order, so they agree bit for bit — also across a call that is cut into pieces."""
+    from hirest_amd import _lib
+    from hirest_amd.moment_model import MomentModel
+    lib = _lib.load()
+    for M, N, K in ((200, 768, 768), (25, 30528, 768), (256, 132, 3072), (77, 512, 1040)):
+        a = synth.tensor("jo.a", (M, K), 1.0, 2).to(dev)
+        w = synth.tensor("jo.w", (N, K), 0.05, 2).to(dev)
+        b = synth.tensor("jo.b", (N,), 0.3, 2).to(dev)
+        outs = []
+        for kernel in (0, 1):
+            _lib.check(lib.hirest_gemm_f32_select_kernel(kernel), "select")
+            outs.append(MomentModel._gemm(a, w, b, act=1))
+        lib.hirest_gemm_f32_select_kernel(0)
+        assert torch.equal(outs[0], outs[1]), (M, N, K)
+        big = torch.cat([a, a, a], 0)                              # 3 M > 256 rows: the 64x64 kernel in automatic mode
+        if 3 * M > 256:
+            assert torch.equal(MomentModel._gemm(big, w, b, act=1)[M:2 * M], outs[0]), (M, N, K)
+
+
+def _gemm_f32_case(dev, M, N, K, act, MomentModel):
     a = synth.tensor("jf.a", (M, K), 1.0, 1)
     w = synth.tensor("jf.w", (N, K), 0.05, 1)
     b = synth.tensor("jf.b", (N,), 0.3, 1)
@@ -125,6 +159,11 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     res = model.test_step(batch, num_beams=pred["beams"], return_ids=True)
     assert res["prediction"] == pred["prediction"]
     assert [" ".join(str(i) for i in h) for h in res["token_ids"]] == pred["prediction"]
+    # default = decoding with the self-attention K / V of earlier positions kept per beam; recomputing the whole prefix every
+    # step, as the reference does (train.py:547-566), gives the same tokens
+    assert model.caption_kv_cache
+    model.caption_kv_cache = False
+    assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
 
 
 def test_clip_text_ids_path_equals_text_feat_path(dev, golden_dir):
