@@ -534,37 +534,62 @@ extern "C" int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float
 }
 
 // out[r][v] = x[r][v] - logsumexp(x[r]) + row_add[r]   (log_softmax of train.py:563-564 fused with the beam score add of beam.py:76)
-__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ row_add,
-                                                         float* __restrict__ out, int64_t ldo, int V) {
-    __shared__ float red[4];
+// One 1024-thread block per row (beam search: 5-25 rows of 30 522 logits, so the row itself has to supply the parallelism):
+// 16-byte loads where the row allows them, three passes over a row that stays in the L2.
+__global__ __launch_bounds__(1024) void log_softmax_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ row_add,
+                                                          float* __restrict__ out, int64_t ldo, int V, int vec) {
+    __shared__ float red[16];
     __shared__ float bc;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xr = x + (int64_t)r * ldx;
+    float* o = out + (int64_t)r * ldo;
+    const int V4 = vec ? V >> 2 : 0;                      // 4-wide part (all of the row when vec), scalar tail otherwise
     float mx = -INFINITY;
-    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, xr[i]);
+    for (int i = tid; i < V4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    for (int i = 4 * V4 + tid; i < V; i += 1024) mx = fmaxf(mx, xr[i]);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (tid == 0) {
+        float m = red[0];
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+        bc = m;
+    }
     __syncthreads();
     mx = bc;
     float s = 0.f;
-    for (int i = tid; i < V; i += 256) s += expf(xr[i] - mx);
+    for (int i = tid; i < V4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+        s += (expf(v[0] - mx) + expf(v[1] - mx)) + (expf(v[2] - mx) + expf(v[3] - mx));
+    }
+    for (int i = 4 * V4 + tid; i < V; i += 1024) s += expf(xr[i] - mx);
     s = wave_sum(s);
     __syncthreads();
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    if (tid == 0) bc = logf((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];          // fixed order
+        bc = logf(t);
+    }
     __syncthreads();
     const float lse = bc, add = row_add ? row_add[r] : 0.f;
-    float* o = out + (int64_t)r * ldo;
-    for (int i = tid; i < V; i += 256) o[i] = ((xr[i] - mx) - lse) + add;
+    for (int i = tid; i < V4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+        *reinterpret_cast<f32x4*>(o + 4 * i) = f32x4{((v[0] - mx) - lse) + add, ((v[1] - mx) - lse) + add, ((v[2] - mx) - lse) + add,
+                                                     ((v[3] - mx) - lse) + add};
+    }
+    for (int i = 4 * V4 + tid; i < V; i += 1024) o[i] = ((xr[i] - mx) - lse) + add;
 }
 
 extern "C" int hirest_log_softmax_f32(const float* x, int64_t ldx, const float* row_add, float* out, int64_t ldo, int32_t rows,
                                       int32_t V, void* stream) {
     if (!x || !out || rows <= 0 || V <= 0) return HIREST_E_BADARG;
-    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, row_add, out, ldo, V);
+    const int vec = (V % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, row_add, out, ldo, V, vec);
     return hirest_launch_status();
 }
 

@@ -35,6 +35,19 @@ def test_gemm_f32(dev, M, N, K, act, kernel):
         _lib.load().hirest_gemm_f32_select_kernel(0)
 
 
+@pytest.mark.parametrize("rows,V", [(25, 30528), (7, 30522), (3, 5), (2, 1030)])
+def test_log_softmax_rows(dev, rows, V):
+    """train.py:563-564 + the beam score add of beam.py:76"""
+    import ctypes as C
+    from hirest_amd import _lib, ops
+    x = synth.tensor("ls.x", (rows, V), 3.0, 3).to(dev)
+    add = synth.tensor("ls.a", (rows,), 2.0, 3).to(dev)
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().hirest_log_softmax_f32(x.data_ptr(), V, add.data_ptr(), out.data_ptr(), V, rows, V, ops.stream_ptr()), "ls")
+    ref = torch.log_softmax(x.double(), 1) + add.double()[:, None]
+    assert (out.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+
+
 def test_gemm_f32_kernels_share_their_summation_order(dev):
     """A row's result must not depend on how many rows the call has (batch invariance of every fp32 path: a sentence embedded
     alone or in a batch, a beam's hidden state recomputed or cached): the split-K kernel for M <= 256 and the 64x64 kernel add the
