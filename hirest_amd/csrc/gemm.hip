@@ -1363,12 +1363,12 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
         if (flags != 8 && !(flags && epi == HIREST_EPI_BIAS_BF16 && (flags == 1 || flags == 2 || flags == 4 || flags == 6))) flags = 0;
         snprintf(out, out_len, "gemm_w4<%d, %d>", epi, flags);
     } else if (fused) {
-        if (a->K >= 4096 && f != 6) snprintf(out, out_len, "gemm_pp256<%d>", epi);
-        else snprintf(out, out_len, "gemm_p256<%d, 64, false>", epi);
-    } else if (f == 0 && big && a->K >= 4096) snprintf(out, out_len, "gemm_pp256<%d>", epi);
-    else if (f == 6 || (f == 0 && big)) snprintf(out, out_len, "gemm_p256<%d, 64, %s>", epi, dbg_inst ? "true" : "false");
-    else if (f == 7) snprintf(out, out_len, "gemm_p256<%d, 128, false>", epi);
-    else if (f == 8) snprintf(out, out_len, "gemm_pp256<%d>", epi);
+        if (a->K >= 4096 && f != 6) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
+        else snprintf(out, out_len, "gemm_p256<%d, 64, false, 1>", epi);
+    } else if (f == 0 && big && a->K >= 4096) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
+    else if (f == 6 || (f == 0 && big)) snprintf(out, out_len, "gemm_p256<%d, 64, %s, 1>", epi, dbg_inst ? "true" : "false");
+    else if (f == 7) snprintf(out, out_len, "gemm_p256<%d, 128, false, 1>", epi);
+    else if (f == 8) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
     else if (f == 5) snprintf(out, out_len, "gemm_t256q<%d>", epi);
     else if (f == 4) snprintf(out, out_len, "gemm_t256p<%d>", epi);
     else if (f == 2) snprintf(out, out_len, "gemm_t256<%d, 4>", epi);

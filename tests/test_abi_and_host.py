@@ -166,7 +166,7 @@ def test_profiled_kernels_are_the_dispatched_ones(lib):
                 (Mt, 2304, 768, _lib.EPI_BIAS_BF16), (Mt, 768, 768, _lib.EPI_BIAS_RESID_F32), (Mt, 3072, 768, _lib.EPI_BIAS_GELU_BF16),
                 (Mt, 768, 3072, _lib.EPI_BIAS_RESID_F32), (546, 1024, 768, _lib.EPI_BIAS_F32)]
     dispatched = {name(*p) for p in problems}
-    assert {"gemm_p256<7, 64, false>", "gemm_p256<6, 64, false>", "gemm_p256<8, 64, false>", "gemm_pp256<6>"} <= dispatched
+    assert {"gemm_p256<7, 64, false, 1>", "gemm_p256<6, 64, false, 1>", "gemm_p256<8, 64, false, 1>", "gemm_pp256<6, 1>"} <= dispatched
     rounds = sorted(d for d in os.listdir(os.path.join(REPO, "profiles")) if re.fullmatch(r"r\d\d", d))
     newest = os.path.join(REPO, "profiles", rounds[-1])
     src = open(os.path.join(REPO, "bench.py")).read()
