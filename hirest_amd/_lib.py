@@ -60,6 +60,18 @@ class TextTower(C.Structure):
                 ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p), ("proj_w", C.c_void_p)]
 
 
+class CaptionLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_b", "so_w", "so_b", "so_ln_g", "so_ln_b", "cq_w", "cq_b",
+                                          "co_w", "co_b", "co_ln_g", "co_ln_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ff_ln_g", "ff_ln_b")]
+
+
+class CaptionDecoder(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("layers", "heads", "hidden", "inter", "vocab_padded", "max_pos")] + \
+               [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "emb_ln_g", "emb_ln_b")] + \
+               [("layer", C.POINTER(CaptionLayer))] + \
+               [(n, C.c_void_p) for n in ("tr_w", "tr_b", "tr_ln_g", "tr_ln_b", "lm_w", "lm_b")]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("kind", C.c_int32), ("tag", C.c_int32), ("d0", C.c_int64), ("d1", C.c_int64), ("d2", C.c_int64),
                 ("ms", C.c_float)]
@@ -104,6 +116,10 @@ _SIGNATURES = {
     "hirest_attention_f32_qkv": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hirest_gemm_f32_select_kernel": (C.c_int, [C.c_int32]),
+    "hirest_caption_step_workspace_bytes": (C.c_size_t, [C.POINTER(CaptionDecoder), C.c_int32]),
+    "hirest_caption_decode_step": (C.c_int, [C.POINTER(CaptionDecoder), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hirest_attention_f32_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                               C.c_float, C.c_void_p]),
     "hirest_log_softmax_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

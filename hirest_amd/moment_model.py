@@ -192,6 +192,29 @@ class MomentModel(nn.Module):
         padn = (-we.shape[0]) % 4
         c["lm_w"] = torch.cat([we, torch.zeros((padn, we.shape[1]), device=dev)], 0).contiguous() if padn else we
         c["lm_b"] = torch.cat([vb, torch.full((padn,), -3.0e38, device=dev)]).contiguous() if padn else vb
+        # descriptor of the C-side decoder step (csrc/caption.hip): device pointers into the tensors above
+        Dp = "clip4cap_model.decoder."
+        nl = len(self.clip4cap_model.decoder.decoder.layer)
+        layers = (_lib.CaptionLayer * nl)()
+        for i in range(nl):
+            p = Dp + f"decoder.layer.{i}."
+            layers[i] = _lib.CaptionLayer(*[c[k].data_ptr() for k in (
+                f"dec_qkv_w.{i}", f"dec_qkv_b.{i}", p + "slf_attn.output.dense.weight", p + "slf_attn.output.dense.bias",
+                p + "slf_attn.output.LayerNorm.weight", p + "slf_attn.output.LayerNorm.bias",
+                p + "enc_attn.att.query.weight", p + "enc_attn.att.query.bias", p + "enc_attn.output.dense.weight",
+                p + "enc_attn.output.dense.bias", p + "enc_attn.output.LayerNorm.weight", p + "enc_attn.output.LayerNorm.bias",
+                p + "intermediate.dense.weight", p + "intermediate.dense.bias", p + "output.dense.weight", p + "output.dense.bias",
+                p + "output.LayerNorm.weight", p + "output.LayerNorm.bias")])
+        cp = Dp + "classifier.cls.predictions."
+        c["dec_layers"] = layers
+        c["dec_desc"] = _lib.CaptionDecoder(
+            nl, self.heads, 768, c[Dp + "decoder.layer.0.intermediate.dense.weight"].shape[0], c["lm_w"].shape[0],
+            c[Dp + "embeddings.position_embeddings.weight"].shape[0],
+            c[Dp + "embeddings.word_embeddings.weight"].data_ptr(), c[Dp + "embeddings.position_embeddings.weight"].data_ptr(),
+            c[Dp + "embeddings.LayerNorm.weight"].data_ptr(), c[Dp + "embeddings.LayerNorm.bias"].data_ptr(), layers,
+            c[cp + "transform.dense.weight"].data_ptr(), c[cp + "transform.dense.bias"].data_ptr(),
+            c[cp + "transform.LayerNorm.weight"].data_ptr(), c[cp + "transform.LayerNorm.bias"].data_ptr(),
+            c["lm_w"].data_ptr(), c["lm_b"].data_ptr())
         c["head_bias"] = torch.cat([f(getattr(m, "0").bias) for m in
                                     (self.start_predictor, self.end_predictor, self.segment_predictor)]).contiguous()
         self._cache = c
@@ -467,69 +490,64 @@ class MomentModel(nn.Module):
                    "hirest_log_softmax_f32")
         return out
 
-    def _decoder_step_cached(self, last_ids: torch.Tensor, position: int, parent_rows: Optional[torch.Tensor], cache: list,
-                             enc_kv: List[torch.Tensor], row_add: torch.Tensor):
-        """The same arithmetic for the LAST position only, with the self-attention keys / values of the earlier positions kept
-        from the previous steps (rows re-gathered by each beam's parent).  Valid because the reference's "causal" penalty of
-        -10000 (module_decoder.py:394-397) makes exp() of every future key exactly 0 in fp32: a position's hidden state never
-        depends on later tokens, so recomputing the prefix (train.py:547-566 does, every step) reproduces the rows kept here
-        bit for bit.  last_ids int32 [R] = the newest token of every beam, position = its index.  Returns ([R, vocab], cache)."""
+    def _beam_search_cached(self, beams, enc_kv_all, num_beams, max_words, return_ids):
+        """Beam search with one C-side call per word (csrc/caption.hip: ~35 kernels enqueued without returning to Python, each beam's
+        self-attention K / V kept and re-gathered by parent beam).  The row set never shrinks: a finished sample's rows keep being
+        computed and are ignored, which costs a few rows of tiny GEMMs and saves re-packing every buffer when a sample ends."""
+        from .beam import BOS_ID, EOS_ID
         c, lib = self._w(), _lib.load()
-        Dp = "clip4cap_model.decoder."
-        R = last_ids.numel()
-        H, Dm = self.heads, 768
-        dev = last_ids.device
-        x = torch.empty((R, Dm), dtype=torch.float32, device=dev)
-        pos_ids = torch.full((R,), position, dtype=torch.int32, device=dev)
-        _lib.check(lib.hirest_embedding_pos_fwd_f32(last_ids.data_ptr(), pos_ids.data_ptr(),
-                                                    c[Dp + "embeddings.word_embeddings.weight"].data_ptr(),
-                                                    c[Dp + "embeddings.position_embeddings.weight"].data_ptr(), x.data_ptr(), R, Dm,
-                                                    ops.stream_ptr()), "hirest_embedding_pos_fwd_f32")
-        x = self._ln(x, c[Dp + "embeddings.LayerNorm.weight"], c[Dp + "embeddings.LayerNorm.bias"], 1e-12)
-        scale = (Dm // H) ** -0.5
-        new_cache = []
-        for i in range(len(self.clip4cap_model.decoder.decoder.layer)):
-            p = Dp + f"decoder.layer.{i}."
-            qkv = self._gemm(x, c[f"dec_qkv_w.{i}"], c[f"dec_qkv_b.{i}"])
-            k_new, v_new = qkv[:, Dm:2 * Dm].unsqueeze(1), qkv[:, 2 * Dm:].unsqueeze(1)
-            if parent_rows is None:
-                K, V = k_new.contiguous(), v_new.contiguous()
-            else:
-                K = torch.cat([cache[i][0].index_select(0, parent_rows), k_new], 1)
-                V = torch.cat([cache[i][1].index_select(0, parent_rows), v_new], 1)
-            new_cache.append((K, V))
-            Tk = K.shape[1]
-            ctx = torch.empty_like(x)
-            _lib.check(lib.hirest_attention_f32_qkv(qkv.data_ptr(), 3 * Dm, K.data_ptr(), V.data_ptr(), Dm, ctx.data_ptr(),
-                                                    R, 1, Tk, H, Dm // H, scale, 0.0, 0.0, ops.stream_ptr()), "self attention")
-            s1 = self._gemm(ctx, c[p + "slf_attn.output.dense.weight"], c[p + "slf_attn.output.dense.bias"], resid=x)
-            s1 = self._ln(s1, c[p + "slf_attn.output.LayerNorm.weight"], c[p + "slf_attn.output.LayerNorm.bias"], 1e-12)
-            q2 = self._gemm(s1, c[p + "enc_attn.att.query.weight"], c[p + "enc_attn.att.query.bias"])
-            kv = enc_kv[i]
-            _lib.check(lib.hirest_attention_f32_qkv(q2.data_ptr(), Dm, kv.data_ptr(), kv.data_ptr() + 4 * Dm, 2 * Dm, ctx.data_ptr(),
-                                                    R, 1, kv.shape[1], H, Dm // H, scale, -10000.0, 0.0, ops.stream_ptr()),
-                       "cross attention")
-            d = self._gemm(ctx, c[p + "enc_attn.output.dense.weight"], c[p + "enc_attn.output.dense.bias"], resid=s1)
-            d = self._ln(d, c[p + "enc_attn.output.LayerNorm.weight"], c[p + "enc_attn.output.LayerNorm.bias"], 1e-12)
-            hmid = self._gemm(d, c[p + "intermediate.dense.weight"], c[p + "intermediate.dense.bias"], act=1)
-            y = self._gemm(hmid, c[p + "output.dense.weight"], c[p + "output.dense.bias"], resid=d)
-            x = self._ln(y, c[p + "output.LayerNorm.weight"], c[p + "output.LayerNorm.bias"], 1e-12)
-        cp = Dp + "classifier.cls.predictions."
-        hh = self._gemm(x, c[cp + "transform.dense.weight"], c[cp + "transform.dense.bias"], act=1)
-        hh = self._ln(hh, c[cp + "transform.LayerNorm.weight"], c[cp + "transform.LayerNorm.bias"], 1e-12)
-        logits = self._gemm(hh, c["lm_w"], c["lm_b"])
-        V_ = logits.shape[1]
-        out = torch.empty_like(logits)
-        _lib.check(lib.hirest_log_softmax_f32(logits.data_ptr(), V_, row_add.data_ptr(), out.data_ptr(), V_, R, V_, ops.stream_ptr()),
-                   "hirest_log_softmax_f32")
-        return out, new_cache
+        dev = c["dev"]
+        B, F = enc_kv_all[0].shape[0], enc_kv_all[0].shape[1]
+        R, nl, Dm = B * num_beams, len(enc_kv_all), 768
+        desc = c["dec_desc"]
+        Vp = desc.vocab_padded
+        enc = [kv.repeat_interleave(num_beams, 0).contiguous() for kv in enc_kv_all]             # [R, F, 1536], loop invariant
+        enc_ptrs = (C.c_void_p * nl)(*[e.data_ptr() for e in enc])
+        ws = torch.empty(lib.hirest_caption_step_workspace_bytes(C.byref(desc), R), dtype=torch.uint8, device=dev)
+        cache = [torch.empty((2 * nl, R, max_words, Dm), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
+        ptrs = [(C.c_void_p * (2 * nl))(*[cb[i].data_ptr() for i in range(2 * nl)]) for cb in cache]
+        logp = torch.empty((R, Vp), dtype=torch.float32, device=dev)
+        active = set(range(B))
+        rowmap = {}
+        for t in range(1, max_words + 1):
+            # rows in the reference's order (get_tentative_hypothesis: beams by score); each brings its newest token, the row its
+            # parent beam had in the previous step, and its running score (beam.py:76; first step: only beam 0 competes, :78)
+            last, parents, add, new_map = [], [], [], {}
+            for b in range(B):
+                live = b in active
+                for r, k in enumerate(beams[b]._order() if live else range(num_beams)):
+                    row = b * num_beams + r
+                    new_map[(b, k)] = row
+                    if not live:
+                        last.append(EOS_ID); parents.append(row)
+                    elif t == 1:
+                        last.append(BOS_ID); parents.append(row)
+                    else:
+                        last.append(beams[b].tokens[-1][k]); parents.append(rowmap[(b, beams[b].backptr[-1][k])])
+                add.extend([(x if (t > 1 or k == 0) else -3.0e38) for k, x in enumerate(beams[b].scores)] if live
+                           else [0.0] * num_beams)
+            rowmap = new_map
+            ints = torch.tensor(last + parents, dtype=torch.int32).to(dev, non_blocking=True)
+            addt = torch.tensor(add, dtype=torch.float32).to(dev, non_blocking=True)
+            _lib.check(lib.hirest_caption_decode_step(
+                C.byref(desc), R, t - 1, ints.data_ptr(), ints.data_ptr() + 4 * R if t > 1 else None,
+                ptrs[t & 1] if t > 1 else None, ptrs[(t + 1) & 1], enc_ptrs, F, addt.data_ptr(), logp.data_ptr(),
+                ws.data_ptr(), ws.numel(), ops.stream_ptr()), "hirest_caption_decode_step")
+            val, idx = ops.topk(logp.reshape(B, num_beams * Vp), num_beams)
+            both = torch.cat([val, idx.to(torch.float32)], 1).cpu()                              # ids < 2^24: exact in fp32
+            val_h, idx_h = both[:, :num_beams].tolist(), both[:, num_beams:].to(torch.int64).tolist()
+            for b in sorted(active):
+                if beams[b].advance(val_h[b], idx_h[b], Vp):
+                    active.discard(b)
+            if not active:
+                break
+        return self._caption_result(beams, return_ids)
 
     @torch.no_grad()
     def test_step_captioning(self, batch, num_beams=5, return_ids=False, **kwargs):
         """modeling.py:556-632.  Returns {'prediction': [str]} (token strings joined like the reference; ids are
         printed as decimal strings when no BERT vocab is attached via ``tokenizer_vocab``)."""
-        from .beam import BeamState, BOS_ID
-        lib = _lib.load()
+        from .beam import BeamState
         dev = self._w()["dev"]
         c = self._w()
         max_frames = int(getattr(self.args, "max_frames_step_captioning", 20)) if self.args is not None else 20
@@ -548,39 +566,25 @@ class MomentModel(nn.Module):
                       for i in range(len(self.clip4cap_model.decoder.decoder.layer))]
         beams = [BeamState(num_beams) for _ in range(B)]
         active = list(range(B))
-        use_cache = bool(getattr(self, "caption_kv_cache", True))
-        cache, rowmap = None, {}
+        if bool(getattr(self, "caption_kv_cache", True)):
+            return self._beam_search_cached(beams, enc_kv_all, num_beams, max_words, return_ids)
         for t in range(1, max_words + 1):
             sel = torch.tensor([b for b in active for _ in range(num_beams)], dtype=torch.long, device=dev)
             enc_kv = [kv.index_select(0, sel).contiguous() for kv in enc_kv_all]
             # row_add = running beam scores (beam.py:76); on the first step only beam 0 competes (beam.py:78)
             add = torch.tensor([(x if (t > 1 or k == 0) else -3.0e38) for b in active
                                 for k, x in enumerate(beams[b].scores)], dtype=torch.float32, device=dev)
-            if use_cache:
-                # rows of this step in the reference's order (get_tentative_hypothesis: beams by score); each brings its newest
-                # token and the row its parent beam had in the previous step
-                last, parents, new_map = [], [], {}
-                for b in active:
-                    for k in beams[b]._order():
-                        new_map[(b, k)] = len(last)
-                        if t == 1:
-                            last.append(BOS_ID)
-                        else:
-                            last.append(beams[b].tokens[-1][k])
-                            parents.append(rowmap[(b, beams[b].backptr[-1][k])])
-                logp, cache = self._decoder_step_cached(
-                    torch.tensor(last, dtype=torch.int32, device=dev), t - 1,
-                    torch.tensor(parents, dtype=torch.long, device=dev) if t > 1 else None, cache, enc_kv, add)
-                rowmap = new_map
-            else:                                                                                   # full-prefix recompute
-                seqs = [s for b in active for s in beams[b].current_state()]
-                logp = self._decoder_last_logprob(torch.tensor(seqs, dtype=torch.long, device=dev), enc_kv, add)   # [n*beam, V]
+            seqs = [s for b in active for s in beams[b].current_state()]                            # full-prefix recompute
+            logp = self._decoder_last_logprob(torch.tensor(seqs, dtype=torch.long, device=dev), enc_kv, add)   # [n*beam, V]
             n, V = len(active), logp.shape[1]
             val, idx = ops.topk(logp.reshape(n, num_beams * V), num_beams)
             val_h, idx_h = val.cpu().tolist(), idx.cpu().tolist()
             active = [b for i, b in enumerate(active) if not beams[b].advance(val_h[i], idx_h[i], V)]
             if not active:
                 break
+        return self._caption_result(beams, return_ids)
+
+    def _caption_result(self, beams, return_ids):
         hyps = [bm.best_hypothesis() for bm in beams]
         texts = []
         for h in hyps:

@@ -314,6 +314,38 @@ int hirest_joint_mask_add(const float* base, const int32_t* moment_mask, const i
 int hirest_linear_heads(const float* x, int64_t rows, int32_t D, int32_t nheads, const float* w0, const float* w1,
                         const float* w2, const float* bias3, float* logits, void* stream);
 /* ------------------------------------------------------------------------------------
+ * Step-captioning decoder, one beam-search step per call (clip4caption/modules/module_decoder.py:279-406 as driven by
+ * clip4caption/train.py:511-599): embeds every beam's newest token, runs the post-LN decoder layers with each beam's kept
+ * self-attention K / V (gathered from its parent beam's row of the previous step), cross-attends to the encoded frames, applies the
+ * LM head and returns log_softmax + row_add.  Same numbers as re-running the whole prefix (the reference's -10000 "causal" penalty
+ * is exactly 0 after exp in fp32).  All pointers are device pointers except the HOST arrays marked so.  head width must be 64.
+ * ------------------------------------------------------------------------------------ */
+typedef struct hirest_caption_layer {
+    const float* qkv_w; const float* qkv_b;                         /* self-attention query | key | value, fused [3D, D], [3D] */
+    const float* so_w; const float* so_b; const float* so_ln_g; const float* so_ln_b;     /* slf_attn.output dense + LayerNorm */
+    const float* cq_w; const float* cq_b;                           /* enc_attn.att.query */
+    const float* co_w; const float* co_b; const float* co_ln_g; const float* co_ln_b;     /* enc_attn.output dense + LayerNorm */
+    const float* ff1_w; const float* ff1_b;                         /* intermediate.dense [I, D] (gelu) */
+    const float* ff2_w; const float* ff2_b; const float* ff_ln_g; const float* ff_ln_b;   /* output.dense [D, I] + LayerNorm */
+} hirest_caption_layer;
+typedef struct hirest_caption_decoder {
+    int32_t layers, heads, hidden, inter, vocab_padded, max_pos;
+    const float* word_emb; const float* pos_emb; const float* emb_ln_g; const float* emb_ln_b;
+    const hirest_caption_layer* layer;                              /* HOST array [layers] */
+    const float* tr_w; const float* tr_b; const float* tr_ln_g; const float* tr_ln_b;     /* cls.predictions.transform */
+    const float* lm_w; const float* lm_b;                           /* [vocab_padded, D] (tied to word_emb), [vocab_padded] */
+} hirest_caption_decoder;
+size_t hirest_caption_step_workspace_bytes(const hirest_caption_decoder* d, int32_t R);
+/* R beams (rows).  position = index of the newest token (0 for [CLS]).  kv_in / kv_out: HOST arrays of 2 * layers device buffers
+ * (K0, V0, K1, V1, ...): kv_in[.] holds [R, position, D] from the previous step (unused at position 0), kv_out[.] receives
+ * [R, position + 1, D]; they must not alias.  parent_rows[r] = the row of the previous step beam r continues (NULL at position 0).
+ * enc_kv: HOST array [layers] of [R, F, 2 D] cross-attention key | value rows.  logp: [R, vocab_padded]. */
+int hirest_caption_decode_step(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
+                               const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
+                               const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Joint model, training side: backward of MomentModel.train_moment_retrieval (modeling.py:155-270) in exact fp32.
  * Matrix products of the backward pass are hirest_gemm_f32 calls on transposed operands (dX = dY W: A = dY, W-operand = W^T;
  * dW = dY^T X: A = dY^T, W-operand = X^T over the zero-padded row count); the entries below are everything that is not a GEMM.
