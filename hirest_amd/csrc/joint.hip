@@ -42,15 +42,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     const float* ap = p.A + (int64_t)gm * p.lda + sk;
     const float* wp = p.W + (int64_t)gn * p.ldw + sk;
     // Summation order (shared with gemm_f32_skinny_kernel below, so that a row's result does not depend on how many rows the call
-    // has): slab s = k0 / 32 goes to partial sum s & 3; inside a slab MFMA step j pairs k0 + j (lanes < 32) with k0 + 16 + j
-    // (lanes >= 32); the four partial sums are added as ((p0 + p1) + p2) + p3.
-    f32x16 part[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) part[u][e] = 0.f;
-    const int arow = (wm * 32 + (lane & 31)) * FLD + 16 * (lane >> 5);
-    const int wrow = (wn * 32 + (lane & 31)) * FLD + 16 * (lane >> 5);
+    // has): K is cut into four contiguous quarters of ceil(nslab / 4) 32-deep slabs, quarter u gives partial sum p_u (slabs in
+    // ascending order; inside a slab MFMA step j pairs k0 + j (lanes < 32) with k0 + 16 + j (lanes >= 32)), and the result is
+    // ((p0 + p1) + p2) + p3.  Here the quarters are walked one after the other, so memory is read front to back and only one
+    // accumulator block is live (four live ones cost 13 % on moment retrieval / segmentation: occupancy).
+    // LDS slab image: k is stored at position 2 (k & 15) + (k >> 4), so the step that pairs k0 + j with k0 + 16 + j reads positions
+    // 2 j (lanes < 32) and 2 j + 1 (lanes >= 32): with the 33-float row stride both halves hit distinct banks.
+    const int arow = (wm * 32 + (lane & 31)) * FLD + (lane >> 5);
+    const int wrow = (wn * 32 + (lane & 31)) * FLD + (lane >> 5);
+    const int spos = 2 * (sk & 15) + (sk >> 4);          // position of this thread's first k; its 8 k's are 2 apart
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int k0, f32x4 (&av)[2], f32x4 (&wv)[2]) {
 #pragma unroll
@@ -60,28 +60,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
             wv[h] = in ? *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h) : zero;
         }
     };
+    const int nslab = (p.K + FK - 1) / FK;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     f32x4 av[2], wv[2];
     fetch(0, av, wv);
-    for (int kb = 0; kb < p.K; kb += 4 * FK) {
+    const int quarter = (nslab + 3) >> 2;
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {                             // partial sum u: slabs u * quarter .. (u + 1) * quarter - 1
+        f32x16 part;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k0 = kb + u * FK;
-            if (k0 >= p.K) break;                              // (block-uniform)
+        for (int e = 0; e < 16; ++e) part[e] = 0.f;
+        const int s_end = (u + 1) * quarter < nslab ? (u + 1) * quarter : nslab;
+#pragma unroll 1
+        for (int sl = u * quarter; sl < s_end; ++sl) {
             __syncthreads();
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { As[srow * FLD + sk + 4 * h + e] = av[h][e]; Ws[srow * FLD + sk + 4 * h + e] = wv[h][e]; }
+                for (int e = 0; e < 4; ++e) { As[srow * FLD + spos + 2 * (4 * h + e)] = av[h][e]; Ws[srow * FLD + spos + 2 * (4 * h + e)] = wv[h][e]; }
             __syncthreads();
-            if (k0 + FK < p.K) fetch(k0 + FK, av, wv);
+            if (sl + 1 < nslab) fetch((sl + 1) * FK, av, wv);
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                part[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + j], As[arow + j], part[u], 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + 2 * j], As[arow + 2 * j], part, 0, 0, 0);
+        }
+        if (u == 0) acc = part;
+        else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += part[e];
         }
     }
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
     const int m = M0 + wm * 32 + (lane & 31);
     if (m >= p.M) return;
 #pragma unroll
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
 
 // Few rows (M <= 256: beam-search decoding, 5-25 rows per step): the 64x64 kernel above runs as a handful of blocks whose K loop
 // is a chain of global-load latencies.  Here a block owns a 32x32 output tile and its four waves split K (wave w multiplies the
-// 32-deep slabs w, w + 4, ...), so 24-954 blocks x 4 waves work on a problem at once; operands go straight from global memory
+// w-th quarter of the 32-deep slabs), so 24-954 blocks x 4 waves work on a problem at once; operands go straight from global memory
 // into registers (lane = row, 16 consecutive k per half-wave, three slabs in flight — no LDS, no barrier in the loop).  MFMA step
 // j of a slab pairs k0 + j (lanes < 32) with k0 + 16 + j (lanes >= 32).  The four partial tiles are added in wave order through
 // LDS, so the result does not depend on timing.
@@ -119,10 +129,11 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF p) {
     const float* ap = p.A + (int64_t)gm * p.lda + 16 * khalf;
     const float* wp = p.W + (int64_t)gn * p.ldw + 16 * khalf;
     const int nslab = (p.K + FK - 1) / FK;
-    const int cnt = (nslab - wave + 3) >> 2;                // slabs of this wave
+    const int quarter = (nslab + 3) >> 2, first = wave * quarter;      // this wave's K quarter (see gemm_f32_kernel)
+    int cnt = nslab - first; cnt = cnt < 0 ? 0 : (cnt > quarter ? quarter : cnt);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     auto load = [&](int s, f32x4 (&a)[4], f32x4 (&w)[4]) {
-        const int k0 = (wave + 4 * s) * FK;
+        const int k0 = (first + s) * FK;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const bool in = s < cnt && k0 + 16 * khalf + 4 * h < p.K;     // K % 4 == 0: whole 4-vectors
