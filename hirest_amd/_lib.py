@@ -117,6 +117,9 @@ _SIGNATURES = {
                                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hirest_gemm_f32_select_kernel": (C.c_int, [C.c_int32]),
     "hirest_caption_step_workspace_bytes": (C.c_size_t, [C.POINTER(CaptionDecoder), C.c_int32]),
+    "hirest_beam_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "hirest_caption_decode_step": (C.c_int, [C.POINTER(CaptionDecoder), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -42,6 +42,32 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     if (i < n) p[i] = v;
 }
 
+// Beam bookkeeping of one step for every sample (clip4caption/modules/beam.py:70-92 given the device's top-`beam` of the
+// beam x vocabulary scores, which arrive sorted, so the reference's torch.sort of the scores is the identity).  One block per
+// sample, thread k = beam k.  A finished sample (top beam emitted [SEP] in an earlier step) is left untouched and gets inert rows.
+__global__ void beam_advance_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx, int beam, int vocab, int step,
+                                    int max_steps, int eos, float* __restrict__ scores, int32_t* __restrict__ tokens,
+                                    int32_t* __restrict__ backptr, int32_t* __restrict__ n_steps, int32_t* __restrict__ done,
+                                    int32_t* __restrict__ next_ids, int32_t* __restrict__ next_parents, float* __restrict__ next_add) {
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (k >= beam) return;
+    const int row = b * beam + k;
+    if (done[b]) {                                       // (block-uniform: written only by this block, in an earlier launch)
+        next_ids[row] = eos; next_parents[row] = row; next_add[row] = 0.f;
+        return;
+    }
+    const int flat = idx[row];
+    const int prev = flat / vocab, word = flat - prev * vocab;
+    scores[row] = val[row];
+    tokens[((int64_t)b * max_steps + step) * beam + k] = word;
+    backptr[((int64_t)b * max_steps + step) * beam + k] = prev;
+    next_ids[row] = word; next_parents[row] = b * beam + prev; next_add[row] = val[row];
+    if (k == 0) {
+        n_steps[b] = step + 1;
+        if (word == eos) done[b] = 1;                    // read by the NEXT launch only
+    }
+}
+
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws { size_t x, qkv, ctx, a, b, mid, logits, pos, total; };
@@ -120,5 +146,15 @@ extern "C" int hirest_caption_decode_step(const hirest_caption_decoder* d, int32
     CK(hirest_layernorm(a, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
     CK(hirest_gemm_f32(b, D, d->lm_w, D, d->lm_b, nullptr, 0, nullptr, 0, logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
     CK(hirest_log_softmax_f32(logits, d->vocab_padded, row_add, logp, d->vocab_padded, R, d->vocab_padded, stream));
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_beam_advance(const float* val, const int32_t* idx, int32_t B, int32_t beam, int32_t vocab, int32_t step,
+                                   int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr, int32_t* n_steps,
+                                   int32_t* done, int32_t* next_ids, int32_t* next_parents, float* next_add, void* stream) {
+    if (!val || !idx || !scores || !tokens || !backptr || !n_steps || !done || !next_ids || !next_parents || !next_add) return HIREST_E_BADARG;
+    if (B <= 0 || beam <= 0 || beam > 64 || vocab <= 0 || step < 0 || step >= max_steps) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), val, idx, beam, vocab, step,
+                       max_steps, eos_id, scores, tokens, backptr, n_steps, done, next_ids, next_parents, next_add);
     return hirest_launch_status();
 }

@@ -491,9 +491,10 @@ class MomentModel(nn.Module):
         return out
 
     def _beam_search_cached(self, beams, enc_kv_all, num_beams, max_words, return_ids):
-        """Beam search with one C-side call per word (csrc/caption.hip: ~35 kernels enqueued without returning to Python, each beam's
-        self-attention K / V kept and re-gathered by parent beam).  The row set never shrinks: a finished sample's rows keep being
-        computed and are ignored, which costs a few rows of tiny GEMMs and saves re-packing every buffer when a sample ends."""
+        """Beam search without a host round trip per word: one C-side decoder step (csrc/caption.hip: ~35 kernels enqueued without
+        returning to Python, each beam's self-attention K / V kept and re-gathered by parent beam), the top-k over beams x vocabulary
+        and the beam bookkeeping (`hirest_beam_advance`: beam.py:70-92) all stay on the device.  The host only watches the "done" flags,
+        two steps behind, to stop early.  The row set never shrinks: a finished sample's rows keep being computed and are ignored."""
         from .beam import BOS_ID, EOS_ID
         c, lib = self._w(), _lib.load()
         dev = c["dev"]
@@ -507,40 +508,45 @@ class MomentModel(nn.Module):
         cache = [torch.empty((2 * nl, R, max_words, Dm), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
         ptrs = [(C.c_void_p * (2 * nl))(*[cb[i].data_ptr() for i in range(2 * nl)]) for cb in cache]
         logp = torch.empty((R, Vp), dtype=torch.float32, device=dev)
-        active = set(range(B))
-        rowmap = {}
+        # device-side beam state (beam.py: scores, next_ys, prev_ks) and the inputs of the next step
+        ids = torch.full((R,), BOS_ID, dtype=torch.int32, device=dev)
+        parents = torch.arange(R, dtype=torch.int32, device=dev)
+        add = torch.full((B, num_beams), -3.0e38, dtype=torch.float32, device=dev)            # first step: only beam 0 competes
+        add[:, 0] = 0.0                                                                       # (beam.py:78)
+        scores = torch.zeros((R,), dtype=torch.float32, device=dev)
+        tokens = torch.zeros((B, max_words, num_beams), dtype=torch.int32, device=dev)
+        backptr = torch.zeros((B, max_words, num_beams), dtype=torch.int32, device=dev)
+        n_steps = torch.zeros((B,), dtype=torch.int32, device=dev)
+        done = torch.zeros((B,), dtype=torch.int32, device=dev)
+        done_host = [torch.zeros((B,), dtype=torch.int32).pin_memory() for _ in range(max_words)]
+        copied = [torch.cuda.Event() for _ in range(max_words)]
+        need = lib.hirest_topk_workspace_bytes(B, num_beams * Vp, num_beams)
+        tk_ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
+        val = torch.empty((B, num_beams), dtype=torch.float32, device=dev)
+        idx = torch.empty((B, num_beams), dtype=torch.int32, device=dev)
+        st = ops.stream_ptr()
         for t in range(1, max_words + 1):
-            # rows in the reference's order (get_tentative_hypothesis: beams by score); each brings its newest token, the row its
-            # parent beam had in the previous step, and its running score (beam.py:76; first step: only beam 0 competes, :78)
-            last, parents, add, new_map = [], [], [], {}
-            for b in range(B):
-                live = b in active
-                for r, k in enumerate(beams[b]._order() if live else range(num_beams)):
-                    row = b * num_beams + r
-                    new_map[(b, k)] = row
-                    if not live:
-                        last.append(EOS_ID); parents.append(row)
-                    elif t == 1:
-                        last.append(BOS_ID); parents.append(row)
-                    else:
-                        last.append(beams[b].tokens[-1][k]); parents.append(rowmap[(b, beams[b].backptr[-1][k])])
-                add.extend([(x if (t > 1 or k == 0) else -3.0e38) for k, x in enumerate(beams[b].scores)] if live
-                           else [0.0] * num_beams)
-            rowmap = new_map
-            ints = torch.tensor(last + parents, dtype=torch.int32).to(dev, non_blocking=True)
-            addt = torch.tensor(add, dtype=torch.float32).to(dev, non_blocking=True)
             _lib.check(lib.hirest_caption_decode_step(
-                C.byref(desc), R, t - 1, ints.data_ptr(), ints.data_ptr() + 4 * R if t > 1 else None,
-                ptrs[t & 1] if t > 1 else None, ptrs[(t + 1) & 1], enc_ptrs, F, addt.data_ptr(), logp.data_ptr(),
-                ws.data_ptr(), ws.numel(), ops.stream_ptr()), "hirest_caption_decode_step")
-            val, idx = ops.topk(logp.reshape(B, num_beams * Vp), num_beams)
-            both = torch.cat([val, idx.to(torch.float32)], 1).cpu()                              # ids < 2^24: exact in fp32
-            val_h, idx_h = both[:, :num_beams].tolist(), both[:, num_beams:].to(torch.int64).tolist()
-            for b in sorted(active):
-                if beams[b].advance(val_h[b], idx_h[b], Vp):
-                    active.discard(b)
-            if not active:
-                break
+                C.byref(desc), R, t - 1, ids.data_ptr(), parents.data_ptr() if t > 1 else None,
+                ptrs[t & 1] if t > 1 else None, ptrs[(t + 1) & 1], enc_ptrs, F, add.data_ptr(), logp.data_ptr(),
+                ws.data_ptr(), ws.numel(), st), "hirest_caption_decode_step")
+            _lib.check(lib.hirest_topk_f32_ws(logp.data_ptr(), None, B, num_beams * Vp, num_beams, idx.data_ptr(), val.data_ptr(),
+                                              tk_ws.data_ptr(), tk_ws.numel(), st), "hirest_topk_f32_ws")
+            _lib.check(lib.hirest_beam_advance(val.data_ptr(), idx.data_ptr(), B, num_beams, Vp, t - 1, max_words, EOS_ID,
+                                               scores.data_ptr(), tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(),
+                                               done.data_ptr(), ids.data_ptr(), parents.data_ptr(), add.data_ptr(), st),
+                       "hirest_beam_advance")
+            done_host[t - 1].copy_(done, non_blocking=True)
+            copied[t - 1].record()
+            if t >= 3:                                   # look at the flags of two steps ago: never waits for the GPU
+                copied[t - 3].synchronize()
+                if int(done_host[t - 3].min()) == 1:
+                    break
+        tok_h, bp_h, n_h, sc_h = tokens.cpu().tolist(), backptr.cpu().tolist(), n_steps.cpu().tolist(), scores.view(B, -1).cpu().tolist()
+        for b in range(B):                               # hand the recorded search to the host-side BeamState for the read-out
+            beams[b].scores = sc_h[b]
+            beams[b].backptr = [bp_h[b][j] for j in range(n_h[b])]
+            beams[b].tokens = [[BOS_ID] * num_beams] + [tok_h[b][j] for j in range(n_h[b])]
         return self._caption_result(beams, return_ids)
 
     @torch.no_grad()

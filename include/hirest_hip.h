@@ -345,6 +345,15 @@ int hirest_caption_decode_step(const hirest_caption_decoder* d, int32_t R, int32
                                const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Beam bookkeeping of one decoding step on the device (clip4caption/modules/beam.py:70-92): val / idx = the sorted top-`beam` of
+ * every sample's beam x vocab scores ([B, beam]; idx = source_beam * vocab + word).  Per sample b that is not done: scores <- val,
+ * tokens[b][step][k] / backptr[b][step][k] record (word, source beam), n_steps[b] = step + 1, done[b] = 1 once the best beam emits
+ * eos_id; next_ids / next_parents / next_add ([B * beam]) are the inputs of the next hirest_caption_decode_step.  Done samples keep
+ * their state and get inert rows.  tokens / backptr: int32 [B, max_steps, beam]. */
+int hirest_beam_advance(const float* val, const int32_t* idx, int32_t B, int32_t beam, int32_t vocab, int32_t step, int32_t max_steps,
+                        int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr, int32_t* n_steps, int32_t* done,
+                        int32_t* next_ids, int32_t* next_parents, float* next_add, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Joint model, training side: backward of MomentModel.train_moment_retrieval (modeling.py:155-270) in exact fp32.
  * Matrix products of the backward pass are hirest_gemm_f32 calls on transposed operands (dX = dY W: A = dY, W-operand = W^T;
