@@ -177,6 +177,12 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     assert model.caption_kv_cache
     model.caption_kv_cache = False
     assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
+    # greedy decoding (one beam) and a wider beam through both paths
+    for nb in (1, 7):
+        model.caption_kv_cache = False
+        ref = model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"]
+        model.caption_kv_cache = True
+        assert model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"] == ref, nb
 
 
 def test_clip_text_ids_path_equals_text_feat_path(dev, golden_dir):
