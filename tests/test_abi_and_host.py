@@ -44,6 +44,18 @@ def test_argument_errors_without_gpu(lib):
     assert lib.hirest_layernorm(None, 0, None, None, None, 0.0, None, 0, 0, 0, 0, None) == -1
     assert lib.hirest_attention_bf16(None, None, 1, 1, 1, 64, 1.0, 0, None) == -1
     assert lib.hirest_vision_workspace_bytes(None, 4) == 0
+    # round-2 entry points: captioning step, beam bookkeeping, ragged BERT batch, fp32 GEMM selector
+    d = _lib.CaptionDecoder(2, 12, 768, 3072, 30528, 512)
+    al = lambda v: (v + 255) // 256 * 256
+    assert lib.hirest_caption_step_workspace_bytes(ctypes.byref(d), 25) == \
+        5 * al(25 * 768 * 4) + al(25 * 3 * 768 * 4) - al(25 * 768 * 4) + al(25 * 3072 * 4) + al(25 * 30528 * 4) + al(25 * 4)
+    assert lib.hirest_caption_step_workspace_bytes(None, 25) == 0
+    assert lib.hirest_caption_decode_step(ctypes.byref(d), 25, 0, None, None, None, None, None, 20, None, None, None, 0, None) == -1
+    assert lib.hirest_beam_advance(None, None, 5, 5, 30528, 0, 48, 102, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.hirest_attention_f32_varlen(None, None, None, 1, 1, 12, 64, 0.125, 0.0, None) == -1
+    assert lib.hirest_pool_l2norm_varlen(None, None, None, 1, 384, None) == -1
+    assert lib.hirest_embedding_pos_fwd_f32(None, None, None, None, None, 1, 384, None) == -1
+    assert lib.hirest_gemm_f32_select_kernel(2) == -1 and lib.hirest_gemm_f32_select_kernel(0) == 0
 
 
 def test_workspace_size_formula(lib):
