@@ -40,7 +40,7 @@ N_QUERIES = 546                 # size of the real HiREST test prompt set
 TOPK = 10
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 GFLOP_PER_FRAME = 534.06        # algorithmic work of the vision tower
-PROFILE_ROUNDS = ("r02", "r01")  # newest first: where roofline.traffic is looked up
+PROFILE_ROUNDS = ("r03", "r02", "r01")  # newest first: where roofline.traffic is looked up
 
 
 def matched_recall(model, dev):
@@ -203,10 +203,11 @@ def main():
     tokens = synth.tokens("bench.queries", N_QUERIES, 5).to(dev)
     text_n = retrieval.encode_texts(model, tokens)            # queries encoded once, outside the frame metric
     V_total = V_local * world
+    gather = retrieval.RowGather()                                          # receive buffer allocated once, reused every step
 
     def step():
         pooled = retrieval.encode_videos(model, frames)                     # [V_local, 1024]
-        allv = retrieval.gather_rows(pooled, V_total)                       # RCCL all-gather (no-op at N=1)
+        allv = gather(pooled, V_total)                                      # RCCL all-gather (no-op at N=1)
         _, val, idx = retrieval.retrieve(text_n, allv, min(TOPK, V_total))
         return idx
 

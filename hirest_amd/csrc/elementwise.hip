@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void rowstats_bf16_kernel(const float* __restr
         var = var > 0.0 ? var : 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (int64_t)row) = f32x2{(float)mean, rstd};
-        worst = fmaxf(worst, fabsf((float)mean) * rstd);
+        const float r = fabsf((float)mean) * rstd;
+        worst = r <= 3.0e38f ? fmaxf(worst, r) : __builtin_inff();   // a NaN / inf row trips the guard (fmaxf alone would drop a NaN)
     }
     if (guard && lane == 0) guard_max(guard, worst);
 }
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{(float)mean, rstd};
         ratio = fabsf((float)mean) * rstd;
+        ratio = ratio <= 3.0e38f ? ratio : __builtin_inff();          // NaN / inf rows trip the guard
     }
     if (guard) {
         ratio = wave_max(ratio);

@@ -234,7 +234,7 @@ class VisionTower(_Tower):
             if goff != _NO_GUARD:
                 ratio = float(ws[goff:goff + 4].view(torch.float32).item())
                 self.last_fold_ratio = max(self.last_fold_ratio, ratio)
-                if not ratio <= self.fold_guard_ratio:                      # also catches NaN
+                if not ratio <= self.fold_guard_ratio:                      # non-finite rows report +inf (elementwise.hip)
                     self.fold_fallbacks += 1
                     _lib.check(lib.hirest_vision_forward(*args, _lib.TOWER_NO_LNFOLD, ops.stream_ptr()), "hirest_vision_forward")
         return out

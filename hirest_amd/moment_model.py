@@ -164,17 +164,27 @@ class MomentModel(nn.Module):
             self.clip_model.eval()
 
     def _w(self):
-        """fp32 contiguous device views + fused QKV weights, built once per parameter version."""
+        """fp32 contiguous device views + fused QKV weights, built once per parameter version.
+
+        Most entries are views of the parameters and follow in-place optimizer updates; the fused / padded tensors
+        (QKV concatenations, padded LM head, head biases, any non-fp32 parameter) are COPIES, so the cache remembers the
+        ``_version`` counters of their sources and is rebuilt when one of them has moved (run.py:328-336 validates after
+        every epoch of in-place AdamW steps)."""
         if self._cache is not None:
-            return self._cache
+            if sum(p._version for p in self._cache["copied"]) == self._cache["copied_version"]:
+                return self._cache
+            self._cache = None
         dev = self.clip_g_map.weight.device
         if dev.type != "cuda":
             raise RuntimeError("hirest_amd.MomentModel runs on MI355X only (no CPU fallback); move the model to a GPU")
         f = lambda t: t.detach().float().contiguous()
         c = {"dev": dev}
+        copied = []
         for name, prm in self.named_parameters():
             if not name.startswith("clip_model."):
                 c[name] = f(prm)
+                if c[name].data_ptr() != prm.data_ptr():
+                    copied.append(prm)
         for i, lay in enumerate(self.clip4cap_model.visual.encoder.layer):
             s = lay.attention.self
             c[f"qkv_w.{i}"] = torch.cat([f(s.query.weight), f(s.key.weight), f(s.value.weight)], 0).contiguous()
@@ -217,6 +227,14 @@ class MomentModel(nn.Module):
             c["lm_w"].data_ptr(), c["lm_b"].data_ptr())
         c["head_bias"] = torch.cat([f(getattr(m, "0").bias) for m in
                                     (self.start_predictor, self.end_predictor, self.segment_predictor)]).contiguous()
+        for lay in self.clip4cap_model.visual.encoder.layer:
+            copied += [q for m in (lay.attention.self.query, lay.attention.self.key, lay.attention.self.value) for q in m.parameters()]
+        for lay in self.clip4cap_model.decoder.decoder.layer:
+            copied += [q for a in (lay.slf_attn.att, lay.enc_attn.att) for m in (a.query, a.key, a.value) for q in m.parameters()]
+        copied += [self.clip4cap_model.decoder.embeddings.word_embeddings.weight, self.clip4cap_model.decoder.classifier.cls.predictions.bias]
+        copied += [getattr(m, "0").bias for m in (self.start_predictor, self.end_predictor, self.segment_predictor)]
+        c["copied"] = copied
+        c["copied_version"] = sum(p._version for p in copied)
         self._cache = c
         return c
 

@@ -99,12 +99,14 @@ _default_gather: Dict[object, RowGather] = {}
 
 def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """All-gather equally padded row blocks [per, E] -> [n_total, E] in rank order.  Works on any backend (RCCL on GPU
-    tensors, gloo on CPU tensors); a no-op without an initialised group.  The returned tensor is a view of a buffer that
-    the next call with the same shape overwrites (see RowGather)."""
+    tensors, gloo on CPU tensors); a no-op without an initialised group.  Returns a tensor of its own (two consecutive
+    gathers of the same shape — video rows, then text rows — do not alias); a steady-state loop that wants the
+    allocation-free form holds a ``RowGather`` and calls that (bench.py does)."""
     g = _default_gather.get(group)
     if g is None:
         g = _default_gather[group] = RowGather(group)
-    return g(local, n_total)
+    out = g(local, n_total)
+    return out.clone() if out.data_ptr() != local.data_ptr() else out
 
 
 def tie_rank_from_names(names: Sequence[str], device=None) -> torch.Tensor:

@@ -367,3 +367,129 @@ def sentence_ids(name: str, n: int, seed: int, vocab_size: int, min_len: int = 2
             else np.zeros(0, np.int64)
         rows.append([cls_id] + [int(x) for x in body] + [sep_id])
     return rows
+
+
+# ----------------------------------------------------------------------------------
+# Seeded input builders of the joint-model / evaluation / timeline fixtures.  tests/golden/make_golden.py feeds these to the
+# real reference; the GPU tests, tools/ and bench.py rebuild the same inputs from here (nothing in them touches the reference).
+# ----------------------------------------------------------------------------------
+
+def joint_inputs(name, B, T, seed):
+    """C4-style synthetic batch: L2-normalised frame features, sparse ASR features, ragged lengths."""
+    vis = tensor(f"{name}.vis", (B, T, 1024), 1.0, seed)
+    vis = vis / vis.norm(dim=-1, keepdim=True)
+    asr = tensor(f"{name}.asr", (B, T, 384), 0.05, seed)
+    gaps = uniform_pm1(f"{name}.gap", B * T, seed).reshape(B, T) > 0.2      # ~40 % all-zero rows
+    asr = asr * torch.from_numpy(~gaps).float()[..., None]
+    text = tensor(f"{name}.text", (B, 1024), 1.0, seed)
+    lens = [T - (b * T) // (3 * B) for b in range(B)]                             # ragged
+    vis_mask = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate(lens):
+        vis_mask[b, :n] = 1
+        vis[b, n:] = 0
+        asr[b, n:] = 0
+    bounds = torch.tensor([[int(0.1 * n), int(0.8 * n)] for n in lens], dtype=torch.long)
+    moment_mask = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        moment_mask[b, bounds[b, 0]:bounds[b, 1] + 1] = 1
+    return vis, asr, text, vis_mask, moment_mask, bounds
+
+
+TRAIN_CASES = {"a": (3, 64), "b": (2, 300)}
+
+
+def train_targets(name, B, T, seed, bounds):
+    """start / end targets inside the moment, a previous-boundary mask and a segmentation target (hirest_dataset.py:409-531 keys)."""
+    u = (uniform_pm1(f"{name}.tgt", 4 * B, seed).reshape(4, B) + 1.0) * 0.5
+    lo, hi = bounds[:, 0].numpy(), bounds[:, 1].numpy()
+    st = (lo + u[0] * (hi - lo)).astype(np.int64)
+    et = np.maximum(st, (lo + u[1] * (hi - lo)).astype(np.int64))
+    seg = (lo + u[2] * (hi - lo)).astype(np.int64)
+    prev = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        prev[b, int(lo[b])] = 1
+    return torch.from_numpy(st), torch.from_numpy(et), torch.from_numpy(seg), prev
+
+
+def caption_targets(name, B, max_words, seed):
+    """Teacher-forcing triples in the reference's target_text 9-tuple layout (fields 5, 6, 7: decoder input ids, decoder mask,
+    output ids with -1 on the padding): [CLS] w1 .. wn  /  w1 .. wn [SEP]."""
+    u = (uniform_pm1(f"{name}.cap", B * (max_words + 1), seed).reshape(B, max_words + 1) + 1.0) * 0.5
+    out = []
+    for b in range(B):
+        n = 3 + int(u[b, 0] * (max_words - 8))
+        words = (1000 + (u[b, 1:1 + n] * 29000)).astype(np.int64).tolist()
+        inp = [101] + words + [0] * (max_words - 1 - n)
+        mask = [1] * (n + 1) + [0] * (max_words - 1 - n)
+        outp = words + [102] + [-1] * (max_words - 1 - n)
+        out.append((None, None, None, None, None, inp, mask, outp, None))
+    return out
+
+
+def moment_eval_inputs():
+    """Seeded synthetic gt / predictions in evaluate.py's JSON layouts (shared with tests/test_evaluation.py)."""
+    cats = ["Food", "Hobbies", "Home"]
+    u = uniform_pm1("moment_eval", 20000, 17)
+    it = iter(((u + 1.0) * 0.5).tolist())
+    rnd = lambda lo, hi: lo + (hi - lo) * next(it)
+    prompt_to_cat, video_to_cat = {}, {}
+    mr_gt, mr_pred, sb_gt, sb_pred = {}, {}, {}, {}
+    for pi in range(24):
+        prompt = f"prompt {pi}"
+        prompt_to_cat[prompt] = cats[pi % 3]
+        mr_gt[prompt], mr_pred[prompt] = {}, {}
+        for vi in range(1 + pi % 3):
+            video = f"vid_{pi}_{vi}.mp4"
+            video_to_cat[video] = cats[(pi + vi) % 3]
+            dur = int(rnd(40, 600))
+            a = int(rnd(0, dur * 0.6)); b = a + 1 + int(rnd(2, dur * 0.4))
+            clip = (pi + vi) % 5 != 0
+            mr_gt[prompt][video] = {"clip": clip, "bounds": [a, b], "v_duration": dur}
+            mode = (pi + 2 * vi) % 6
+            if mode == 0:
+                pb = [a, b]                                            # exact
+            elif mode == 1:
+                pb = [b + 3, b + 9]                                    # disjoint
+            elif mode == 2:
+                pb = [a, a + (b - a) // 2]                             # IoU near 0.5
+            else:
+                pb = [max(0, a + int(rnd(-15, 15))), b + int(rnd(-15, 15))]
+                if pb[1] <= pb[0]:
+                    pb[1] = pb[0] + 1
+            mr_pred[prompt][video] = {"bounds": pb}
+            if clip:
+                n_steps = 2 + int(rnd(0, 7))
+                cuts = sorted(set([a, b] + [int(rnd(a + 1, b - 1)) for _ in range(n_steps)]))
+                refs = [[cuts[i], cuts[i + 1]] for i in range(len(cuts) - 1)]
+                sb_gt[video] = {"bounds": refs}
+                preds = []
+                for r in refs:                                         # jittered, duplicated, nested and outside boxes
+                    if next(it) < 0.8:
+                        preds.append([r[0] + int(rnd(-3, 4)), r[1] + int(rnd(-3, 4))])
+                    if next(it) < 0.3:
+                        preds.append([r[0] + 1, r[1] - 1] if r[1] - r[0] > 3 else [r[0], r[1]])
+                if next(it) < 0.5:
+                    preds.append([a - 5, a + 2])
+                if next(it) < 0.3:
+                    preds.append([rnd(a, b), rnd(a, b) + 2.5])         # float bounds
+                preds = [p if p[1] > p[0] else [p[0], p[0] + 1] for p in preds]
+                sb_pred[video] = {"bounds": preds}
+    return {"prompt_to_cat": prompt_to_cat, "video_to_cat": video_to_cat, "mr_gt": mr_gt, "mr_pred": mr_pred,
+            "sb_gt": sb_gt, "sb_pred": sb_pred}
+
+
+def timeline_cases():
+    """Inputs of the frame-index <-> timestamp fixture (pure numpy; shared with tests/test_timeline.py): per case the
+    frame indices 0..n-1 and a timestamp list holding a regular sweep past the end, every bin value exactly, and the
+    doubles just below / above every bin (the digitize(right=True) edge)."""
+    cases = []
+    for dur in (1.0, 1.9, 2.0, 3.7, 17.3, 59.9, 60.0, 199.99, 200.0, 367.8, 571.4, 1855.2, 2500.5):
+        for n in (-1, 1, 2, 3, 20, 32, 64, 300, 2048):
+            nn = int(dur) if n < 0 else n
+            bins = np.linspace(0, int(dur) - 1, nn)
+            t = np.concatenate([np.arange(-1.0, dur + 3.0, 0.37), bins, np.nextafter(bins, -np.inf), np.nextafter(bins, np.inf),
+                                np.arange(0, int(dur) + 2, dtype=np.float64)])
+            cases.append({"duration": dur, "n_frames": n, "frames": np.arange(nn, dtype=np.int64), "timestamps": t})
+    return cases
+
+

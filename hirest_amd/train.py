@@ -633,13 +633,20 @@ def allreduce_gradients(parameters, group=None, bucket_bytes: int = 64 << 20) ->
     DistributedDataParallel is there for.  (The reference calls ``model.module.train_step`` directly, run.py:247-255, which
     bypasses DDP's forward and with it the reducer's bookkeeping; an explicit bucketed all-reduce after ``loss.backward()`` is
     the dependable form of the same exchange.)  Gradients are packed into flat fp32 buckets of up to `bucket_bytes` so the
-    63 M parameters travel as a handful of large messages over xGMI instead of ~130 small ones; a parameter without a gradient
-    on this rank contributes zeros (every rank must present the same buckets)."""
+    63 M parameters travel as a handful of large messages over xGMI instead of ~130 small ones.  Only parameters that
+    received a gradient on SOME rank take part (agreed on with one all-reduced bitmask): a task leaves the other tasks' heads,
+    ``moment_conv`` and — for the moment tasks — the whole caption decoder without a gradient, and those must stay ``None``
+    as in a single-process run so that AdamW skips them (no weight decay, no moment decay, no step count)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
     params = [p for p in parameters if p.requires_grad]
+    if not params:
+        return
+    has = torch.tensor([1 if p.grad is not None else 0 for p in params], dtype=torch.int32, device=params[0].device)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
+    params = [p for p, h in zip(params, has.tolist()) if h]
     bucket, size = [], 0
 
     def flush():

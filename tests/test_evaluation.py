@@ -9,8 +9,7 @@ import pytest
 import torch
 
 HERE = os.path.dirname(__file__)
-sys.path.insert(0, os.path.join(HERE, "golden"))
-from make_golden import moment_eval_inputs  # noqa: E402  (pure-python generator; does not touch /root/reference)
+from hirest_amd.synth import moment_eval_inputs
 from oracle import eval_cpu as E  # noqa: E402
 
 GOLD = json.load(open(os.path.join(HERE, "golden", "moment_eval.json")))

@@ -103,8 +103,7 @@ def test_attention_f32_with_constant_shift(dev, B, T, H):
 
 
 def _case(golden_dir, case):
-    sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs
+    from hirest_amd.synth import joint_inputs
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
     pred = json.load(open(os.path.join(golden_dir, "joint_predictions.json")))[case]
     g = np.load(os.path.join(golden_dir, f"joint_{case}.npz"))
@@ -150,8 +149,7 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     """BASELINE configs[4] in miniature: trim_feats + encoder + beam-searched decoder; token ids exact vs the
     REAL reference MomentModel.test_step (tests/golden/caption_predictions.json)."""
     import hirest_amd
-    sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs
+    from hirest_amd.synth import joint_inputs
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
     sd = synth.joint_state_dict(shapes, 31)
     sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
@@ -191,8 +189,7 @@ def test_clip_text_ids_path_equals_text_feat_path(dev, golden_dir):
     tasks from token ids; feeding the same encoder's output as batch['text_feat'] must give bit-identical predictions,
     and the ids really matter (other prompts -> other text features)."""
     import hirest_amd
-    sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs
+    from hirest_amd.synth import joint_inputs
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
     sd = synth.joint_state_dict(shapes, 31)
     sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5

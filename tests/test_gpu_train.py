@@ -23,8 +23,7 @@ def dev():
 
 def _setup(golden_dir, case, dev):
     import hirest_amd
-    sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs, train_targets, caption_targets, TRAIN_CASES
+    from hirest_amd.synth import joint_inputs, train_targets, caption_targets, TRAIN_CASES
     B, T = TRAIN_CASES[case]
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
     model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
@@ -124,3 +123,38 @@ def test_training_loop_contract_and_dropout(dev, golden_dir):
     # predictions still come out of the updated weights through the inference path
     out = model.test_step(dict(batch, tasks=["moment_retrieval"]))["prediction"]
     assert len(out) == batch["vis_feats"].shape[0]
+
+
+def test_inference_cache_follows_optimizer_updates(dev, golden_dir):
+    """run.py:328-336 validates after every epoch: test_step -> train (in-place AdamW) -> test_step must run on the UPDATED
+    weights everywhere, including the fused / padded copies the inference path caches (QKV concatenations, padded LM head,
+    head biases).  The second test_step has to equal a model freshly loaded from the updated state_dict, bit for bit."""
+    import hirest_amd
+    model, batch, seg_batch, cap_batch, _ = _setup(golden_dir, "a", dev)
+    model.eval()
+    tb = dict(batch, tasks=["moment_retrieval"])
+    cb = dict(cap_batch, tasks=["step_captioning"])
+    before = model.test_step(tb)["prediction"]
+    model.test_step(cb, num_beams=3, return_ids=True)         # fills the decoder part of the cache as well
+    optim = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-3)
+    for b in (batch, cap_batch, seg_batch, batch):
+        model.train_step(b)["loss"].backward()
+        optim.step()
+        for p in model.parameters():
+            p.grad = None
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    fresh = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=False)
+    fresh = fresh.to(dev).eval()
+    from hirest_amd.synth import joint_inputs, TRAIN_CASES
+    bounds = joint_inputs("train.a", *TRAIN_CASES["a"], 53)[-1]
+    sb = dict(batch, tasks=["moment_segmentation"], moment_bound_frames=bounds)
+    for tb_, kw in ((tb, {}), (sb, {}), (cb, {"num_beams": 3, "return_ids": True})):
+        got, want = model.test_step(tb_, **kw), fresh.test_step(tb_, **kw)
+        assert json.dumps(got, default=str, sort_keys=True) == json.dumps(want, default=str, sort_keys=True), tb_["tasks"]
+    fl = model.forward_moment_retrieval(batch["vis_feats"].to(dev), batch["text_feat"].to(dev), batch["vis_mask"].to(dev),
+                                        batch["moment_mask"].to(dev), batch["asr_feats"].to(dev))
+    ff = fresh.forward_moment_retrieval(batch["vis_feats"].to(dev), batch["text_feat"].to(dev), batch["vis_mask"].to(dev),
+                                        batch["moment_mask"].to(dev), batch["asr_feats"].to(dev))
+    assert torch.equal(fl["start_logits"], ff["start_logits"]) and torch.equal(fl["end_logits"], ff["end_logits"])
+    assert before is not None

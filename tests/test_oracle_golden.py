@@ -134,8 +134,7 @@ def test_tokenizer_matches_reference(golden_dir):
 
 def _joint_case(golden_dir, case):
     import sys
-    sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs
+    from hirest_amd.synth import joint_inputs
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
     sd = synth.joint_state_dict(shapes, 31)
     pred = json.load(open(os.path.join(golden_dir, "joint_predictions.json")))
@@ -168,8 +167,7 @@ def test_step_captioning_matches_reference(golden_dir, case):
     """trim_feats + fusion/encoder on 20 frames + 2-layer decoder + beam search vs the real MomentModel
     (token ids exact; the reference's tokenizer is stubbed to print ids)."""
     import sys
-    sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs
+    from hirest_amd.synth import joint_inputs
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
     sd = synth.joint_state_dict(shapes, 31)
     sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
@@ -223,8 +221,7 @@ def test_training_loss_and_gradients_match_reference(golden_dir, case):
     """SURVEY 8f-4 oracle: autograd on the restated train_moment_retrieval equals the REAL reference's loss.backward()
     (tests/golden/train_*.npz: all 56 trainable tensors that receive a gradient), and the segmentation loss value."""
     import sys
-    sys.path.insert(0, golden_dir)
-    from make_golden import joint_inputs, train_targets, TRAIN_CASES
+    from hirest_amd.synth import joint_inputs, train_targets, TRAIN_CASES
     g = load(golden_dir, f"train_{case}.npz")
     B, T = TRAIN_CASES[case]
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
@@ -251,7 +248,7 @@ def test_training_loss_and_gradients_match_reference(golden_dir, case):
     n_ret = check(O.moment_retrieval_loss(sd, vis, text, asr, vis_mask, moment_mask, st, et), "")
     n_seg = check(O.moment_segmentation_loss(sd, vis, text, asr, vis_mask, moment_mask, prev, seg), "seg.")
     # step captioning: the tied LM-head / input-embedding matrix is ONE parameter in the reference (first registered name)
-    from make_golden import caption_targets
+    from hirest_amd.synth import caption_targets
     tied_a, tied_b = "clip4cap_model.decoder.embeddings.word_embeddings.weight", "clip4cap_model.decoder.classifier.cls.predictions.decoder.weight"
     tied = sd[tied_a]
     sd[tied_b] = tied

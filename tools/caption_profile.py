@@ -3,10 +3,9 @@
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import hirest_amd
 from hirest_amd import synth
-from make_golden import joint_inputs
+from hirest_amd.synth import joint_inputs
 shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "joint_schema.json"))).items()}
 sd = synth.joint_state_dict(shapes, 31)
 dev = torch.device("cuda:0")

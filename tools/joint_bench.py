@@ -9,10 +9,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import hirest_amd  # noqa: E402
 from hirest_amd import synth  # noqa: E402
-from make_golden import joint_inputs  # noqa: E402
+from hirest_amd.synth import joint_inputs
 from oracle import ref_cpu as O  # noqa: E402
 
 shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "joint_schema.json"))).items()}

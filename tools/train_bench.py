@@ -12,10 +12,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import hirest_amd  # noqa: E402
 from hirest_amd import synth  # noqa: E402
-from make_golden import joint_inputs, train_targets, caption_targets  # noqa: E402
+from hirest_amd.synth import joint_inputs, train_targets, caption_targets
 from oracle import ref_cpu as O  # noqa: E402
 
 
