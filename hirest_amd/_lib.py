@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
  EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16) = range(9)
 
 TOWER_NO_LNFOLD = 1
+TOWER_NO_PRUNE = 2
 GEMM_REVERSE = 1
 ABI_VERSION = 3   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
 
@@ -92,6 +93,8 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_attention_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_float, C.c_int32, C.c_void_p]),
+    "hirest_attention_bf16_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_patchify": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_void_p]),
     "hirest_rowstats_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

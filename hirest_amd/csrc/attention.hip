@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 // still owns 5 tiles, but every SIMD has a third instruction stream to cover softmax VALU and LDS latency with).
 template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
 __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                          int N, int H, float scale_log2e, int causal, int dbg_bits) {
+                                                          int N, int H, float scale_log2e, int causal, int dbg_bits, int nq) {
     const int dbg = DBG ? dbg_bits : 0;   // timing-experiment switches fold away in the production instantiation
     using C = AttnCfg2<DH, DP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
     const bf16_t* fbase = qkv + (int64_t)b * N * ld;
     const int g = lane >> 4, c16 = lane & 15;
     const int gk = g ^ ((-(c16 >> 2)) & 3);
-    const int nqt = (N + 15) >> 4;
+    const int nqt = (nq + 15) >> 4;   // query tiles to compute: all of them, or the leading ones only (hirest_attention_bf16_rows)
 
     // LDS-DMA piece i of this wave covers 16-B chunks ci = i*64 + lane, i = wave, wave + 9, ...: 576 chunks = 48 rows
     // further each time, same column -> one (row0, column) pair per lane.
@@ -522,22 +522,22 @@ int g_attn_dbg = 0;   // timing experiments only (hirest_attention_debug_mode)
 int g_attn_variant = 3;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame, 9 waves; default for N > 80), 4 = v3 with 12 waves
 
 template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9>
-int launch3_impl(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
+int launch3_impl(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, int nq, hipStream_t s) {
     using C = AttnCfg2<DH, DP, NT>;
     constexpr int LDS = (2 * C::NPAD + C::KP) * C::RS;
     static_assert(LDS <= 163840, "K x2 + V must fit the CU's LDS");
     static HirestDevCfg cfg;
     auto kern = attention_kernel_v3<DH, DP, NT, FAST, DBG, NW>;
     if (int e = hirest_configure(kern, LDS, cfg)) return e;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg, nq);
     return hirest_launch_status();
 }
 
 template <int DH, int DP, int NT, bool FAST>
-int launch3(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, hipStream_t s) {
-    if (g_attn_dbg && FAST) return launch3_impl<DH, DP, NT, FAST, true>(qkv, out, B, N, H, scale, causal, s);
-    if (g_attn_variant == 4) return launch3_impl<DH, DP, NT, FAST, false, 12>(qkv, out, B, N, H, scale, causal, s);
-    return launch3_impl<DH, DP, NT, FAST, false>(qkv, out, B, N, H, scale, causal, s);
+int launch3(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, int causal, int nq, hipStream_t s) {
+    if (g_attn_dbg && FAST) return launch3_impl<DH, DP, NT, FAST, true>(qkv, out, B, N, H, scale, causal, nq, s);
+    if (g_attn_variant == 4) return launch3_impl<DH, DP, NT, FAST, false, 12>(qkv, out, B, N, H, scale, causal, nq, s);
+    return launch3_impl<DH, DP, NT, FAST, false>(qkv, out, B, N, H, scale, causal, nq, s);
 }
 
 
@@ -563,17 +563,23 @@ extern "C" int hirest_attention_select_kernel(int32_t which) {
 
 extern "C" int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out, int32_t B, int32_t N, int32_t H,
                                      int32_t dh, float scale, int32_t causal, void* stream) {
-    if (!qkv || !out || B <= 0 || N <= 0 || H <= 0) return HIREST_E_BADARG;
+    return hirest_attention_bf16_rows(qkv, out, B, N, H, dh, scale, causal, N, stream);
+}
+
+extern "C" int hirest_attention_bf16_rows(const hirest_bf16* qkv, hirest_bf16* out, int32_t B, int32_t N, int32_t H,
+                                          int32_t dh, float scale, int32_t causal, int32_t q_rows, void* stream) {
+    if (!qkv || !out || B <= 0 || N <= 0 || H <= 0 || q_rows <= 0 || q_rows > N) return HIREST_E_BADARG;
+    const int nq = q_rows;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
     bf16_t* o = reinterpret_cast<bf16_t*>(out);
     HirestProfScope prof(HIREST_PROF_ATTENTION, causal, (int64_t)B * H, N, dh, s);
     if (g_attn_variant >= 3 && N > 80 && N <= 272 && B >= 64) {
         const bool fast = !causal && N > 256;
-        if (dh == 88) return fast ? launch3<88, 96, 17, true>(q, o, B, N, H, scale, causal, s)
-                                  : launch3<88, 96, 17, false>(q, o, B, N, H, scale, causal, s);
-        if (dh == 64) return fast ? launch3<64, 64, 17, true>(q, o, B, N, H, scale, causal, s)
-                                  : launch3<64, 64, 17, false>(q, o, B, N, H, scale, causal, s);
+        if (dh == 88) return fast ? launch3<88, 96, 17, true>(q, o, B, N, H, scale, causal, nq, s)
+                                  : launch3<88, 96, 17, false>(q, o, B, N, H, scale, causal, nq, s);
+        if (dh == 64) return fast ? launch3<64, 64, 17, true>(q, o, B, N, H, scale, causal, nq, s)
+                                  : launch3<64, 64, 17, false>(q, o, B, N, H, scale, causal, nq, s);
     }
     if (g_attn_variant >= 2) {
         if (dh == 88) {

@@ -1305,7 +1305,8 @@ int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 w
 // LN-fold epilogues exist in the persistent kernels only
 template <int EPI>
 int launch_fused(const GemmP& p, hipStream_t s) {
-    const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
+    // (the persistent kernels take any M, N: a small problem just leaves CUs idle — the CLS-row GEMMs of a tower's last block)
+    const bool big = p.M >= 64 && p.N >= 256;
     if (!big || !p.aux0 || !p.aux1) return !big ? HIREST_E_SHAPE : HIREST_E_BADARG;
     if (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
     GemmP q = p; q.dbg = 0;
@@ -1353,8 +1354,8 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (!a || a->struct_size != sizeof(hirest_gemm_args) || !out || out_len < 48) return HIREST_E_BADARG;
     const int epi = a->epilogue, f = g_force_kernel;
     if (epi < 0 || epi > HIREST_EPI_LNFOLD_GELU_BF16) return HIREST_E_BADARG;
-    const bool big = (int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256;
     const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
+    const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
     const bool w4_ok = epi != HIREST_EPI_BIAS_QGELU_BF16 && epi != HIREST_EPI_PATCH_POS_F32;
     const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;

@@ -105,6 +105,27 @@ int run_block_lnfold(const hirest_block_weights& w, float* x, hirest_bf16* h, hi
     return 0;
 }
 
+// The LAST block of a tower whose caller reads only token 0 of every frame (vit_model.py:340-351: norm -> x[:, 0] -> head):
+// keys and values are still needed for all tokens, but the attention output, proj, fc1 and fc2 only for the B CLS rows.  The
+// qkv GEMM runs as usual; attention computes the leading query tile of each frame; the three GEMMs after it take the CLS rows
+// through strides (A / residual rows T*D apart) with M = B, and the row-indexed side buffers (xb, part, stats) are used
+// compactly, row b = frame b — nothing reads their all-token contents after the qkv GEMM.  Every surviving row goes through
+// the same kernels and epilogues as in run_block_lnfold, so the CLS rows of x are bit-identical to the unpruned block's.
+int run_block_lnfold_cls(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf16* big, hirest_bf16* xb, float* part,
+                         float* stats, float* guard, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream) {
+    const int M = B * T, G = (D + 63) / 64;
+    const int64_t TD = (int64_t)T * D;
+    CHECK(gemm(xb, D, w.qkv_wf, D, w.qkv_bf, big, 3 * D, M, 3 * D, D, HIREST_EPI_LNFOLD_BF16, stream, nullptr, 0, stats,
+               const_cast<float*>(w.qkv_s)));
+    CHECK(hirest_attention_bf16_rows(big, h, B, T, heads, dh, 1.0f / sqrtf((float)dh), 0, 1, stream));
+    CHECK(gemm(h, TD, w.proj_w, D, w.proj_b, x, TD, B, D, D, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
+    CHECK(hirest_ln_stats_finalize(part, G, stats, eps, B, D, guard, stream));
+    CHECK(gemm(xb, D, w.fc1_wf, D, w.fc1_bf, big, Dm, B, Dm, D, HIREST_EPI_LNFOLD_GELU_BF16, stream, nullptr, 0, stats,
+               const_cast<float*>(w.fc1_s)));
+    CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, x, TD, B, D, Dm, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int hirest_abi_version(void) { return HIREST_ABI_VERSION; }
@@ -152,9 +173,15 @@ extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* f
         float* guard = reinterpret_cast<float*>(ws + r.guard);
         if (hipMemsetAsync(guard, 0, 256, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return hirest_launch_status();
         CHECK(hirest_rowstats_bf16(x, D, xb, stats, t->ln_eps, B * T, D, guard, stream));
-        for (int l = 0; l < t->layers; ++l)
-            CHECK(run_block_lnfold(t->blocks[l], x, h, big, xb, part, stats, guard, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps,
-                                   stream));
+        const bool prune = !t->out_all_tokens && !(flags & HIREST_TOWER_NO_PRUNE);
+        for (int l = 0; l < t->layers; ++l) {
+            if (prune && l == t->layers - 1)
+                CHECK(run_block_lnfold_cls(t->blocks[l], x, h, big, xb, part, stats, guard, B, T, D, t->heads, t->head_dim, t->mlp_dim,
+                                           t->ln_eps, stream));
+            else
+                CHECK(run_block_lnfold(t->blocks[l], x, h, big, xb, part, stats, guard, B, T, D, t->heads, t->head_dim, t->mlp_dim,
+                                       t->ln_eps, stream));
+        }
     } else {
         for (int l = 0; l < t->layers; ++l)
             CHECK(run_block(t->blocks[l], x, h, big, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps, t->act, 0, stream));

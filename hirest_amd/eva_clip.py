@@ -146,6 +146,7 @@ class VisionTower(_Tower):
         self.fold_guard_ratio = 4.0      # a call whose worst token row sits > 4 sigma off zero is redone with LayerNorm passes
         self.last_fold_ratio = 0.0       # (None: never check).  Largest |mean| / sigma seen by the last forward()
         self.fold_fallbacks = 0          # calls redone so far
+        self.prune_last_block = True     # the last block computes only what x[:, 0] needs (bit-identical CLS rows; False: A/B)
 
     def _prepare(self, device):
         if self._prepared is not None and self._prepared["device"] == device:
@@ -226,7 +227,8 @@ class VisionTower(_Tower):
         for s in range(0, B, step):
             n = min(step, B - s)
             args = (C.byref(prep["desc"]), image[s:s + n].data_ptr(), code, n, out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel())
-            _lib.check(lib.hirest_vision_forward(*args, 0, ops.stream_ptr()), "hirest_vision_forward")
+            flags = 0 if self.prune_last_block else _lib.TOWER_NO_PRUNE
+            _lib.check(lib.hirest_vision_forward(*args, flags, ops.stream_ptr()), "hirest_vision_forward")
             # Guard of the folded LayerNorm (include/hirest_hip.h): the call reports the largest |mean| / sigma any token row
             # had in any layer.  Row offsets of more than `fold_guard_ratio` sigma would lose precision in the un-normalised
             # bf16 operand, so such a call is repeated with the LayerNorm passes (one 4-byte read-back per call).
@@ -236,7 +238,7 @@ class VisionTower(_Tower):
                 self.last_fold_ratio = max(self.last_fold_ratio, ratio)
                 if not ratio <= self.fold_guard_ratio:                      # non-finite rows report +inf (elementwise.hip)
                     self.fold_fallbacks += 1
-                    _lib.check(lib.hirest_vision_forward(*args, _lib.TOWER_NO_LNFOLD, ops.stream_ptr()), "hirest_vision_forward")
+                    _lib.check(lib.hirest_vision_forward(*args, flags | _lib.TOWER_NO_LNFOLD, ops.stream_ptr()), "hirest_vision_forward")
         return out
 
 

@@ -135,6 +135,13 @@ int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_index,
 int hirest_attention_bf16(const hirest_bf16* qkv, hirest_bf16* out,
                           int32_t B, int32_t N, int32_t H, int32_t dh,
                           float scale, int32_t causal, void* stream);
+/* The same, but only the output rows of queries [0, q_rows) of every sequence are guaranteed to be written (the
+ * persistent kernel computes the leading ceil(q_rows / 16) query tiles and still streams all keys / values; the other
+ * kernels compute everything).  Rows that are written are bit-identical to hirest_attention_bf16's.  The last
+ * block of the vision tower uses q_rows = 1: vit_model.py:340-351 reads only x[:, 0] after it. */
+int hirest_attention_bf16_rows(const hirest_bf16* qkv, hirest_bf16* out,
+                               int32_t B, int32_t N, int32_t H, int32_t dh,
+                               float scale, int32_t causal, int32_t q_rows, void* stream);
 /* 1 = register-staged kernel with a transposed V image, 2 = LDS-DMA staging + hardware transpose reads, one workgroup
  * per (frame, head), 3 (default) = 2's arithmetic in one persistent workgroup per frame (used for 80 < N <= 272 tokens
  * and >= 64 frames; other shapes fall back to 2).  For tests / A-B timing. */
@@ -248,7 +255,9 @@ size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B);
  * A folded call leaves, at byte offset hirest_vision_guard_offset(t, B) of the workspace, one float = the largest
  * |mean| / sigma any token row of any layer had (see hirest_rowstats_bf16); the offset is (size_t)-1 for calls that do
  * not fold.  The host layer re-runs a call with HIREST_TOWER_NO_LNFOLD when that value exceeds its threshold. */
-enum { HIREST_TOWER_NO_LNFOLD = 1 };
+enum { HIREST_TOWER_NO_LNFOLD = 1,
+       /* run the last block on every token (A/B timing and the bit-identity test of the pruned form) */
+       HIREST_TOWER_NO_PRUNE = 2 };
 int hirest_vision_forward(const hirest_vision_tower* t, const void* frames, int32_t in_dtype,
                           int32_t B, float* out, void* workspace, size_t workspace_bytes,
                           int32_t flags, void* stream);

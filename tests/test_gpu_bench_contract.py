@@ -36,11 +36,29 @@ def test_bench_line_contract():
     assert cb["min_cosine_gpu_vs_cpu_on_sample"] > 0.999
     assert cb["single_thread"] > 0 and str(cb["cores"]) in cb["by_threads"] and cb["host_cpus"] >= cb["cores"]
     assert set(cb["by_threads"]) >= {"1", str(min(32, cb["host_cpus"]))} and all(v["frames_per_s"] > 0 for v in cb["by_threads"].values())
+    assert all(v["how"].startswith(("measured", "extrapolated from a 2-block probe of one frame")) for v in cb["by_threads"].values())
     # matched R@k at EVA-CLIP-g/14 scale against the real reference's rankings (tests/golden/eva_g14_c3.npz)
     mr = d["matched_recall"]
     assert mr["queries"] == 546 and mr["videos"] == 64
     assert mr["matched_R@5"] == 100.0 and mr["matched_R@10"] == 100.0 and mr["matched_R@1"] >= 85.0
     assert mr["top1_exact_where_margin_gt_2x_error"] is True and mr["pooled_min_cosine_vs_reference"] > 0.999
+    # executed vs unpruned work (the last block serves x[:, 0] only): the tower fraction is priced on executed FLOPs
+    assert rf["executed_gflop_per_frame"] < rf["unpruned_gflop_per_frame"] == 534.06
+    assert abs(rf["whole_tower_frac"] - d["value"] * rf["executed_gflop_per_frame"] / 1e3 / 2500.0) < 1e-9
+    # the other SURVEY-8 rows at the reference's operating point: value + roofline + CPU oracle each
+    sec = d["secondary"]
+    units = {"moment_retrieval": "videos/s", "moment_segmentation": "videos/s", "step_captioning_beam3": "captions/s",
+             "step_captioning_beam5": "captions/s", "train_step": "ms/step", "asr_sentence_encoder": "sentences/s"}
+    for key, unit in units.items():
+        e = sec[key]
+        assert e["unit"] == unit and e["value"] > 0, key
+        r_ = e["roofline"]
+        assert r_["bound"] in ("mfma", "hbm") and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-12 and 0 < r_["frac"] < 1, key
+        if key != "step_captioning_beam3":
+            assert e["cpu_baseline"]["kind"] == "port" and e["cpu_baseline"]["value"] > 0 and e["cpu_baseline"]["cores"] >= 1, key
+    assert sec["moment_retrieval"]["indices_equal_cpu_oracle"] and sec["moment_segmentation"]["boundaries_equal_cpu_oracle"]
+    assert sec["step_captioning_beam5"]["token_ids_equal_cpu_oracle_on_sample"]
+    assert sec["moment_retrieval"]["value"] > 38 and sec["moment_segmentation"]["value"] > 8 and sec["step_captioning_beam3"]["value"] > 48
 
 
 def test_bench_gpus_flag_is_binding():

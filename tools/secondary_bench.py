@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Driver-verifiable numbers for the rows of SURVEY 8 that are not the headline (BASELINE configs[3], configs[4], row f4):
+the joint model's moment retrieval / moment segmentation / step captioning, its training step and the ASR sentence encoder,
+each at the reference's own operating point (B = 5 = scripts/run.sh:14, T = 300 frames; beam 3 and 5, 48 words), each with
+its roofline fraction and with the CPU oracle timed beside it on this host.
+
+``bench.py`` calls ``measure()`` outside its timed region (rank 0, N = 1) and prints the result as the ``secondary`` object
+of its JSON line; ``python tools/secondary_bench.py`` prints the same object on its own (profiles/rNN/secondary.json).
+
+The reference's published speeds for these paths are val_inference_and_evaluation.ipynb:708,713,716 (T4): 38 videos/s
+moment retrieval, 8 videos/s moment segmentation, 48 captions/s.
+
+Roofline conventions: the joint model runs exact fp32 on v_mfma_f32_32x32x2_f32, dense peak 157.3 TFLOP/s
+(MI355X_MICROARCH.md); algorithmic FLOPs are counted from the layer shapes below, masked / padded positions included (the
+kernels compute them).  Step captioning is bound by streaming the decoder's weights once per word for the whole batch of beams
+(LM head 30522 x 768 fp32 = 94 MB + 2 decoder layers): bytes per word / 8 TB/s.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+E, H, FF, VOCAB = 512, 768, 3072, 30522
+
+
+def encoder_flops_per_token(T):
+    """VisualModel (module_visual.py:396-424): embedding Linear(512, 768) + 2 x (QKV, out, FFN, attention over T keys)."""
+    return 2 * E * H + 2 * (2 * (4 * H * H + 2 * H * FF) + 4 * T * H)
+
+
+def fusion_flops_per_token():
+    """modeling.py:158-195: clip_g_map 1024->512, asr 384->512, temporal 512->512 (per token); the text map is per video."""
+    return 2 * (1024 * E + 384 * E + E * E)
+
+
+def _timeit(fn, reps, sync):
+    fn(); sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def measure(dev=None, cpu=True, log=lambda m: None):
+    import hirest_amd
+    from hirest_amd import synth
+    from hirest_amd.sentence_encoder import SentenceTransformer
+    from hirest_amd.synth import joint_inputs, train_targets, caption_targets
+    dev = dev or torch.device("cuda:0")
+    sync = torch.cuda.synchronize
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", "joint_schema.json"))).items()}
+    sd = synth.joint_state_dict(shapes, 31)
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).eval()
+    B, T = 5, 300
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"jb.{T}", B, T, 43)
+    g = lambda t: t.to(dev)
+    common = {"vis_feats": g(vis), "vis_mask": g(vis_mask), "asr_feats": g(asr), "text_feat": g(text)}
+    out = {"operating_point": f"B={B} videos, T={T} frames, fp32 (joint model), synthetic weights / features; CPU = oracle/ref_cpu.py, "
+                              f"{threads} torch threads", "reference_T4": {"moment_retrieval_videos_per_s": 38,
+                                                                           "moment_segmentation_videos_per_s": 8, "captions_per_s_beam3": 48,
+                                                                           "where": "val_inference_and_evaluation.ipynb:708,713,716"}}
+    if cpu:
+        from oracle import ref_cpu as O
+
+    # ---- moment retrieval (BASELINE configs[3]; modeling.py:272-308)
+    log("secondary: moment retrieval")
+    bmr = dict(common, tasks=["moment_retrieval"], moment_mask=g(moment_mask))
+    dt, pred = _timeit(lambda: model.test_step(bmr)["prediction"], 20, sync)
+    flops = B * T * (fusion_flops_per_token() + encoder_flops_per_token(T) + 2 * 2 * H)
+    ent = {"value": B / dt, "unit": "videos/s", "ms_per_batch": dt * 1e3,
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_batch": flops}}
+    if cpu:
+        t0 = time.perf_counter(); p_cpu, _, _ = O.moment_retrieval(sd, vis, text, asr, vis_mask, moment_mask); tc = time.perf_counter() - t0
+        ent["cpu_baseline"] = {"value": B / tc, "unit": "videos/s", "cores": threads, "kind": "port", "sample": "one batch"}
+        ent["indices_equal_cpu_oracle"] = bool(p_cpu == pred)
+    out["moment_retrieval"] = ent
+
+    # ---- moment segmentation, 20 iterations (modeling.py:353-474)
+    log("secondary: moment segmentation")
+    bsg = dict(common, tasks=["moment_segmentation"], moment_bound_frames=bounds)
+    dt, pred = _timeit(lambda: model.test_step(bsg)["prediction"], 5, sync)
+    flops = B * T * (fusion_flops_per_token() + 20 * (encoder_flops_per_token(T) + 2 * H))
+    ent = {"value": B / dt, "unit": "videos/s", "ms_per_batch": dt * 1e3, "iterations": 20,
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_batch": flops}}
+    if cpu:
+        t0 = time.perf_counter(); s_cpu, _ = O.moment_segmentation(sd, vis, text, asr, vis_mask, bounds); tc = time.perf_counter() - t0
+        ent["cpu_baseline"] = {"value": B / tc, "unit": "videos/s", "cores": threads, "kind": "port", "sample": "one batch"}
+        ent["boundaries_equal_cpu_oracle"] = bool(s_cpu == pred)
+    out["moment_segmentation"] = ent
+
+    # ---- step captioning (BASELINE configs[4]; modeling.py:556-632): 15-frame moments -> 20 trimmed frames, 48 words
+    mm15 = torch.zeros_like(moment_mask); mm15[:, 10:25] = 1
+    bcp = dict(common, tasks=["step_captioning"], moment_mask=mm15)
+    layer_w = (3 * H * H + H * H) + (H * H + H * H) + 2 * H * FF       # self qkv + out, cross q + out, FFN (cross K/V are per batch)
+    bytes_per_word = 4 * (2 * layer_w + H * H + VOCAB * H)              # fp32 weights streamed once per word for all beams
+    for beams in (3, 5):
+        log(f"secondary: step captioning, beam {beams}")
+        res = {}
+        dt, r = _timeit(lambda: model.test_step(bcp, num_beams=beams, return_ids=True), 3, sync)
+        words = max(len(h) for h in r["token_ids"])
+        gbs = bytes_per_word * 48 / dt / 1e9
+        ent = {"value": B / dt, "unit": "captions/s", "ms_per_batch": dt * 1e3, "beam": beams, "max_words": 48,
+               "longest_hypothesis_words": words,
+               "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_word_step": bytes_per_word,
+                            "note": "decoder + LM-head fp32 weights once per word for the whole batch of beams, 48 word steps"}}
+        if cpu and beams == 5:
+            t0 = time.perf_counter()
+            c_cpu, _ = O.step_captioning(sd, vis[:1], text[:1], asr[:1], mm15[:1], beams=beams)
+            tc = time.perf_counter() - t0
+            ent["cpu_baseline"] = {"value": 1 / tc, "unit": "captions/s", "cores": threads, "kind": "port", "sample": "one caption (video 0)"}
+            ent["token_ids_equal_cpu_oracle_on_sample"] = bool(list(c_cpu[0]) == list(r["token_ids"][0]))
+        out[f"step_captioning_beam{beams}"] = ent
+
+    # ---- joint-model training step (row f4; run.py:238-295): train_step + backward + clip_grad_norm_ + AdamW
+    log("secondary: training step")
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    st, et, seg, prev = train_targets(f"tb.{T}", B, T, 61, bounds)
+    btr = {"vis_feats": vis, "vis_mask": vis_mask, "asr_feats": asr, "text_feat": text, "tasks": ["moment_retrieval"],
+           "moment_mask": moment_mask, "moment_retrieval_start_target": st, "moment_retrieval_end_target": et}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.train_step(btr)["loss"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return loss
+    dt, _ = _timeit(step, 10, sync)
+    flops = 3 * B * T * (fusion_flops_per_token() + encoder_flops_per_token(T))      # forward + dX + dW
+    ent = {"value": dt * 1e3, "unit": "ms/step", "higher_is_better": False, "videos_per_s": B / dt, "task": "moment_retrieval",
+           "includes": "train_step + backward + clip_grad_norm_ + AdamW over the 63 M trainable parameters",
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_step": flops}}
+    if cpu:
+        psd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+        t0 = time.perf_counter()
+        O.moment_retrieval_loss(psd, vis, text, asr, vis_mask, moment_mask, st, et).backward()
+        tc = time.perf_counter() - t0
+        ent["cpu_baseline"] = {"value": tc * 1e3, "unit": "ms/step", "cores": threads, "kind": "port",
+                               "sample": "oracle loss under torch autograd, forward + backward only (no optimizer)"}
+    out["train_step"] = ent
+    model.eval()
+    del opt
+
+    # ---- ASR sentence encoder (row f4 tail; extract_ASR_embedding.py:14,25,54), MiniLM-L6 schema
+    log("secondary: ASR sentence encoder")
+    cfg = synth.MINILM_L6
+    bsd = synth.bert_state_dict(cfg, 52)
+    rows = synth.sentence_ids("asr_bench", 2048, 7, cfg["vocab_size"], 4, 40)
+    enc = SentenceTransformer(config=cfg, state_dict=bsd).eval().to(dev)
+    dt, emb = _timeit(lambda: enc.encode_ids(rows), 3, sync)
+    toks = sum(map(len, rows))
+    D, I, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    flops = L * (toks * 2 * (4 * D * D + 2 * D * I) + sum(4 * len(r) * len(r) * D for r in rows))
+    ent = {"value": len(rows) / dt, "unit": "sentences/s", "tokens_per_s": toks / dt, "sentences": len(rows), "tokens": toks,
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_call": flops}}
+    if cpu:
+        n = 64
+        t0 = time.perf_counter(); ref = O.sentence_embeddings(bsd, rows[:n], cfg["num_attention_heads"]); tc = time.perf_counter() - t0
+        ent["cpu_baseline"] = {"value": n / tc, "unit": "sentences/s", "cores": threads, "kind": "port", "sample": f"first {n} sentences"}
+        ent["max_abs_diff_vs_cpu_oracle_on_sample"] = (emb[:n].cpu() - ref).abs().max().item()
+    out["asr_sentence_encoder"] = ent
+    return out
+
+
+if __name__ == "__main__":
+    res = measure(cpu="--no-cpu" not in sys.argv, log=lambda m: print(m, file=sys.stderr, flush=True))
+    print(json.dumps(res, indent=1))
