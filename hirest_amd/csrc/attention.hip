@@ -338,6 +338,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 // =================================================================================================
 // NW waves per workgroup: 9 (17 query tiles = 2,2,...,2,1) or 12 (three waves on every SIMD instead of 3/2/2/2: the busiest SIMD
 // still owns 5 tiles, but every SIMD has a third instruction stream to cover softmax VALU and LDS latency with).
+template <int NW, int CPR> struct ROWS_PER_PIECE_OK { static constexpr bool value = (NW * 64 % CPR == 0) && ((NW * 64 / CPR) % 8 == 0); };
 template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
 __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           int N, int H, float scale_log2e, int causal, int dbg_bits, int nq) {
@@ -359,7 +360,14 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
     // further each time, same column -> one (row0, column) pair per lane.
     const int ci0 = wave * 64 + lane;
     const int row0 = ci0 / C::CPR, col0 = ci0 - row0 * C::CPR;
-    const int vc = col0 * 8 < DH ? col0 : DH / 8 - 1;
+    // V image: the 32-B block (16 head dims) at position p of row r holds logical block p ^ ((r >> 2) & 1).  The transpose
+    // reads below fetch, per 32-lane half, rows 4g .. 4g + 3 for two values of g at one block position: at the 192-B row
+    // stride rows r and r + 4 start 768 B = 3 bank rows apart, i.e. on the SAME 8 banks (2-way conflict on every P.V
+    // fragment: 33 % of the kernel's LDS cycles in profiles/r02/pmc_summary.md); the swap puts them 32 B apart.
+    constexpr bool VSWAP = C::RS == 192;   // (head dim 64: 128-B rows, a different conflict pattern — image left as it is)
+    const int vlog = VSWAP ? ((((col0 >> 1) ^ ((row0 >> 2) & 1)) << 1) | (col0 & 1)) : col0;
+    const int vc = vlog * 8 < DH ? vlog : DH / 8 - 1;
+    static_assert(ROWS_PER_PIECE_OK<NW, C::CPR>::value, "a lane's rows must keep (row >> 2) & 1 from piece to piece");
     static_assert((NW * 64) % C::CPR == 0, "piece stride must be whole rows");
     constexpr int ROWS_PER_PIECE = NW * 64 / C::CPR;
     auto dma_k = [&](int h, char* dst) -> int {
@@ -475,6 +483,9 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
                 v_ready = true;
             }
             const char* vlane = Vs + (4 * g + (c16 >> 2)) * C::RS + (c16 & 3) * 8;
+            // block swap of the V image (see dma_v): even d tiles at +32 (g & 1), odd ones at +32 (1 - (g & 1)) - 32
+            const char* vl_e = vlane + ((VSWAP && (g & 1)) ? 32 : 0);
+            const char* vl_o = vlane - ((VSWAP && (g & 1)) ? 32 : 0);
             f32x4 oacc[DP / 16];
 #pragma unroll
             for (int dt = 0; dt < DP / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
             for (int s2 = 0; s2 < C::KS; ++s2) {
 #pragma unroll
                 for (int dt = 0; dt < DP / 16; ++dt) {   // DP/16 independent accumulators per key step
-                    const char* vrow = vlane + dt * 32 + s2 * 32 * C::RS;
+                    const char* vrow = ((dt & 1) ? vl_o : vl_e) + dt * 32 + s2 * 32 * C::RS;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vrow));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vrow + 16 * C::RS));
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};

@@ -153,7 +153,9 @@ __device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane
     return f32x4{v0[0], v0[1], v1[0], v1[1]};
 }
 
-template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1>   // PRE: the caller has already brought the row statistics into LDS
+// SREG (gemm_d2, whose two workgroups per CU leave no LDS for them): the (mean, rstd) pairs of the lane's NM rows go
+// straight from global memory (L2-resident, written by hirest_ln_stats_finalize) into registers at the start of the epilogue.
+template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1, bool SREG = false>   // PRE: the caller has already brought the row statistics into LDS
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
     if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
 #pragma unroll
@@ -167,7 +169,15 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
     const int rr = lane >> 3, rc = lane & 7;                     // read-back: row (it*8 + rr), 16-B chunk rc
     if constexpr (OUT_BF16) {
         bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-        if constexpr (FOLD) {   // (mean, rstd) of this wave's 128 rows -> LDS behind the staging area (one 16-B load per lane)
+        f32x2 mrs[SREG ? NM : 1];
+        if constexpr (FOLD && SREG) {
+            const float* st = reinterpret_cast<const float*>(p.aux0);
+#pragma unroll
+            for (int mi = 0; mi < NM; ++mi) {
+                const int r = Mw + mi * 16 + srow;
+                mrs[mi] = *reinterpret_cast<const f32x2*>(st + 2 * (int64_t)(r < p.M ? r : p.M - 1));
+            }
+        } else if constexpr (FOLD) {   // (mean, rstd) of this wave's 128 rows -> LDS behind the staging area (one 16-B load per lane)
             if constexpr (!PRE) *reinterpret_cast<f32x4*>(stg + P_STG + 16 * lane) = load_row_stats(p, Mw, lane);
             HX_LDS_ORDER();
         }
@@ -182,11 +192,12 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                     sv[n] = col < p.N ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux1) + col) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             f32x2 mr_next = {0.f, 1.f};
-            if constexpr (FOLD) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + srow * 8);
+            if constexpr (FOLD && !SREG) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + srow * 8);
 #pragma unroll
             for (int mi = 0; mi < NM; ++mi) {
-                const f32x2 mr = mr_next;                              // (mean, rstd) of row mi*16 + srow, read one pass ahead
-                if constexpr (FOLD) { if (mi + 1 < NM) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + ((mi + 1) * 16 + srow) * 8); }
+                f32x2 mr = mr_next;                                    // (mean, rstd) of row mi*16 + srow, read one pass ahead
+                if constexpr (FOLD && SREG) mr = mrs[mi];
+                if constexpr (FOLD && !SREG) { if (mi + 1 < NM) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + ((mi + 1) * 16 + srow) * 8); }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     f32x4 v;

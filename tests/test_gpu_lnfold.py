@@ -16,7 +16,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[0, 9, 17], ids=["auto", "w4", "w4h"])
+@pytest.fixture(params=[0, 9, 17, 18], ids=["auto", "w4", "w4h", "d2"])
 def fused_kernel(request):
     """The LN-fold epilogues exist in the persistent kernels: the default dispatch and the 4-wave kernel (gemm_w4.hip)."""
     from hirest_amd import ops
