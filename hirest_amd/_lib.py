@@ -61,6 +61,19 @@ class TextTower(C.Structure):
                 ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p), ("proj_w", C.c_void_p)]
 
 
+class BlockWeightsF32(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                                          "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VisionTowerF32(C.Structure):     # hirest_vision_tower_f32: the same fields with fp32 weight pointers
+    _fields_ = [(n, t) if n != "blocks" else (n, C.POINTER(BlockWeightsF32)) for n, t in VisionTower._fields_]
+
+
+class TextTowerF32(C.Structure):
+    _fields_ = [(n, t) if n != "blocks" else (n, C.POINTER(BlockWeightsF32)) for n, t in TextTower._fields_]
+
+
 class CaptionLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_b", "so_w", "so_b", "so_ln_g", "so_ln_b", "cq_w", "cq_b",
                                           "co_w", "co_b", "co_ln_g", "co_ln_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ff_ln_g", "ff_ln_b")]
@@ -181,6 +194,12 @@ _SIGNATURES = {
     "hirest_vision_forward": (C.c_int, [C.POINTER(VisionTower), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "hirest_vision_guard_offset": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),
+    "hirest_vision_workspace_bytes_f32": (C.c_size_t, [C.POINTER(VisionTowerF32), C.c_int32]),
+    "hirest_vision_forward_f32": (C.c_int, [C.POINTER(VisionTowerF32), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hirest_text_workspace_bytes_f32": (C.c_size_t, [C.POINTER(TextTowerF32), C.c_int32]),
+    "hirest_text_forward_f32": (C.c_int, [C.POINTER(TextTowerF32), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
     "hirest_text_workspace_bytes": (C.c_size_t, [C.POINTER(TextTower), C.c_int32]),
     "hirest_text_forward": (C.c_int, [C.POINTER(TextTower), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),

@@ -22,7 +22,7 @@ struct GemmF {
     const float* resid; int64_t ldr;
     const float* periodic; int period;
     float* out; int64_t ldo;
-    int M, N, K, act;   // act: 0 none, 1 gelu (erf), 2 tanh
+    int M, N, K, act;   // act: 0 none, 1 gelu (erf), 2 tanh, 3 quick-gelu
 };
 
 constexpr int FK = 32, FLD = FK + 1;      // K is staged 32 deep; K itself only has to be a multiple of 16 (zero fill)
@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
         } else if (p.act == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        } else if (p.act == 3) {                      // QuickGELU (model.py:175-177), the fp32 reference-precision towers
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-1.702f * v[e])));
         }
         if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
         if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
@@ -179,6 +182,9 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF p) {
         } else if (p.act == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        } else if (p.act == 3) {                      // QuickGELU (model.py:175-177), the fp32 reference-precision towers
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-1.702f * v[e])));
         }
         if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
         if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
@@ -195,12 +201,14 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF p) {
 //   O^T = V^T.P^T  P is reused in place as the B operand: k-step r pairs key kap(r,0) (lanes < 32) with
 //                  kap(r,1) = kap(r,0)+4 (lanes >= 32), which is exactly what each half-wave holds in reg r.
 // ---------------------------------------------------------------------------------------------
-constexpr int ADH = 64, ALD = ADH + 1;
-
+// DHP = head dim padded to a multiple of 32 (64, or 96 for EVA-CLIP's 88-wide heads: the fp32 reference-precision tower);
+// dh = the real head dim (the packed layouts are addressed with it; padded dims are zeros and their outputs are not stored).
+template <int DHP>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
                                                            const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
-                                                           int Tq, int T, int H, float scale, float add_const, float causal_penalty,
-                                                           const int32_t* __restrict__ seq_off) {
+                                                           int Tq, int T, int H, int dh, float scale, float add_const,
+                                                           float causal_penalty, const int32_t* __restrict__ seq_off) {
+    constexpr int ALD = DHP + 1, NO = DHP / 32;
     __shared__ float Ks[32 * ALD];
     __shared__ float Vs[32 * ALD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,33 +216,36 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const int qblocks = (Tq + 127) / 128;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
     const int b = bh / H, h = bh - b * H;
-    const int D = H * ADH;
+    const int D = H * dh;
     int64_t qrow0 = (int64_t)b * Tq, krow0 = (int64_t)b * T;
     if (seq_off) {   // packed ragged self-attention: sequence b = rows seq_off[b] .. seq_off[b+1]; Tq was only the longest one
         qrow0 = krow0 = seq_off[b];
         Tq = T = seq_off[b + 1] - seq_off[b];
         if (qb * 128 >= Tq) return;                       // (block-uniform)
     }
-    const float* qbase = qp + qrow0 * ldq + h * ADH;
-    const float* kbase = kp + krow0 * ldkv + h * ADH;
-    const float* vbase = vp + krow0 * ldkv + h * ADH;
+    const float* qbase = qp + qrow0 * ldq + h * dh;
+    const float* kbase = kp + krow0 * ldkv + h * dh;
+    const float* vbase = vp + krow0 * ldkv + h * dh;
     const int q = qb * 128 + wave * 32 + l31;
     const bool qvalid = q < Tq;
-    // Q^T fragments: B operand [k = d][j = query]: lane holds Q[q][2s + half] for s = 0..31
-    float qf[32];
+    // Q^T fragments: B operand [k = d][j = query]: lane holds Q[q][2s + half] for s = 0..DHP/2-1
+    float qf[DHP / 2];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) qf[s] = qvalid ? qbase[(int64_t)q * ldq + 2 * s + half] : 0.f;
-    f32x16 o0, o1;   // O^T rows d = 0..31 and 32..63, column = query
+    for (int s = 0; s < DHP / 2; ++s) qf[s] = (qvalid && 2 * s + half < dh) ? qbase[(int64_t)q * ldq + 2 * s + half] : 0.f;
+    f32x16 o[NO];    // O^T rows d = 32 j .. 32 j + 31, column = query
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    for (int j = 0; j < NO; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
     float mrun = -3.0e38f, lrun = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < T; k0 += 32) {
         __syncthreads();
-        for (int i = tid; i < 32 * 16; i += 256) {   // 32 keys x 16 float4
-            const int kr = i >> 4, c = (i & 15) * 4;
+        for (int i = tid; i < 32 * (DHP / 4); i += 256) {   // 32 keys x DHP/4 float4
+            const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
             const int key = k0 + kr < T ? k0 + kr : T - 1;
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + c);
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + c);
+            const f32x4 kv = c < dh ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + c) : zero4;
+            const f32x4 vv = c < dh ? *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + c) : zero4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Ks[kr * ALD + c + e] = kv[e]; Vs[kr * ALD + c + e] = vv[e]; }
         }
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s)   // A operand: K[key = l31][d = 2s + half]
+        for (int s = 0; s < DHP / 2; ++s)   // A operand: K[key = l31][d = 2s + half]
             st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * ALD + 2 * s + half], qf[s], st, 0, 0, 0);
         float tmax = -3.0e38f;
 #pragma unroll
@@ -265,23 +276,37 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         lrun = lrun * alpha + psum;
         mrun = mnew;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        for (int j = 0; j < NO; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {   // k-step r: keys kap(r,0) | kap(r,1); A operand V^T[d = l31 (+32)][key]
+            for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {   // k-step r: keys kap(r,0) | kap(r,1); A operand V^T[d = l31 (+32 j)][key]
             const int kr = (r & 3) + 8 * (r >> 2) + 4 * half;
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kr * ALD + l31], st[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kr * ALD + 32 + l31], st[r], o1, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NO; ++j)
+                o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kr * ALD + 32 * j + l31], st[r], o[j], 0, 0, 0);
         }
     }
     if (!qvalid) return;
     const float inv = 1.0f / lrun;
-    float* orow = out + (qrow0 + q) * D + h * ADH;
+    float* orow = out + (qrow0 + q) * D + h * dh;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {   // O^T rows (reg&3) + 8*(reg>>2) + 4*half = d
-        const int d = 8 * g + 4 * half;
-        *reinterpret_cast<f32x4*>(orow + d) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(orow + 32 + d) = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
-    }
+    for (int j = 0; j < NO; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // O^T rows (reg&3) + 8*(reg>>2) + 4*half = d
+            const int d = 32 * j + 8 * g + 4 * half;
+            if (d < dh)
+                *reinterpret_cast<f32x4*>(orow + d) = f32x4{o[j][4 * g] * inv, o[j][4 * g + 1] * inv, o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv};
+        }
+}
+
+// dh 64 -> the 64-wide instantiation (the joint model, the sentence encoder's padded heads), 64 < dh <= 96 -> the 96-wide one
+template <class... Args>
+int launch_attention_f32(int dh, dim3 grid, hipStream_t s, Args... args) {
+    if (dh == 64) hipLaunchKernelGGL(attention_f32_kernel<64>, grid, dim3(256), 0, s, args...);
+    else if (dh > 64 && dh <= 96 && dh % 4 == 0) hipLaunchKernelGGL(attention_f32_kernel<96>, grid, dim3(256), 0, s, args...);
+    else return HIREST_E_SHAPE;
+    return hirest_launch_status();
 }
 
 // base[b,t,:] = v[b,t,:] * tn[b,:] + asr[b,t,:] + temporal[b,t,:]     (loop-invariant part of modeling.py:167-195)
@@ -500,7 +525,7 @@ extern "C" int hirest_gemm_f32_select_kernel(int32_t which) {   // 0 automatic (
 extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                                const float* resid, int64_t ldr, const float* periodic, int32_t period,
                                float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
-    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return HIREST_E_BADARG;
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
     if (M <= 256 && g_f32_skinny) {
@@ -514,34 +539,29 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
 extern "C" int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,
                                     float scale, float add_const, void* stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
-    if (dh != ADH) return HIREST_E_SHAPE;
-    const int64_t ld = 3 * (int64_t)H * ADH;
+    const int64_t ld = 3 * (int64_t)H * dh;
     const int qblocks = (T + 127) / 128;
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, ld,
-                       qkv + H * ADH, qkv + 2 * H * ADH, ld, out, T, T, H, scale, add_const, 0.f, nullptr);
-    return hirest_launch_status();
+    return launch_attention_f32(dh, dim3(B * H * qblocks), reinterpret_cast<hipStream_t>(stream), qkv, ld, qkv + H * dh, qkv + 2 * H * dh, ld,
+                                out, (int)T, (int)T, (int)H, (int)dh, scale, add_const, 0.f, (const int32_t*)nullptr);
 }
 
 extern "C" int hirest_attention_f32_varlen(const float* qkv, float* out, const int32_t* seq_off, int32_t B, int32_t max_len, int32_t H,
                                            int32_t dh, float scale, float add_const, void* stream) {
     if (!qkv || !out || !seq_off || B <= 0 || max_len <= 0 || H <= 0) return HIREST_E_BADARG;
-    if (dh != ADH) return HIREST_E_SHAPE;
-    const int64_t ld = 3 * (int64_t)H * ADH;
+    const int64_t ld = 3 * (int64_t)H * dh;
     const int qblocks = (max_len + 127) / 128;
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, ld,
-                       qkv + H * ADH, qkv + 2 * H * ADH, ld, out, max_len, max_len, H, scale, add_const, 0.f, seq_off);
-    return hirest_launch_status();
+    return launch_attention_f32(dh, dim3(B * H * qblocks), reinterpret_cast<hipStream_t>(stream), qkv, ld, qkv + H * dh, qkv + 2 * H * dh, ld,
+                                out, (int)max_len, (int)max_len, (int)H, (int)dh, scale, add_const, 0.f, seq_off);
 }
 
 extern "C" int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out,
                                         int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, float add_const,
                                         float causal_penalty, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
-    if (dh != ADH || ldq % 4 != 0 || ldkv % 4 != 0) return HIREST_E_SHAPE;
+    if (ldq % 4 != 0 || ldkv % 4 != 0) return HIREST_E_SHAPE;
     const int qblocks = (Tq + 127) / 128;
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H * qblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
-                       ldkv, out, Tq, Tk, H, scale, add_const, causal_penalty, nullptr);
-    return hirest_launch_status();
+    return launch_attention_f32(dh, dim3(B * H * qblocks), reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk,
+                                (int)H, (int)dh, scale, add_const, causal_penalty, (const int32_t*)nullptr);
 }
 
 // out[r][v] = x[r][v] - logsumexp(x[r]) + row_add[r]   (log_softmax of train.py:563-564 fused with the beam score add of beam.py:76)

@@ -11,9 +11,11 @@ text.transformer.resblocks.N.attn.in_proj_weight, ...), so ``eva_clip_psz14.pt``
 strict=True and ``state_dict()`` / ``parameters()`` / ``.to()`` / ``.float()`` / ``.eval()``
 behave like the nn.Module callers expect (modeling.py:115-129, run.py:61-65).
 
-Numerics: GEMMs and attention run in bf16 on MFMA with fp32 accumulation; the residual stream,
-LayerNorm statistics and softmax are fp32.  Outputs are returned in fp32 (``precision='fp32'``)
-and agree with the fp32 reference to the tolerance stated in tests/test_gpu_parity.py.
+Numerics: two kernel sets.  ``precision='bf16'`` (what ``EVA_CLIP(**cfg)`` starts in and what bench.py measures): GEMMs and
+attention in bf16 on MFMA with fp32 accumulation; residual stream, LayerNorm statistics and softmax fp32; agrees with the
+fp32 reference to the tolerance stated in tests/test_gpu_parity.py.  ``precision='fp32'`` (the default of
+``create_model`` / ``build_eva_model_and_transforms``, as in the reference): exact-fp32 kernels end to end
+(csrc/tower_f32.hip), embeddings within ~1e-6 of the reference and its retrieval ranks reproduced.
 There is no CPU path: calling an encoder on CPU tensors raises.
 """
 from __future__ import annotations
@@ -85,6 +87,10 @@ class _Tower(nn.Module):
         super().__init__()
         self._prepared = None
         self._workspace = None
+        # 'bf16': GEMMs / attention on the bf16 MFMA kernels (fp32 accumulation, residual stream, statistics): the measured hot
+        # path.  'fp32': every product in exact fp32 (csrc/tower_f32.hip): the reference's own precision (eva_clip.py:90), ~16x
+        # the time; what ``create_model(..., precision='fp32')`` selects.
+        self.precision = "bf16"
 
     def _apply(self, fn, *a, **k):
         self._prepared = None
@@ -142,6 +148,7 @@ class VisionTower(_Tower):
         self.head = _linear(embed_dim, D)
         self.image_mean, self.image_std = OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
         self.max_frames_per_call = 1024  # micro-batch per tower call (workspace ~5.4 GB at 1024 frames)
+        self.max_frames_per_call_f32 = 256   # fp32 towers: 35.8 KB of activations per token -> 2.4 GB at 256 frames
         self.fold_layernorm = True       # tower calls of >= 64 frames fold both LayerNorms of a block into its GEMMs
         self.fold_guard_ratio = 4.0      # a call whose worst token row sits > 4 sigma off zero is redone with LayerNorm passes
         self.last_fold_ratio = 0.0       # (None: never check).  Largest |mean| / sigma seen by the last forward()
@@ -149,7 +156,7 @@ class VisionTower(_Tower):
         self.prune_last_block = True     # the last block computes only what x[:, 0] needs (bit-identical CLS rows; False: A/B)
 
     def _prepare(self, device):
-        if self._prepared is not None and self._prepared["device"] == device:
+        if self._prepared is not None and self._prepared["device"] == device and not self._prepared.get("f32"):
             return self._prepared
         if device.type != "cuda":
             raise RuntimeError("hirest_amd: the vision tower runs on MI355X only (no CPU fallback); move the model to a GPU")
@@ -195,6 +202,56 @@ class VisionTower(_Tower):
         self._prepared = {"device": device, "desc": desc, "blocks": blocks, "keep": keep}
         return self._prepared
 
+    def _prepare_f32(self, device):
+        """fp32 master parameters as they are (contiguous fp32 views, no copies except the zero-padded patch weight)."""
+        if self._prepared is not None and self._prepared["device"] == device and self._prepared.get("f32"):
+            return self._prepared
+        if device.type != "cuda":
+            raise RuntimeError("hirest_amd: the vision tower runs on MI355X only (no CPU fallback); move the model to a GPU")
+        D, P = self.width, self.patch_size
+        K = 3 * P * P
+        kpad = (K + 63) // 64 * 64
+        keep = []
+
+        def hold(t):
+            t = t.detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        pw = torch.zeros((D, kpad), dtype=torch.float32, device=device)
+        pw[:, :K] = self.patch_embed.proj.weight.detach().float().reshape(D, K)
+        blocks = (_lib.BlockWeightsF32 * self.layers)()
+        for i, b in enumerate(self.blocks):
+            qkv_b = torch.cat([b.attn.q_bias.detach().float(), torch.zeros(D, device=device), b.attn.v_bias.detach().float()])
+            blocks[i] = _lib.BlockWeightsF32(
+                hold(b.norm1.weight), hold(b.norm1.bias), hold(b.attn.qkv.weight), hold(qkv_b),
+                hold(b.attn.proj.weight), hold(b.attn.proj.bias), hold(b.norm2.weight), hold(b.norm2.bias),
+                hold(b.mlp.fc1.weight), hold(b.mlp.fc1.bias), hold(b.mlp.fc2.weight), hold(b.mlp.fc2.bias))
+        mean = torch.tensor(self.image_mean, dtype=torch.float32, device=device)
+        std = torch.tensor(self.image_std, dtype=torch.float32, device=device)
+        desc = _lib.VisionTowerF32(
+            self.image_size, P, D, self.heads, D // self.heads, self.mlp_dim, self.layers, self.embed_dim, kpad,
+            1 if self.quick_gelu else 0, 1e-6, hold(pw), hold(self.patch_embed.proj.bias), hold(self.cls_token.reshape(-1)),
+            hold(self.pos_embed.reshape(self.num_tokens, D)), blocks, hold(self.norm.weight), hold(self.norm.bias),
+            hold(self.head.weight), hold(self.head.bias), hold(mean), hold(std), None, None, 0)
+        self._prepared = {"device": device, "desc": desc, "blocks": blocks, "keep": keep, "f32": True}
+        return self._prepared
+
+    def _forward_f32(self, image: torch.Tensor) -> torch.Tensor:
+        prep = self._prepare_f32(image.device)
+        lib = _lib.load()
+        B = image.shape[0]
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=image.device)
+        if B == 0:
+            return out
+        step = min(B, max(1, int(self.max_frames_per_call_f32)))
+        ws = self._ws(lib.hirest_vision_workspace_bytes_f32(C.byref(prep["desc"]), step), image.device)
+        code = ops._IN_DTYPES[image.dtype]
+        for s in range(0, B, step):
+            n = min(step, B - s)
+            _lib.check(lib.hirest_vision_forward_f32(C.byref(prep["desc"]), image[s:s + n].data_ptr(), code, n, out[s:s + n].data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), ops.stream_ptr()), "hirest_vision_forward_f32")
+        return out
+
     @torch.no_grad()
     @ops.on_tensor_device
     def forward(self, image: torch.Tensor) -> torch.Tensor:
@@ -208,9 +265,11 @@ class VisionTower(_Tower):
                 image = image.float()
         assert H == self.image_size and W == self.image_size, \
             f"Input image size ({H}*{W}) doesn't match model ({self.image_size}*{self.image_size})."  # vit_model.py:203
+        image = image.contiguous()
+        if self.precision == "fp32":
+            return self._forward_f32(image)
         prep = self._prepare(image.device)
         lib = _lib.load()
-        image = image.contiguous()
         B = image.shape[0]
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=image.device)
         if B == 0:
@@ -268,8 +327,32 @@ class TextTower(_Tower):
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
         self.max_rows_per_call = 1024
 
+    def _prepare_f32(self, device):
+        if self._prepared is not None and self._prepared["device"] == device and self._prepared.get("f32"):
+            return self._prepared
+        if device.type != "cuda":
+            raise RuntimeError("hirest_amd: the text tower runs on MI355X only (no CPU fallback); move the model to a GPU")
+        keep = []
+
+        def hold(t):
+            t = t.detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        blocks = (_lib.BlockWeightsF32 * self.layers)()
+        for i, b in enumerate(self.transformer.resblocks):
+            blocks[i] = _lib.BlockWeightsF32(
+                hold(b.ln_1.weight), hold(b.ln_1.bias), hold(b.attn.in_proj_weight), hold(b.attn.in_proj_bias),
+                hold(b.attn.out_proj.weight), hold(b.attn.out_proj.bias), hold(b.ln_2.weight), hold(b.ln_2.bias),
+                hold(b.mlp.c_fc.weight), hold(b.mlp.c_fc.bias), hold(b.mlp.c_proj.weight), hold(b.mlp.c_proj.bias))
+        desc = _lib.TextTowerF32(
+            self.context_length, self.vocab_size, self.width, self.heads, self.layers, self.embed_dim,
+            1 if self.quick_gelu else 0, 1e-5, hold(self.token_embedding.weight), hold(self.positional_embedding), blocks,
+            hold(self.ln_final.weight), hold(self.ln_final.bias), hold(self.text_projection.detach().float().t()))
+        self._prepared = {"device": device, "desc": desc, "blocks": blocks, "keep": keep, "f32": True}
+        return self._prepared
+
     def _prepare(self, device):
-        if self._prepared is not None and self._prepared["device"] == device:
+        if self._prepared is not None and self._prepared["device"] == device and not self._prepared.get("f32"):
             return self._prepared
         if device.type != "cuda":
             raise RuntimeError("hirest_amd: the text tower runs on MI355X only (no CPU fallback); move the model to a GPU")
@@ -302,18 +385,20 @@ class TextTower(_Tower):
         """text: [B, context_length] int64 token ids (EOT = row max). Returns [B, embed_dim] fp32."""
         if text.dim() != 2 or text.shape[1] != self.context_length:
             raise RuntimeError(f"encode_text expects [B,{self.context_length}] token ids, got {tuple(text.shape)}")
-        prep = self._prepare(text.device)
+        f32 = self.precision == "fp32"
+        prep = self._prepare_f32(text.device) if f32 else self._prepare(text.device)
         lib = _lib.load()
         text = text.to(torch.int64).contiguous()
         B = text.shape[0]
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=text.device)
         step = max(1, int(self.max_rows_per_call))
-        ws = self._ws(lib.hirest_text_workspace_bytes(C.byref(prep["desc"]), min(B, step)), text.device)
+        ws_bytes, fwd = (lib.hirest_text_workspace_bytes_f32, lib.hirest_text_forward_f32) if f32 else \
+            (lib.hirest_text_workspace_bytes, lib.hirest_text_forward)
+        ws = self._ws(ws_bytes(C.byref(prep["desc"]), min(B, step)), text.device)
         for s in range(0, B, step):
             n = min(step, B - s)
-            _lib.check(lib.hirest_text_forward(C.byref(prep["desc"]), text[s:s + n].data_ptr(), n,
-                                               out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(), ops.stream_ptr()),
-                       "hirest_text_forward")
+            _lib.check(fwd(C.byref(prep["desc"]), text[s:s + n].data_ptr(), n, out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
+                           ops.stream_ptr()), "hirest_text_forward_f32" if f32 else "hirest_text_forward")
         return out
 
 
@@ -330,6 +415,13 @@ class EVA_CLIP(nn.Module):
         self.text = TextTower(t.get("vocab_size", 49408), t.get("width", 512), t.get("layers", 12), t.get("heads", 8),
                               t.get("context_length", 77), embed_dim, quick_gelu)
         self.output_dtype = torch.float32
+
+    def set_precision(self, precision: str):
+        """'fp32' = the reference's own arithmetic (exact-fp32 kernels, eva_clip.py:90 default); 'bf16' = the bf16 MFMA towers."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.visual.precision = self.text.precision = precision
+        return self
 
     @torch.no_grad()
     def init_random_(self, seed: int = 0):
@@ -409,6 +501,15 @@ def create_model(model_name: str, pretrained: str = "", precision: str = "fp32",
         load_checkpoint(model, pretrained)
     device = torch.device(device)
     model.to(device=device)
+    # precision: 'fp32' (the reference's default) runs the exact-fp32 towers, so ranks and indices downstream are the fp32
+    # reference's; 'bf16' / 'amp' / 'amp_bf16' select the bf16 MFMA towers (the measured hot path, ~16x faster; embeddings
+    # within cos 0.9999 of fp32); 'fp16' as the reference: half-precision outputs (computed on the bf16 towers).
+    if precision == "fp32":
+        model.set_precision("fp32")
+    elif precision in ("bf16", "amp", "amp_bf16", "amp_bfloat16", "fp16"):
+        model.set_precision("bf16")
+    else:
+        raise ValueError(f"unknown precision {precision!r} (fp32 | bf16 | amp | fp16)")
     if precision == "fp16":
         assert device.type != "cpu"
         model.output_dtype = torch.float16   # reference returns the model dtype (eva_model.py:337-358)

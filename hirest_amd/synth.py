@@ -493,3 +493,21 @@ def timeline_cases():
     return cases
 
 
+
+
+# ----------------------------------------------------------------------------------
+# BASELINE configs[2] sub-corpus of the matched-R@k check: tests/golden/make_golden.py encodes it with the real
+# reference; bench.py and the GPU tests re-encode it with the kernels.
+# ----------------------------------------------------------------------------------
+
+def c3_corpus(V: int, F: int) -> torch.Tensor:
+    """video v's frames = base_v + 0.1 * noise_{v,f} (non-degenerate, seeded): [V, F, 3, 224, 224] fp32."""
+    base = frames("c3.base", (V, 1, 3, 224, 224), 5)
+    return base + 0.1 * frames("c3.noise", (V, F, 3, 224, 224), 6)
+
+
+def c3_names(V: int) -> list:
+    """File names deliberately NOT in index order under string sort, so the (score, name) tie rule of evaluate.py:58-60 is
+    exercised; unique for V <= 257."""
+    assert V <= 257
+    return [f"vid_{(v * 37) % 257:03d}.mp4" for v in range(V)]

@@ -279,11 +279,59 @@ int hirest_text_forward(const hirest_text_tower* t, const int64_t* tokens, int32
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Reference-precision towers (csrc/tower_f32.hip): the same forwards with every product in exact fp32 (hirest_gemm_f32,
+ * hirest_attention_f32_qkv incl. 88-wide heads, fp32 LayerNorm and activations).  What the host layer runs for
+ * precision='fp32' — the reference's own default (EVA_clip/eva_clip.py:90; modeling.py:120 `.float()`): retrieval ranks then
+ * equal the fp32 reference's wherever fp32 itself decides them.  ~16x the cost of the bf16 towers; fields as in
+ * hirest_block_weights / hirest_vision_tower / hirest_text_tower with fp32 weights [out, in] as nn.Linear stores them.
+ * ------------------------------------------------------------------------------------ */
+typedef struct hirest_block_weights_f32 {
+    const float* ln1_g; const float* ln1_b;
+    const float* qkv_w; const float* qkv_b;
+    const float* proj_w; const float* proj_b;
+    const float* ln2_g; const float* ln2_b;
+    const float* fc1_w; const float* fc1_b;
+    const float* fc2_w; const float* fc2_b;
+} hirest_block_weights_f32;
+
+typedef struct hirest_vision_tower_f32 {
+    int32_t image_size, patch, width, heads, head_dim, mlp_dim, layers, embed_dim;
+    int32_t kpad;                          /* padded 3*P*P (multiple of 16) */
+    int32_t act;                           /* 0 gelu_erf, 1 quick_gelu */
+    float ln_eps;
+    const float* patch_w;                  /* [width, kpad], zero padded */
+    const float* patch_b; const float* cls; const float* pos;
+    const hirest_block_weights_f32* blocks;    /* HOST array [layers] */
+    const float* norm_g; const float* norm_b;
+    const float* head_w; const float* head_b;  /* [embed_dim, width], [embed_dim] or NULL */
+    const float* image_mean; const float* image_std;
+    const float* ln_pre_g; const float* ln_pre_b;
+    int32_t out_all_tokens;
+} hirest_vision_tower_f32;
+
+typedef struct hirest_text_tower_f32 {
+    int32_t context, vocab, width, heads, layers, embed_dim;
+    int32_t act;
+    float ln_eps;
+    const float* tok_emb; const float* pos;
+    const hirest_block_weights_f32* blocks;    /* HOST array [layers] */
+    const float* lnf_g; const float* lnf_b;
+    const float* proj_w;                       /* [embed_dim, width] = text_projection^T */
+} hirest_text_tower_f32;
+
+size_t hirest_vision_workspace_bytes_f32(const hirest_vision_tower_f32* t, int32_t B);
+int hirest_vision_forward_f32(const hirest_vision_tower_f32* t, const void* frames, int32_t in_dtype, int32_t B, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+size_t hirest_text_workspace_bytes_f32(const hirest_text_tower_f32* t, int32_t B);
+int hirest_text_forward_f32(const hirest_text_tower_f32* t, const int64_t* tokens, int32_t B, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Joint model (MomentModel) path — fp32 end to end, because its outputs are frame INDICES
  * (modeling.py:155-474; clip4caption/modules/module_visual.py:104-264,396-424).
  * ------------------------------------------------------------------------------------ */
 /* out = act(A @ W^T + bias) (+ resid) (+ periodic[m % period]) in exact fp32 (k-ordered fmaf chain on
- * v_mfma_f32_32x32x2_f32).  act: 0 none, 1 gelu(erf), 2 tanh.  K % 16 == 0, N % 4 == 0.
+ * v_mfma_f32_32x32x2_f32).  act: 0 none, 1 gelu(erf), 2 tanh, 3 quick-gelu.  K % 16 == 0, N % 4 == 0.
  * Replaces the nn.Linear layers of the fusion, VisualEmbeddings (periodic = position embeddings),
  * VisualSelfOutput / VisualOutput (resid = the residual that precedes the post-LayerNorm). */
 int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,

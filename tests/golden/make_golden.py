@@ -217,18 +217,15 @@ def gen_eval():
 
 
 
-C3_V, C3_F = 64, 4          # sub-corpus of the matched-R@k check: 64 videos x 4 frames = 256 frames on the real reference
+C3_V, C3_F = 256, 4         # sub-corpus of the matched-R@k check (256 videos x 4 frames = 1024 frames on the real reference)
 
 
 def c3_corpus():
-    """SURVEY 8d C3 corpus rule: video v's frames = base_v + 0.1 * noise_f (non-degenerate, seeded)."""
-    base = synth.frames("c3.base", (C3_V, 1, 3, 224, 224), 5)
-    return base + 0.1 * synth.frames("c3.noise", (C3_V, C3_F, 3, 224, 224), 6)
+    return synth.c3_corpus(C3_V, C3_F)
 
 
 def c3_names():
-    # deliberately NOT in index order under string sort, so the (score, name) tie rule of evaluate.py:58-60 is exercised
-    return [f"vid_{(v * 37) % 101:03d}.mp4" for v in range(C3_V)]
+    return synth.c3_names(C3_V)
 
 
 def gen_c3(prompts):

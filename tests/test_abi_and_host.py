@@ -74,7 +74,7 @@ def test_model_schema_and_errors():
         hirest_amd.build_eva_model_and_transforms("no-such-model", pretrained="synth:0")
     with pytest.raises(Exception):
         hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained="/nonexistent.pt")
-    model, pre = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained="synth:11")
+    model, pre = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained="synth:11", precision="bf16")
     assert model.training  # the reference returns a train-mode module (eva_clip.py:155-172)
     sd = synth.eva_clip_state_dict(synth.EVA_CLIP_TINY, 11)
     got = model.state_dict()

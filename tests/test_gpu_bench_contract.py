@@ -42,6 +42,9 @@ def test_bench_line_contract():
     assert mr["queries"] == 546 and mr["videos"] == 64
     assert mr["matched_R@5"] == 100.0 and mr["matched_R@10"] == 100.0 and mr["matched_R@1"] >= 85.0
     assert mr["top1_exact_where_margin_gt_2x_error"] is True and mr["pooled_min_cosine_vs_reference"] > 0.999
+    # the reference-precision towers (precision='fp32') reproduce the reference's ranks; their speed is a separate figure
+    p32 = mr["precision_fp32"]
+    assert p32["top1_flips"] == 0 and p32["matched_R@1"] == 100.0 and p32["max_abs_score_error"] < 2e-5 and p32["frames_per_s"] > 10
     # executed vs unpruned work (the last block serves x[:, 0] only): the tower fraction is priced on executed FLOPs
     assert rf["executed_gflop_per_frame"] < rf["unpruned_gflop_per_frame"] == 534.06
     assert abs(rf["whole_tower_frac"] - d["value"] * rf["executed_gflop_per_frame"] / 1e3 / 2500.0) < 1e-9

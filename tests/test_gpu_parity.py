@@ -279,12 +279,14 @@ def _check_embed(got, ref, what):
     assert c >= COS_MIN and r <= REL_MAX
 
 
-def test_eva_tiny_towers_vs_reference(dev, golden_dir):
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_eva_tiny_towers_vs_reference(dev, golden_dir, precision):
     import hirest_amd
     g = np.load(os.path.join(golden_dir, "eva_tiny.npz"))
     seed = int(g["seed"])
-    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}")
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}", precision=precision)
     model = model.to(dev).eval()
+    assert model.visual.precision == model.text.precision == precision
     img = synth.frames("eva_tiny.img", (int(g["n_img"]), 3, 224, 224), seed + 1).to(dev)
     tok = torch.from_numpy(g["tokens"]).to(dev)
     _check_embed(model.encode_image(img).cpu(), torch.from_numpy(g["image_embed"]), "tiny image")
@@ -294,6 +296,10 @@ def test_eva_tiny_towers_vs_reference(dev, golden_dir):
     _check_embed(ft.cpu(), torch.from_numpy(g["fwd_text"]), "tiny fwd text")
     assert abs(ls.item() - float(g["logit_scale_exp"])) < 1e-4
     assert torch.equal(model(None, tok), model.encode_text(tok))
+    if precision == "fp32":   # the reference-precision towers (csrc/tower_f32.hip): fp32 agreement, not the bf16 bar
+        for got, key in ((model.encode_image(img), "image_embed"), (model.encode_text(tok), "text_embed")):
+            ref = torch.from_numpy(g[key])
+            assert (got.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), key
     # empty batches (the reference's modules return empty [0, E] tensors) and the reference's input checks
     assert tuple(model.encode_image(img[:0]).shape) == (0, fi.shape[1]) and tuple(model.encode_text(tok[:0]).shape) == (0, ft.shape[1])
     with pytest.raises(AssertionError):
@@ -306,10 +312,21 @@ def test_eva_g14_full_size_vs_reference(dev, golden_dir):
     import hirest_amd
     g = np.load(os.path.join(golden_dir, "eva_g14.npz"))
     seed = int(g["seed"])
-    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_g_14", pretrained=f"synth:{seed}")
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_g_14", pretrained=f"synth:{seed}")   # default = the reference's: fp32
     model = model.to(dev).eval()
     img = synth.frames("eva_g14.img", (int(g["n_img"]), 3, 224, 224), seed + 1).to(dev)
     tok = torch.from_numpy(g["tokens"]).to(dev)
+    # ---- precision='fp32' (eva_clip.py:90 default): 40 exact-fp32 layers agree with the reference's fp32 outputs to ~1e-5, and a
+    # row does not depend on what else is in the call
+    assert model.visual.precision == "fp32"
+    for got, key in ((model.encode_image(img), "image_embed"), (model.encode_text(tok), "text_embed")):
+        ref = torch.from_numpy(g[key])
+        err = (got.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"EVA-g/14 fp32 towers vs reference {key}: max |diff| / max |ref| = {err:.2e}")
+        assert err <= 5e-5, (key, err)
+    assert torch.equal(model.encode_image(torch.cat([img.flip(0), img], 0))[2:], model.encode_image(img))
+    # ---- the bf16 MFMA towers (the measured hot path) from here on
+    model.set_precision("bf16")
     out = model.encode_image(img)
     _check_embed(out.cpu(), torch.from_numpy(g["image_embed"]), "EVA-g/14 image (40 layers)")
     _check_embed(model.encode_text(tok).cpu(), torch.from_numpy(g["text_embed"]), "EVA-g/14 text (12 layers)")

@@ -21,7 +21,7 @@ def test_retrieval_matched_recall_and_shard_invariance():
     dev = torch.device("cuda:0")
     cfg, seed = synth.EVA_CLIP_TINY, 11
     V, F, Q = 40, 4, 24
-    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}")
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}", precision="bf16")
     model = model.to(dev).eval()
     sd = synth.eva_clip_state_dict(cfg, seed)
     # video v's frames = base_v + 0.1 * noise_f (a non-degenerate corpus)
@@ -72,7 +72,7 @@ def test_raw_uint8_videos_are_preprocessed_on_device():
     from oracle import ref_cpu as O
     dev = torch.device("cuda:0")
     cfg, seed = synth.EVA_CLIP_TINY, 11
-    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}")
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}", precision="bf16")
     model = model.to(dev).eval()
     sd = synth.eva_clip_state_dict(cfg, seed)
     V, F = 3, 2
@@ -100,11 +100,10 @@ def test_c3_matched_recall_at_g14_scale_vs_real_reference(golden_dir):
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(golden_dir, "eva_g14_c3.npz"))
     V, F, seed = int(g["V"]), int(g["F"]), int(g["seed"])
-    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_g_14", pretrained=f"synth:{seed}")
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_g_14", pretrained=f"synth:{seed}", precision="bf16")
     model = model.to(dev).eval()
-    base = synth.frames("c3.base", (V, 1, 3, 224, 224), 5)
-    frames = base + 0.1 * synth.frames("c3.noise", (V, F, 3, 224, 224), 6)
-    names = [f"vid_{(v * 37) % 101:03d}.mp4" for v in range(V)]
+    frames = synth.c3_corpus(V, F)
+    names = synth.c3_names(V)
     tok = torch.from_numpy(g["tokens"].astype(np.int64))
     assert torch.equal(tok, hirest_amd.tokenize(json.load(open(os.path.join(golden_dir, "test_prompts.json")))))
     pooled, fe = retrieval.encode_videos(model, frames.to(dev), return_frame_embeds=True)     # one 256-frame tower call
@@ -141,3 +140,17 @@ def test_c3_matched_recall_at_g14_scale_vs_real_reference(golden_dir):
     ref_sorted = ref_scores.sort(dim=1, descending=True).values
     clear = (gaps.min(dim=1).values > 2 * err) & ((ref_sorted[:, 9] - ref_sorted[:, 10]) > 2 * err)
     assert torch.equal(idx[clear], ref_top[clear])
+    # ---- precision='fp32' (the reference's default, eva_clip.py:90): the exact-fp32 towers reproduce the reference's RANKS:
+    # matched R@1 = 100 %, zero top-1 flips, and the whole top-10 wherever fp32 itself separates the scores
+    model.set_precision("fp32")
+    pooled32 = retrieval.encode_videos(model, frames.to(dev))
+    texts32 = retrieval.encode_texts(model, tok.to(dev))
+    scores32, _, idx32 = retrieval.retrieve(texts32, pooled32, 10, retrieval.tie_rank_from_names(names, dev))
+    idx32, scores32 = idx32.cpu().long(), scores32.cpu()
+    err32 = (scores32 - ref_scores).abs().max().item()
+    flips32 = int((idx32[:, 0] != gt_idx).sum())
+    print(f"C3 @ g/14, precision='fp32': max |score error| {err32:.2e}, top-1 flips {flips32} of {gt_idx.numel()}, "
+          f"smallest reference margin {margin.min().item():.2e}")
+    assert err32 < 2e-5 and flips32 == 0
+    clear32 = (gaps.min(dim=1).values > 4 * err32) & ((ref_sorted[:, 9] - ref_sorted[:, 10]) > 4 * err32)
+    assert clear32.float().mean().item() > 0.9 and torch.equal(idx32[clear32], ref_top[clear32])

@@ -190,7 +190,7 @@ def test_c3_fixture_and_host_recall(golden_dir):
     from hirest_amd import retrieval
     g = load(golden_dir, "eva_g14_c3.npz")
     V = int(g["V"])
-    names = [f"vid_{(v * 37) % 101:03d}.mp4" for v in range(V)]
+    names = synth.c3_names(V)
     pooled, scores = torch.from_numpy(g["pooled"]), torch.from_numpy(g["scores"])
     assert np.abs(pooled.norm(dim=-1).numpy() - 1).max() < 1e-5
     assert np.abs(O.similarity(torch.from_numpy(g["text_embed32"]), pooled).numpy() - g["scores"][:32]).max() < 2e-6

@@ -183,7 +183,7 @@ def test_gpu_preprocess_full_size_batch_and_encode():
     u8 = pre(x)
     for b in (0, 17, 47):
         assert np.array_equal(u8[b].cpu().numpy(), P.transform_u8(arr[b], 224))
-    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained="synth:11")
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained="synth:11", precision="bf16")
     model = model.to(dev).eval()
     e_u8 = model.encode_image(u8[:8])
     e_f32 = model.encode_image(pre(x[:8], normalized=True))

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hirest_amd  # noqa: E402
 
 dev = torch.device("cuda:0")
-model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_g_14", pretrained="synth:3")
+model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_g_14", pretrained="synth:3", precision="bf16")
 model = model.to(dev).eval()
 gen = torch.Generator(device=dev); gen.manual_seed(5)
 full = torch.randn((3072, 3, 224, 224), device=dev, generator=gen, dtype=torch.bfloat16)
