@@ -87,7 +87,7 @@ def test_raw_uint8_videos_are_preprocessed_on_device():
 def test_c3_matched_recall_at_g14_scale_vs_real_reference(golden_dir):
     """BASELINE configs[2] / "matched R@1" at EVA-CLIP-g/14 scale.  tests/golden/eva_g14_c3.npz holds
     what the REAL reference (eva_model.EVA_CLIP fp32 on CPU, synthetic weights; make_golden.py gen_c3) produced for a
-    64-video x 4-frame sub-corpus (SURVEY 8d corpus rule) and the 546 real HiREST test prompts: pooled video rows, scores,
+    256-video x 4-frame sub-corpus (SURVEY 8d corpus rule) and the 546 real HiREST test prompts: pooled video rows, scores,
     top-10 under evaluate.py's (score, name) order, top-2 margins.  GT(q) = the reference's top-1.  The GPU path must
     rank every query's GT inside its top-5, agree on top-1 wherever the reference's margin exceeds twice the score error
     bf16 encoding causes, and reproduce the reference's embeddings at the parity bar."""
@@ -106,11 +106,11 @@ def test_c3_matched_recall_at_g14_scale_vs_real_reference(golden_dir):
     names = synth.c3_names(V)
     tok = torch.from_numpy(g["tokens"].astype(np.int64))
     assert torch.equal(tok, hirest_amd.tokenize(json.load(open(os.path.join(golden_dir, "test_prompts.json")))))
-    pooled, fe = retrieval.encode_videos(model, frames.to(dev), return_frame_embeds=True)     # one 256-frame tower call
+    pooled, fe = retrieval.encode_videos(model, frames.to(dev), return_frame_embeds=True)     # one 1024-frame tower call
     texts = retrieval.encode_texts(model, tok.to(dev))
     scores, val, idx = retrieval.retrieve(texts, pooled, 10, retrieval.tie_rank_from_names(names, dev))
     idx, scores = idx.cpu().long(), scores.cpu()
-    # ---- embeddings against the reference's own outputs (16 frames of the 40-layer tower, 32 text rows, 64 pooled rows)
+    # ---- embeddings against the reference's own outputs (16 frames of the 40-layer tower, 32 text rows, 256 pooled rows)
     cosf = torch.nn.functional.cosine_similarity
     c_frame = cosf(fe.reshape(V * F, -1)[:16].cpu(), torch.from_numpy(g["frame_embed16"]), dim=-1).min().item()
     c_pool = cosf(pooled.cpu(), torch.from_numpy(g["pooled"]), dim=-1).min().item()

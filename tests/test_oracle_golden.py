@@ -184,7 +184,7 @@ def test_step_captioning_matches_reference(golden_dir, case):
 
 
 def test_c3_fixture_and_host_recall(golden_dir):
-    """tests/golden/eva_g14_c3.npz (real reference, EVA-CLIP-g/14, 64 videos x 4 frames x 546 prompts) is self-consistent
+    """tests/golden/eva_g14_c3.npz (real reference, EVA-CLIP-g/14, 256 videos x 4 frames x 546 prompts) is self-consistent
     under the oracle's scoring / ranking restatement, and hirest_amd.retrieval.recall_at_k (index form, used on GPU top-k
     output) equals the oracle's evaluate.py restatement on it and on the tie-laden retrieval_eval.json scores."""
     from hirest_amd import retrieval
