@@ -228,6 +228,133 @@ __global__ __launch_bounds__(64) void attention_train_bwd_kv_kernel(AttnT a, con
     dv[(int64_t)(b * a.Tk + j) * lddkv + h * 64 + lane] = gv;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same attention as tiled matrix products (round 3).  One wave per score row (above) ran the five products of a layer —
+// S = Q K^T, ctx = drop(P) V, dP = dctx V^T, dq = dS K, dk = dS^T Q, dv = drop(P)^T dctx — as 64-deep scalar dot products:
+// 1.2 ms per layer at B = 5, T = 300 (2.8 TFLOP/s).  Here each product is a batched 64 x 64-tile GEMM on
+// v_mfma_f32_32x32x2_f32 (one batch entry per (b, h): grid.z), operands addressed through element strides so that transposed
+// and head-sliced views need no copy, the dropout mask regenerated inside the operand load or the epilogue, and the row-wise
+// steps (softmax; dS = P (dP - sum P dP)) are one wave per row over rows that are already in memory.
+//   C[z][m][n] = epi( sum_k A[z][m][k] B[z][n][k] ),   z = (b1, b2): pointer offsets b1 * s?b1 + b2 * s?b2
+// Tile / MFMA layout as hirest_gemm_f32's 64x64 kernel (joint.hip): 4 waves (2 x 2) of one 32x32 tile, K staged 32 deep through
+// LDS with the (2 (k & 15) + (k >> 4)) slab image; summation in k order over slabs (no K-quarter split: these are their own ops).
+struct BGemm {
+    const float* A; int64_t sam, sak, sab1, sab2;
+    const float* B; int64_t sbn, sbk, sbb1, sbb2;
+    float* C; int64_t scm, scb1, scb2;          // C[m][n] at scm * m + n
+    int M, N, K, nb2;
+    float alpha;                                // epilogue: acc * alpha
+    float addc; const float* mask; int64_t smb1;   // scores: + (addc + mask[b1][m][n]) (mask NULL: + addc), mask row stride N
+    int drop_a;                                 // 1: A[m][k] is P[m][k] and gets its dropout keep factor; 2: A[m][k] = P[k][m] (transposed view)
+    int drop_c;                                 // 1: epilogue multiplies by the keep factor of P[m][n]
+    float drop; uint32_t seed; int Tq, Tk;      // mask geometry: element (i, j) of batch entry z has index (z * Tq + i) * Tk + j
+};
+constexpr int BK_ = 32, BLD = BK_ + 1;
+
+__global__ __launch_bounds__(256) void gemm_f32_batched_kernel(BGemm p) {
+    __shared__ float As[64 * BLD];
+    __shared__ float Bs[64 * BLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M0 = blockIdx.y * 64, N0 = blockIdx.x * 64, z = blockIdx.z;
+    const int b1 = z / p.nb2, b2 = z - b1 * p.nb2;
+    const float* Ab = p.A + b1 * p.sab1 + b2 * p.sab2;
+    const float* Bb = p.B + b1 * p.sbb1 + b2 * p.sbb2;
+    // staging: 64 rows x 32 k per operand and slab, 8 elements per thread.  The thread -> element map follows the operand's
+    // contiguous dimension so that a wave's loads are whole lines either way:
+    //   k contiguous (s?k == 1): thread -> row tid / 4, k = 8 (tid % 4) .. + 7
+    //   rows contiguous        : thread -> k = tid / 8 (0..31), rows 8 (tid % 8) .. + 7
+    const bool a_kc = p.sak == 1, b_kc = p.sbk == 1;
+    const int a_r0 = a_kc ? tid >> 2 : (tid & 7) * 8, a_k0 = a_kc ? (tid & 3) * 8 : tid >> 3;
+    const int b_r0 = b_kc ? tid >> 2 : (tid & 7) * 8, b_k0 = b_kc ? (tid & 3) * 8 : tid >> 3;
+    float av[8], bv[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int am = M0 + a_r0 + (a_kc ? 0 : e), ak = k0 + a_k0 + (a_kc ? e : 0);
+            const bool ain = am < p.M && ak < p.K;
+            float v = Ab[(int64_t)(ain ? am : 0) * p.sam + (int64_t)(ain ? ak : 0) * p.sak];
+            if (p.drop_a) {
+                const int pi = p.drop_a == 1 ? am : ak, pj = p.drop_a == 1 ? ak : am;
+                v *= keep_scale(p.seed, ((uint64_t)z * p.Tq + pi) * p.Tk + pj, p.drop);
+            }
+            av[e] = ain ? v : 0.f;
+            const int bn = N0 + b_r0 + (b_kc ? 0 : e), bk = k0 + b_k0 + (b_kc ? e : 0);
+            const bool bin = bn < p.N && bk < p.K;
+            const float w = Bb[(int64_t)(bin ? bn : 0) * p.sbn + (int64_t)(bin ? bk : 0) * p.sbk];
+            bv[e] = bin ? w : 0.f;
+        }
+    };
+    const int arow = (wm * 32 + (lane & 31)) * BLD + (lane >> 5);
+    const int brow = (wn * 32 + (lane & 31)) * BLD + (lane >> 5);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nslab = (p.K + BK_ - 1) / BK_;
+    fetch(0);
+    for (int sl = 0; sl < nslab; ++sl) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ar = a_r0 + (a_kc ? 0 : e), ak = a_k0 + (a_kc ? e : 0);
+            As[ar * BLD + 2 * (ak & 15) + (ak >> 4)] = av[e];
+            const int br = b_r0 + (b_kc ? 0 : e), bk = b_k0 + (b_kc ? e : 0);
+            Bs[br * BLD + 2 * (bk & 15) + (bk >> 4)] = bv[e];
+        }
+        __syncthreads();
+        if (sl + 1 < nslab) fetch((sl + 1) * BK_);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bs[brow + 2 * j], As[arow + 2 * j], acc, 0, 0, 0);
+    }
+    const int m = M0 + wm * 32 + (lane & 31);
+    if (m >= p.M) return;
+    float* crow = p.C + b1 * p.scb1 + b2 * p.scb2 + (int64_t)m * p.scm;
+    const float* mrow = p.mask ? p.mask + b1 * p.smb1 + (int64_t)m * p.N : nullptr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = N0 + wn * 32 + 8 * g + 4 * (lane >> 5) + e;
+            if (n >= p.N) continue;
+            float v = acc[4 * g + e] * p.alpha;
+            if (p.mask || p.addc != 0.f) v = v + (p.addc + (mrow ? mrow[n] : 0.f));      // fl(fl(q.k * scale) + m), as the reference adds it
+            if (p.drop_c) v *= keep_scale(p.seed, ((uint64_t)z * p.Tq + m) * p.Tk + n, p.drop);
+            crow[n] = v;
+        }
+}
+
+// P[row] = softmax(P[row]) in place (row = (b, h, i), Tk scores), one wave per row
+__global__ __launch_bounds__(256) void attn_softmax_rows_kernel(float* __restrict__ P, int64_t rows, int Tk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* pr = P + row * Tk;
+    float mx = -3.0e38f;
+    for (int j = lane; j < Tk; j += 64) mx = fmaxf(mx, pr[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Tk; j += 64) { const float e = __expf(pr[j] - mx); pr[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Tk; j += 64) pr[j] *= inv;
+}
+
+// dS[row] = P[row] * (dP[row] - sum_j P dP) in place over dS (which holds dP), one wave per row
+__global__ __launch_bounds__(256) void attn_ds_rows_kernel(const float* __restrict__ P, float* __restrict__ dS, int64_t rows, int Tk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = P + row * Tk;
+    float* dr = dS + row * Tk;
+    float delta = 0.f;
+    for (int j = lane; j < Tk; j += 64) delta = fmaf(pr[j], dr[j], delta);
+    delta = wave_sum(delta);
+    for (int j = lane; j < Tk; j += 64) dr[j] = pr[j] * (dr[j] - delta);
+}
+
+int g_attn_train_tiled = 1;     // 0: the one-wave-per-row kernels (A/B, tests)
+
 // x[r] = table[ids[r]] + pos[r % T]   (DecoderEmbeddings, module_decoder.py:309-321) and its scatter-add backward
 __global__ void embedding_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table, const float* __restrict__ pos,
                                      float* __restrict__ out, int64_t rows, int T, int D, const int32_t* __restrict__ pos_ids) {
@@ -393,6 +520,17 @@ extern "C" int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const flo
     return hirest_launch_status();
 }
 
+__global__ void scale_by_scalar_kernel(float* __restrict__ x, const float* __restrict__ scalar, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= *scalar;
+}
+
+extern "C" int hirest_scale_by_device_scalar_f32(float* x, const float* scalar, int64_t n, void* stream) {
+    if (!x || !scalar || n <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, grid1(n), dim3(256), 0, S_(stream), x, scalar, n);
+    return hirest_launch_status();
+}
+
 extern "C" int hirest_act_f32(const float* pre, float* y, int64_t n, int32_t act, void* stream) {
     if (!pre || !y || n <= 0 || act < 0 || act > 2) return HIREST_E_BADARG;
     hipLaunchKernelGGL(act_kernel, grid1(n), dim3(256), 0, S_(stream), pre, y, n, act);
@@ -425,7 +563,21 @@ extern "C" int hirest_attention_train_fwd_qkv_f32(const float* q, int64_t ldq, c
     if (!q || !k || !v || !P || !ctx || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
     if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
     const AttnT a{q, ldq, k, v, ldkv, mask_add, B, Tq, Tk, H, scale, add_const, drop_p, seed};
-    hipLaunchKernelGGL(attention_train_fwd_kernel, dim3((unsigned)((int64_t)B * H * Tq)), dim3(64), 0, S_(stream), a, P, ctx, ldctx);
+    if (!g_attn_train_tiled) {
+        hipLaunchKernelGGL(attention_train_fwd_kernel, dim3((unsigned)((int64_t)B * H * Tq)), dim3(64), 0, S_(stream), a, P, ctx, ldctx);
+        return hirest_launch_status();
+    }
+    const dim3 blk(256);
+    const int64_t TT = (int64_t)Tq * Tk;
+    // S = fl(fl(Q K^T * scale) + (add_const + mask)) -> P (raw scores), batch entry z = b * H + h
+    BGemm s_{q, ldq, 1, (int64_t)Tq * ldq, 64, k, ldkv, 1, (int64_t)Tk * ldkv, 64, P, Tk, (int64_t)H * TT, TT, Tq, Tk, 64, H, scale, add_const, mask_add, TT,
+             0, 0, 0.f, seed, Tq, Tk};
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3((Tk + 63) / 64, (Tq + 63) / 64, B * H), blk, 0, S_(stream), s_);
+    hipLaunchKernelGGL(attn_softmax_rows_kernel, dim3((unsigned)(((int64_t)B * H * Tq + 3) / 4)), blk, 0, S_(stream), P, (int64_t)B * H * Tq, Tk);
+    // ctx = drop(P) V: A = P [Tq, Tk] (k contiguous), B[n][k] = V[k][n] (rows contiguous)
+    BGemm c_{P, Tk, 1, (int64_t)H * TT, TT, v, 1, ldkv, (int64_t)Tk * ldkv, 64, ctx, ldctx, (int64_t)Tq * ldctx, 64, Tq, 64, Tk, H, 1.0f, 0.f, nullptr, 0,
+             1, 0, drop_p, seed, Tq, Tk};
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tq + 63) / 64, B * H), blk, 0, S_(stream), c_);
     return hirest_launch_status();
 }
 
@@ -436,10 +588,39 @@ extern "C" int hirest_attention_train_bwd_qkv_f32(const float* q, int64_t ldq, c
     if (!q || !k || !v || !P || !dctx || !dS || !dq || !dk || !dv || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
     if (dh != 64 || !(drop_p >= 0.f && drop_p < 1.f)) return HIREST_E_SHAPE;
     const AttnT a{q, ldq, k, v, ldkv, nullptr, B, Tq, Tk, H, scale, 0.f, drop_p, seed};
-    hipLaunchKernelGGL(attention_train_bwd_q_kernel, dim3((unsigned)((int64_t)B * H * Tq)), dim3(64), 0, S_(stream), a, P, dctx, ldctx, dS, dq, lddq);
-    hipLaunchKernelGGL(attention_train_bwd_kv_kernel, dim3((unsigned)((int64_t)B * H * Tk)), dim3(64), 0, S_(stream), a, P, dctx, ldctx, dS, dk, dv,
-                       lddkv);
+    if (!g_attn_train_tiled) {
+        hipLaunchKernelGGL(attention_train_bwd_q_kernel, dim3((unsigned)((int64_t)B * H * Tq)), dim3(64), 0, S_(stream), a, P, dctx, ldctx, dS, dq, lddq);
+        hipLaunchKernelGGL(attention_train_bwd_kv_kernel, dim3((unsigned)((int64_t)B * H * Tk)), dim3(64), 0, S_(stream), a, P, dctx, ldctx, dS, dk, dv,
+                           lddkv);
+        return hirest_launch_status();
+    }
+    const dim3 blk(256);
+    const int64_t TT = (int64_t)Tq * Tk;
+    const int Z = B * H;
+    // dP = keep * (dctx V^T) -> dS buffer
+    BGemm dp{dctx, ldctx, 1, (int64_t)Tq * ldctx, 64, v, ldkv, 1, (int64_t)Tk * ldkv, 64, dS, Tk, (int64_t)H * TT, TT, Tq, Tk, 64, H, 1.0f, 0.f, nullptr, 0,
+             0, 1, drop_p, seed, Tq, Tk};
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3((Tk + 63) / 64, (Tq + 63) / 64, Z), blk, 0, S_(stream), dp);
+    hipLaunchKernelGGL(attn_ds_rows_kernel, dim3((unsigned)(((int64_t)Z * Tq + 3) / 4)), blk, 0, S_(stream), P, dS, (int64_t)Z * Tq, Tk);
+    // dq = scale * dS K: A = dS [Tq, Tk], B[n][k] = K[k][n]
+    BGemm gq{dS, Tk, 1, (int64_t)H * TT, TT, k, 1, ldkv, (int64_t)Tk * ldkv, 64, dq, lddq, (int64_t)Tq * lddq, 64, Tq, 64, Tk, H, scale, 0.f, nullptr, 0,
+             0, 0, 0.f, seed, Tq, Tk};
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tq + 63) / 64, Z), blk, 0, S_(stream), gq);
+    // dk = scale * dS^T Q: A[m][k] = dS[k][m] (rows contiguous), B[n][k] = Q[k][n]
+    BGemm gk{dS, 1, Tk, (int64_t)H * TT, TT, q, 1, ldq, (int64_t)Tq * ldq, 64, dk, lddkv, (int64_t)Tk * lddkv, 64, Tk, 64, Tq, H, scale, 0.f, nullptr, 0,
+             0, 0, 0.f, seed, Tq, Tk};
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tk + 63) / 64, Z), blk, 0, S_(stream), gk);
+    // dv = drop(P)^T dctx: A[m][k] = keep * P[k][m], B[n][k] = dctx[k][n]
+    BGemm gv{P, 1, Tk, (int64_t)H * TT, TT, dctx, 1, ldctx, (int64_t)Tq * ldctx, 64, dv, lddkv, (int64_t)Tk * lddkv, 64, Tk, 64, Tq, H, 1.0f, 0.f, nullptr, 0,
+             2, 0, drop_p, seed, Tq, Tk};
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tk + 63) / 64, Z), blk, 0, S_(stream), gv);
     return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_train_select(int32_t which) {
+    if (which != 0 && which != 1) return HIREST_E_BADARG;
+    g_attn_train_tiled = which;
+    return 0;
 }
 
 // packed self-attention forms (q | k | v in one [B*T, 3*H*64] activation)

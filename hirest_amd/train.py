@@ -117,6 +117,15 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
+def _scale_by_upstream(dl: torch.Tensor, gloss) -> None:
+    """dl *= gloss, the upstream gradient autograd hands to backward (1 for a plain ``loss.backward()``; a GradScaler's or an
+    accumulation factor otherwise), read by the kernel from device memory: no host synchronisation in the training step."""
+    if gloss is None:
+        return
+    gl = gloss.detach().to(device=dl.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+    _chk(_lib.load().hirest_scale_by_device_scalar_f32(dl.data_ptr(), gl.data_ptr(), dl.numel(), ops.stream_ptr()), "scale_by_upstream")
+
+
 # parameters on a task's graph, in the order the Function receives them / returns gradients for
 _D = "clip4cap_model.decoder."
 
@@ -353,6 +362,9 @@ class MomentLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         S = ctx.S
+        if S is None:
+            raise RuntimeError("hirest_amd: this loss was already back-propagated (the kernels' saved activations are released after "
+                               "the first backward; retain_graph is not supported)")
         lib = _lib.load()
         P, names, model = S["P"], S["names"], S["model"]
         B, T = S["B"], S["T"]
@@ -360,13 +372,14 @@ class MomentLoss(torch.autograd.Function):
         feats, logits, mm32 = S["feats"], S["logits"], S["mm32"]
         dev = feats.device
         G: Dict[str, torch.Tensor] = {}
-        g = float(gloss.item()) if gloss is not None else 1.0       # upstream scale (GradScaler / accumulation); a host scalar
+        g = 1.0                                                     # the upstream scale is applied on the device below (no host read)
         dl = torch.empty_like(logits)
         scratch = torch.zeros((1,), dtype=torch.float32, device=dev)
         dx = torch.empty((R, Hd), dtype=torch.float32, device=dev)
         if S["seg"]:
             _chk(lib.hirest_ce_masked_f32(logits.data_ptr(), mm32.data_ptr(), S["st"].data_ptr(), B, T, g, scratch.data_ptr(), dl.data_ptr(),
                                           ops.stream_ptr()), "ce_masked")
+            _scale_by_upstream(dl, gloss)
             wsg = P["segment_predictor.0.weight"]
             G["segment_predictor.0.weight"] = _K.colsum(feats, weight=dl[0]).reshape(1, Hd)
             G["segment_predictor.0.bias"] = _K.colsum(dl[0].reshape(R, 1))
@@ -375,6 +388,7 @@ class MomentLoss(torch.autograd.Function):
             for h_i, tgt in enumerate((S["st"], S["et"])):
                 _chk(lib.hirest_bce_masked_f32(logits[h_i].data_ptr(), tgt.data_ptr(), mm32.data_ptr(), B, T, 0.5 * g, scratch.data_ptr(),
                                                dl[h_i].data_ptr(), ops.stream_ptr()), "bce_masked")
+            _scale_by_upstream(dl, gloss)
             ws, we = P["start_predictor.0.weight"], P["end_predictor.0.weight"]
             G["start_predictor.0.weight"] = _K.colsum(feats, weight=dl[0]).reshape(1, Hd)
             G["end_predictor.0.weight"] = _K.colsum(feats, weight=dl[1]).reshape(1, Hd)
@@ -476,19 +490,23 @@ class CaptionLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         S = ctx.S
+        if S is None:
+            raise RuntimeError("hirest_amd: this loss was already back-propagated (the kernels' saved activations are released after "
+                               "the first backward; retain_graph is not supported)")
         lib = _lib.load()
         P, names, model = S["P"], S["names"], S["model"]
         B, F, L, drop, seed = S["B"], S["T"], S["L"], S["drop"], S["seed"]
         R, Hd, heads, V, Vp = B * L, 768, model.heads, S["V"], S["Vp"]
         dev = S["enc"].device
         G: Dict[str, torch.Tensor] = {}
-        g = float(gloss.item()) if gloss is not None else 1.0
+        g = 1.0                                                     # the upstream scale is applied on the device below (no host read)
         cp = _D + "classifier.cls.predictions."
         logits = S["logits"]
         dlog = torch.empty_like(logits)
         scratch = torch.zeros((1,), dtype=torch.float32, device=dev)
         _chk(lib.hirest_ce_rows_f32(logits.data_ptr(), Vp, S["tgt32"].data_ptr(), R, Vp, g, S["n_tok"], scratch.data_ptr(), dlog.data_ptr(),
                                     ops.stream_ptr()), "ce_rows")
+        _scale_by_upstream(dlog, gloss)
         dWe = _K.grad_weight(dlog, S["tnorm"])                          # [Vp, 768]: the LM head's share of the tied matrix
         G[cp + "bias"] = _K.colsum(dlog)[:V]
         dtn = _K.grad_input(dlog, S["Wp"])
@@ -574,6 +592,16 @@ def time_grid(n_valid: torch.Tensor, T: int) -> torch.Tensor:
     return torch.stack(rows).to(n_valid.device)
 
 
+def _dropout_seed() -> int:
+    """A fresh seed per step from torch's CPU generator (so torch.manual_seed makes runs repeatable), mixed with the process rank:
+    data-parallel ranks started from the same torch seed must not share their dropout masks."""
+    s = int(torch.randint(0, 2 ** 31 - 1024, (1,)).item())
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        s = (s + 0x9E3779B1 * (dist.get_rank() + 1)) % (2 ** 31 - 1024)
+    return s
+
+
 def _train(model, batch, task) -> Dict[str, torch.Tensor]:
     dev = model.clip_g_map.weight.device
     if dev.type != "cuda":
@@ -582,7 +610,7 @@ def _train(model, batch, task) -> Dict[str, torch.Tensor]:
         text = model._text_feat(batch, dev)
     inp = {"task": task, "vis": batch["vis_feats"].to(dev), "text": text, "vis_mask": batch["vis_mask"].to(dev),
            "moment_mask": batch["moment_mask"].to(dev),
-           "dropout": 0.1 if model.training else 0.0, "seed": int(torch.randint(0, 2 ** 31 - 1024, (1,)).item())}
+           "dropout": 0.1 if model.training else 0.0, "seed": _dropout_seed()}
     if model.use_asr:
         inp["asr"] = batch["asr_feats"].to(dev)
     fn = MomentLoss

@@ -426,6 +426,8 @@ int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const float* row_wei
 /* y = act(pre) and dx = dy * act'(pre);  act: 0 identity, 1 gelu (erf form), 2 tanh; backward only: 3 = tanh given its OUTPUT
  * in `pre` (1 - y^2) */
 int hirest_act_f32(const float* pre, float* y, int64_t n, int32_t act, void* stream);
+/* x[i] *= *scalar (one device float): the upstream gradient of loss.backward() applied to the loss gradient without a host read */
+int hirest_scale_by_device_scalar_f32(float* x, const float* scalar, int64_t n, void* stream);
 int hirest_act_bwd_f32(const float* pre, const float* dy, float* dx, int64_t n, int32_t act, void* stream);
 /* y[i] = (resid ? resid[i] : 0) + x[i] * keep(seed, i) / (1 - p): nn.Dropout with a counter-based mask, fused with the residual
  * add that follows it in VisualSelfOutput / VisualOutput (p = 0: a plain add; the same call on dy is the backward) */
@@ -443,6 +445,9 @@ int hirest_attention_train_bwd_f32(const float* qkv, const float* P, const float
                                    int32_t T, int32_t H, int32_t dh, float scale, float drop_p, uint32_t seed, void* stream);
 /* General forms (caption decoder, module_decoder.py:192-262): separate q [B*Tq, ldq] and k / v [B*Tk, ldkv], an optional
  * additive mask [B, Tq, Tk] (the decoder's -10000 on future and padded keys) on top of add_const. */
+/* 1 (default): the attention products as batched MFMA GEMMs + row kernels; 0: the one-wave-per-score-row kernels of round 2
+ * (A/B timing, tests).  Same interface and buffers either way. */
+int hirest_attention_train_select(int32_t which);
 int hirest_attention_train_fwd_qkv_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                                        const float* mask_add, float* P, float* ctx, int64_t ldctx, int32_t B, int32_t Tq, int32_t Tk,
                                        int32_t H, int32_t dh, float scale, float add_const, float drop_p, uint32_t seed, void* stream);

@@ -158,3 +158,35 @@ def test_inference_cache_follows_optimizer_updates(dev, golden_dir):
                                         batch["moment_mask"].to(dev), batch["asr_feats"].to(dev))
     assert torch.equal(fl["start_logits"], ff["start_logits"]) and torch.equal(fl["end_logits"], ff["end_logits"])
     assert before is not None
+
+
+def test_tiled_training_attention_equals_the_row_kernels_with_dropout_on(dev, golden_dir):
+    """The attention products as batched MFMA GEMMs (round 3) against the one-wave-per-row kernels they replace, in TRAIN mode:
+    the counter-based dropout masks are regenerated inside operand loads / epilogues of five different products (P as the A
+    operand, P^T as the A operand, dP in an epilogue), so the same seed must give the same loss and the same gradients up to
+    the summation order — a mis-indexed mask in any one product shows up as an O(1) gradient difference."""
+    from hirest_amd import _lib
+    lib = _lib.load()
+    model, batch, seg_batch, cap_batch, _ = _setup(golden_dir, "b", dev)
+    model.train()
+    out = {}
+    try:
+        for which in (0, 1):
+            lib.hirest_attention_train_select(which)
+            res = []
+            for b in (batch, cap_batch):
+                for p in model.parameters():
+                    p.grad = None
+                torch.manual_seed(1234)                          # _train draws the dropout seed from torch's CPU generator
+                loss = model.train_step(b)["loss"]
+                loss.backward()
+                res.append((loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+            out[which] = res
+    finally:
+        lib.hirest_attention_train_select(1)
+    for (l0, g0), (l1, g1) in zip(out[0], out[1]):
+        assert abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+        assert g0.keys() == g1.keys()
+        for n in g0:
+            d = (g0[n] - g1[n]).norm().item()
+            assert d <= 1e-4 * g0[n].norm().item() + 1e-7, (n, d, g0[n].norm().item())
