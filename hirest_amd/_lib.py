@@ -156,6 +156,8 @@ _SIGNATURES = {
     "hirest_dropout_add_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint32, C.c_void_p]),
     "hirest_layernorm_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_attention_train_select": (C.c_int, [C.c_int32]),
+    "hirest_gemm_f32_strided": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "hirest_attention_train_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                                  C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "hirest_attention_train_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

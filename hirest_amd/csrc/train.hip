@@ -248,7 +248,13 @@ struct BGemm {
     int drop_a;                                 // 1: A[m][k] is P[m][k] and gets its dropout keep factor; 2: A[m][k] = P[k][m] (transposed view)
     int drop_c;                                 // 1: epilogue multiplies by the keep factor of P[m][n]
     float drop; uint32_t seed; int Tq, Tk;      // mask geometry: element (i, j) of batch entry z has index (z * Tq + i) * Tk + j
+    int a_vec, b_vec;                           // the operand's strides and base allow aligned 16-byte loads along its contiguous dimension
 };
+inline int vec_ok(const float* p, int64_t s0, int64_t s1, int64_t sb1, int64_t sb2) {   // one stride is 1, the others multiples of 4
+    const int64_t big = s0 == 1 ? s1 : s0;
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (s0 == 1 || s1 == 1) && big % 4 == 0 && sb1 % 4 == 0 && sb2 % 4 == 0) ? 1 : 0;
+}
+inline void set_vec(BGemm& g) { g.a_vec = vec_ok(g.A, g.sam, g.sak, g.sab1, g.sab2); g.b_vec = vec_ok(g.B, g.sbn, g.sbk, g.sbb1, g.sbb2); }
 constexpr int BK_ = 32, BLD = BK_ + 1;
 
 __global__ __launch_bounds__(256) void gemm_f32_batched_kernel(BGemm p) {
@@ -268,22 +274,33 @@ __global__ __launch_bounds__(256) void gemm_f32_batched_kernel(BGemm p) {
     const int a_r0 = a_kc ? tid >> 2 : (tid & 7) * 8, a_k0 = a_kc ? (tid & 3) * 8 : tid >> 3;
     const int b_r0 = b_kc ? tid >> 2 : (tid & 7) * 8, b_k0 = b_kc ? (tid & 3) * 8 : tid >> 3;
     float av[8], bv[8];
-    auto fetch = [&](int k0) {
+    // 16-byte loads where the 8 elements of a thread are contiguous, in range and aligned (p.a_vec / p.b_vec: strides and base
+    // are multiples of 4 floats); element-wise otherwise (edges, odd strides)
+    auto fetch_op = [&](const float* base, int64_t s_r, int64_t s_k, bool kc, int r0, int kk0, int R0, int Rn, int k0, bool vec, int dropm,
+                        float (&o)[8]) {
+        const int r = R0 + r0, k = k0 + kk0;
+        const bool full = kc ? (r < Rn && k + 8 <= p.K) : (r + 8 <= Rn && k < p.K);
+        if (vec && full && !dropm) {
+            const float* ptr = base + (int64_t)r * s_r + (int64_t)k * s_k;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ptr), x1 = *reinterpret_cast<const f32x4*>(ptr + 4);
+            o[0] = x0[0]; o[1] = x0[1]; o[2] = x0[2]; o[3] = x0[3]; o[4] = x1[0]; o[5] = x1[1]; o[6] = x1[2]; o[7] = x1[3];
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int am = M0 + a_r0 + (a_kc ? 0 : e), ak = k0 + a_k0 + (a_kc ? e : 0);
-            const bool ain = am < p.M && ak < p.K;
-            float v = Ab[(int64_t)(ain ? am : 0) * p.sam + (int64_t)(ain ? ak : 0) * p.sak];
-            if (p.drop_a) {
-                const int pi = p.drop_a == 1 ? am : ak, pj = p.drop_a == 1 ? ak : am;
+            const int rr = r + (kc ? 0 : e), kk = k + (kc ? e : 0);
+            const bool in = rr < Rn && kk < p.K;
+            float v = base[(int64_t)(in ? rr : 0) * s_r + (int64_t)(in ? kk : 0) * s_k];
+            if (dropm) {
+                const int pi = dropm == 1 ? rr : kk, pj = dropm == 1 ? kk : rr;
                 v *= keep_scale(p.seed, ((uint64_t)z * p.Tq + pi) * p.Tk + pj, p.drop);
             }
-            av[e] = ain ? v : 0.f;
-            const int bn = N0 + b_r0 + (b_kc ? 0 : e), bk = k0 + b_k0 + (b_kc ? e : 0);
-            const bool bin = bn < p.N && bk < p.K;
-            const float w = Bb[(int64_t)(bin ? bn : 0) * p.sbn + (int64_t)(bin ? bk : 0) * p.sbk];
-            bv[e] = bin ? w : 0.f;
+            o[e] = in ? v : 0.f;
         }
+    };
+    auto fetch = [&](int k0) {
+        fetch_op(Ab, p.sam, p.sak, a_kc, a_r0, a_k0, M0, p.M, k0, p.a_vec != 0, p.drop_a, av);
+        fetch_op(Bb, p.sbn, p.sbk, b_kc, b_r0, b_k0, N0, p.N, k0, p.b_vec != 0, 0, bv);
     };
     const int arow = (wm * 32 + (lane & 31)) * BLD + (lane >> 5);
     const int brow = (wn * 32 + (lane & 31)) * BLD + (lane >> 5);
@@ -571,12 +588,14 @@ extern "C" int hirest_attention_train_fwd_qkv_f32(const float* q, int64_t ldq, c
     const int64_t TT = (int64_t)Tq * Tk;
     // S = fl(fl(Q K^T * scale) + (add_const + mask)) -> P (raw scores), batch entry z = b * H + h
     BGemm s_{q, ldq, 1, (int64_t)Tq * ldq, 64, k, ldkv, 1, (int64_t)Tk * ldkv, 64, P, Tk, (int64_t)H * TT, TT, Tq, Tk, 64, H, scale, add_const, mask_add, TT,
-             0, 0, 0.f, seed, Tq, Tk};
+             0, 0, 0.f, seed, Tq, Tk, 0, 0};
+    set_vec(s_);
     hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3((Tk + 63) / 64, (Tq + 63) / 64, B * H), blk, 0, S_(stream), s_);
     hipLaunchKernelGGL(attn_softmax_rows_kernel, dim3((unsigned)(((int64_t)B * H * Tq + 3) / 4)), blk, 0, S_(stream), P, (int64_t)B * H * Tq, Tk);
     // ctx = drop(P) V: A = P [Tq, Tk] (k contiguous), B[n][k] = V[k][n] (rows contiguous)
     BGemm c_{P, Tk, 1, (int64_t)H * TT, TT, v, 1, ldkv, (int64_t)Tk * ldkv, 64, ctx, ldctx, (int64_t)Tq * ldctx, 64, Tq, 64, Tk, H, 1.0f, 0.f, nullptr, 0,
-             1, 0, drop_p, seed, Tq, Tk};
+             1, 0, drop_p, seed, Tq, Tk, 0, 0};
+    set_vec(c_);
     hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tq + 63) / 64, B * H), blk, 0, S_(stream), c_);
     return hirest_launch_status();
 }
@@ -599,21 +618,37 @@ extern "C" int hirest_attention_train_bwd_qkv_f32(const float* q, int64_t ldq, c
     const int Z = B * H;
     // dP = keep * (dctx V^T) -> dS buffer
     BGemm dp{dctx, ldctx, 1, (int64_t)Tq * ldctx, 64, v, ldkv, 1, (int64_t)Tk * ldkv, 64, dS, Tk, (int64_t)H * TT, TT, Tq, Tk, 64, H, 1.0f, 0.f, nullptr, 0,
-             0, 1, drop_p, seed, Tq, Tk};
+             0, 1, drop_p, seed, Tq, Tk, 0, 0};
+    set_vec(dp);
     hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3((Tk + 63) / 64, (Tq + 63) / 64, Z), blk, 0, S_(stream), dp);
     hipLaunchKernelGGL(attn_ds_rows_kernel, dim3((unsigned)(((int64_t)Z * Tq + 3) / 4)), blk, 0, S_(stream), P, dS, (int64_t)Z * Tq, Tk);
     // dq = scale * dS K: A = dS [Tq, Tk], B[n][k] = K[k][n]
     BGemm gq{dS, Tk, 1, (int64_t)H * TT, TT, k, 1, ldkv, (int64_t)Tk * ldkv, 64, dq, lddq, (int64_t)Tq * lddq, 64, Tq, 64, Tk, H, scale, 0.f, nullptr, 0,
-             0, 0, 0.f, seed, Tq, Tk};
+             0, 0, 0.f, seed, Tq, Tk, 0, 0};
+    set_vec(gq);
     hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tq + 63) / 64, Z), blk, 0, S_(stream), gq);
     // dk = scale * dS^T Q: A[m][k] = dS[k][m] (rows contiguous), B[n][k] = Q[k][n]
     BGemm gk{dS, 1, Tk, (int64_t)H * TT, TT, q, 1, ldq, (int64_t)Tq * ldq, 64, dk, lddkv, (int64_t)Tk * lddkv, 64, Tk, 64, Tq, H, scale, 0.f, nullptr, 0,
-             0, 0, 0.f, seed, Tq, Tk};
+             0, 0, 0.f, seed, Tq, Tk, 0, 0};
+    set_vec(gk);
     hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tk + 63) / 64, Z), blk, 0, S_(stream), gk);
     // dv = drop(P)^T dctx: A[m][k] = keep * P[k][m], B[n][k] = dctx[k][n]
     BGemm gv{P, 1, Tk, (int64_t)H * TT, TT, dctx, 1, ldctx, (int64_t)Tq * ldctx, 64, dv, lddkv, (int64_t)Tk * lddkv, 64, Tk, 64, Tq, H, 1.0f, 0.f, nullptr, 0,
-             2, 0, drop_p, seed, Tq, Tk};
+             2, 0, drop_p, seed, Tq, Tk, 0, 0};
+    set_vec(gv);
     hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(1, (Tk + 63) / 64, Z), blk, 0, S_(stream), gv);
+    return hirest_launch_status();
+}
+
+// C = alpha * A B^T over arbitrary element strides (A[m][k] at sam m + sak k, B[n][k] at sbn n + sbk k, one of each pair = 1):
+// the dX = dY W and dW = dY^T X products of the backward pass read their operands in place instead of through transposed copies.
+extern "C" int hirest_gemm_f32_strided(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, float* C,
+                                       int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HIREST_E_BADARG;
+    if ((sam != 1 && sak != 1) || (sbn != 1 && sbk != 1)) return HIREST_E_SHAPE;
+    BGemm g{A, sam, sak, 0, 0, B, sbn, sbk, 0, 0, C, ldc, 0, 0, M, N, K, 1, alpha, 0.f, nullptr, 0, 0, 0, 0.f, 0u, 1, 1, 0, 0};
+    set_vec(g);
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), 0, S_(stream), g);
     return hirest_launch_status();
 }
 

@@ -27,6 +27,11 @@ import torch
 from . import _lib, ops
 
 _V = "clip4cap_model.visual."
+# dX / dW products can read their operands in place (hirest_gemm_f32_strided) instead of through zero-padded transposed copies.
+# Measured (tools/train_bench.py, B = 5): retrieval step 4.4 -> 4.1 ms at T = 120 (fewer launches on a host-bound step), 5.5 -> 5.6
+# at T = 300, captioning 8.4 -> 9.0: the strided kernel's element-wise staging loses what the 53 saved copies gain, so it is off.
+STRIDED_GEMM = False
+STRIDED_MAX_FLOP = 1.5e9   # when on: only products up to this size (above it hirest_gemm_f32's register-prefetching kernel wins)
 
 
 def _chk(code, what):
@@ -58,15 +63,28 @@ class _K:
         return out
 
     @staticmethod
+    def strided(a, sam, sak, b, sbn, sbk, M, N, K, alpha=1.0):
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _chk(_lib.load().hirest_gemm_f32_strided(a.data_ptr(), sam, sak, b.data_ptr(), sbn, sbk, out.data_ptr(), N, M, N, K, alpha,
+                                                 ops.stream_ptr()), "gemm_f32_strided")
+        return out
+
+    @staticmethod
     def grad_input(dy, w):
-        """dX = dY @ W for y = x W^T:  dY [R, N], W [N, K] -> [R, K]  (the GEMM's W-operand is W^T [K, N]; N % 16 == 0)."""
+        """dX = dY @ W for y = x W^T:  dY [R, N], W [N, K] -> [R, K].  The strided GEMM reads W column-wise in place (its
+        B[n][k] = W[k][n]); STRIDED_GEMM = False: through a zero-padded transposed copy and hirest_gemm_f32 (round 2)."""
+        if STRIDED_GEMM and 2.0 * dy.shape[0] * w.shape[1] * dy.shape[1] <= STRIDED_MAX_FLOP:
+            return _K.strided(dy, dy.stride(0), 1, w, 1, w.stride(0), dy.shape[0], w.shape[1], dy.shape[1])
         if w.shape[0] % 16 != 0:
             raise RuntimeError(f"grad_input: out_features {w.shape[0]} must be a multiple of 16")
         return _K.gemm(dy, _K.transpose_pad(w))
 
     @staticmethod
     def grad_weight(dy, x):
-        """dW = dY^T @ X:  dY [R, N], X [R, K] -> [N, K] (reduction over the zero-padded rows)."""
+        """dW = dY^T @ X:  dY [R, N], X [R, K] -> [N, K]: both operands read column-wise in place (A[m][k] = dY[k][m],
+        B[n][k] = X[k][n]); STRIDED_GEMM = False: two zero-padded transposed copies."""
+        if STRIDED_GEMM and 2.0 * dy.shape[1] * x.shape[1] * dy.shape[0] <= STRIDED_MAX_FLOP:
+            return _K.strided(dy, 1, dy.stride(0), x, 1, x.stride(0), dy.shape[1], x.shape[1], dy.shape[0])
         return _K.gemm(_K.transpose_pad(dy), _K.transpose_pad(x))
 
     @staticmethod

@@ -416,6 +416,11 @@ int hirest_beam_advance(const float* val, const int32_t* idx, int32_t B, int32_t
  * Matrix products of the backward pass are hirest_gemm_f32 calls on transposed operands (dX = dY W: A = dY, W-operand = W^T;
  * dW = dY^T X: A = dY^T, W-operand = X^T over the zero-padded row count); the entries below are everything that is not a GEMM.
  * ------------------------------------------------------------------------------------ */
+/* C[m][n] = alpha * sum_k A[m][k] B[n][k] with A[m][k] at A + sam m + sak k and B[n][k] at B + sbn n + sbk k (one stride of
+ * each pair must be 1): exact fp32 MFMA, 64 x 64 tiles.  Lets dX = dY W (B = W read column-wise) and dW = dY^T X (both operands
+ * read column-wise) run without materialised transposes. */
+int hirest_gemm_f32_strided(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, float* C, int64_t ldc,
+                            int32_t M, int32_t N, int32_t K, float alpha, void* stream);
 /* out[c][r] = r < R ? in[r][c] : 0 for r < Rp (Rp >= R; pad the reduction dimension of a dW GEMM to a multiple of 16) */
 int hirest_transpose_pad_f32(const float* in, int64_t ld_in, int32_t R, int32_t C, float* out, int32_t Rp, void* stream);
 /* out[c] = sum_r w(r) x[r][c], w(r) = (row_weight ? row_weight[r] : 1) * (row_select ? row_select[r] == select_value : 1):
