@@ -108,6 +108,8 @@ _SIGNATURES = {
                                         C.c_float, C.c_int32, C.c_void_p]),
     "hirest_attention_bf16_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_fold_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_int32, C.c_void_p]),
     "hirest_patchify": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_void_p]),
     "hirest_rowstats_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

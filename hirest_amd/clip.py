@@ -167,9 +167,10 @@ class CLIP(nn.Module):
         """model.py:358-372: cosine logits scaled by exp(logit_scale)."""
         img = self.encode_image(image)
         txt = self.encode_text(text)
-        img = img / img.norm(dim=-1, keepdim=True)
-        txt = txt / txt.norm(dim=-1, keepdim=True)
-        logits_per_image = self.logit_scale.exp() * img @ txt.t()
+        # F.normalize = the pooling kernel with one row per "video"; logits = exp(logit_scale) * img_n txt_n^T on the fp32 MFMA GEMM
+        img = ops.pool_l2norm(img.float().unsqueeze(1).contiguous())
+        txt = ops.pool_l2norm(txt.float().unsqueeze(1).contiguous())
+        logits_per_image = ops.gemm_f32_strided(img, txt, float(torch.exp(self.logit_scale.detach().float().cpu())))
         return logits_per_image, logits_per_image.transpose(-1, -2)
 
 

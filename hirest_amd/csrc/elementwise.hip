@@ -202,6 +202,30 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
     }
 }
 
+// LayerNorm folded into the Linear that follows it, weight preparation (once per checkpoint; HIREST_EPI_LNFOLD_*):
+//   Wf[n][k] = bf16(W[n][k] * gamma[k]),  s[n] = sum_k float(Wf[n][k]),  b'[n] = b[n] + sum_k W[n][k] * beta[k]
+// One wave per output row n; sums in double (they are one-time and feed every row of every call).
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             bf16_t* __restrict__ Wf, float* __restrict__ bias_out, float* __restrict__ s_out,
+                                                             int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* wr = W + (int64_t)n * K;
+    double ss = 0.0, sb = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float w = wr[k];
+        const bf16_t wf = (bf16_t)(w * gamma[k]);
+        Wf[(int64_t)n * K + k] = wf;
+        ss += (double)(float)wf;
+        sb += (double)w * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); sb += __shfl_xor(sb, o, 64); }
+    if (lane == 0) { s_out[n] = (float)ss; bias_out[n] = (float)((double)(bias ? bias[n] : 0.f) + sb); }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Patch extraction.  One thread produces 8 consecutive k-columns (16 B of bf16) of one patch row.
 // Column k = c*P*P + ph*P + pw (conv weight flatten order, vit_model.py:198).
@@ -381,6 +405,14 @@ extern "C" int hirest_patchify(const void* frames, int32_t in_dtype, int32_t B, 
         case 2: hipLaunchKernelGGL(patchify_kernel<2>, grid, block, 0, s, frames, B, S, P, mean3, std3, o, Kpad); break;
         default: return HIREST_E_BADARG;
     }
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, hirest_bf16* Wf,
+                                     float* bias_out, float* colsum_out, int32_t N, int32_t K, void* stream) {
+    if (!W || !gamma || !beta || !Wf || !bias_out || !colsum_out || N <= 0 || K <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, gamma, beta, bias,
+                       reinterpret_cast<bf16_t*>(Wf), bias_out, colsum_out, N, K);
     return hirest_launch_status();
 }
 

@@ -174,10 +174,17 @@ class VisionTower(_Tower):
 
         def fold(weight, bias, norm):
             """LayerNorm folded into the Linear that follows it (include/hirest_hip.h, HIREST_EPI_LNFOLD_*):
-            LN(x) W^T + b = rstd (x W'^T - mean s) + b',  W' = W gamma (bf16), s = row sums of the bf16 W', b' = b + W beta."""
-            w32 = weight.detach().float()
-            wf = ops.to_bf16((w32 * norm.weight.detach().float()[None, :]).contiguous())
-            return hold(wf), hold((bias + w32 @ norm.bias.detach().float()).contiguous()), hold(wf.float().sum(1).contiguous())
+            LN(x) W^T + b = rstd (x W'^T - mean s) + b',  W' = W gamma (bf16), s = row sums of the bf16 W', b' = b + W beta:
+            one kernel per Linear (hirest_fold_layernorm), once per checkpoint."""
+            w32 = self._f32(weight)
+            N, K = w32.shape
+            wf = torch.empty((N, K), dtype=torch.bfloat16, device=device)
+            bf = torch.empty((N,), dtype=torch.float32, device=device)
+            cs = torch.empty((N,), dtype=torch.float32, device=device)
+            _lib.check(_lib.load().hirest_fold_layernorm(w32.data_ptr(), self._f32(norm.weight).data_ptr(), self._f32(norm.bias).data_ptr(),
+                                                         self._f32(bias).data_ptr(), wf.data_ptr(), bf.data_ptr(), cs.data_ptr(), N, K,
+                                                         ops.stream_ptr()), "hirest_fold_layernorm")
+            return hold(wf), hold(bf), hold(cs)
         for i, b in enumerate(self.blocks):
             qkv_b = torch.cat([b.attn.q_bias.detach().float(), torch.zeros(D, device=device), b.attn.v_bias.detach().float()])
             folded = (None,) * 6

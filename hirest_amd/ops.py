@@ -183,6 +183,17 @@ def similarity(text_n: torch.Tensor, video_n: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gemm_f32_strided(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """alpha * a @ b.T in exact fp32 (hirest_gemm_f32_strided; a [M, K], b [N, K], last dim contiguous)."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(lib.hirest_gemm_f32_strided(_dev(a, torch.float32, "gemm.a"), a.stride(0), 1, _dev(b, torch.float32, "gemm.b"), b.stride(0), 1,
+                                           out.data_ptr(), N, M, N, K, float(alpha), stream_ptr()), "hirest_gemm_f32_strided")
+    return out
+
+
 @on_tensor_device
 def topk(scores: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
     lib = _lib.load()

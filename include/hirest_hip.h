@@ -161,6 +161,10 @@ int hirest_patchify(const void* frames, int32_t in_dtype, int32_t B, int32_t S, 
                     const float* mean3, const float* std3,
                     hirest_bf16* patches, int32_t Kpad, void* stream);
 
+/* Weight preparation of the folded LayerNorm (HIREST_EPI_LNFOLD_*), once per checkpoint:
+ * Wf = bf16(W * gamma) [N, K], colsum_out[n] = sum_k Wf[n][k] (of the rounded values), bias_out = bias + W beta (bias NULL = 0). */
+int hirest_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, hirest_bf16* Wf,
+                          float* bias_out, float* colsum_out, int32_t N, int32_t K, void* stream);
 /* x[b*(P+1)] = cls + pos[0]  for every frame (vit_model.py:330-333, the CLS row). */
 int hirest_write_cls_rows(float* x, int64_t ldx, const float* cls, const float* pos0,
                           int32_t B, int32_t tokens_per_frame, int32_t D, void* stream);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Copy what an end-of-round GPU trip (tools/final_round.sh -> gpurun_out/final/) produced into profiles/<round>/ and refuse when it
+# is older than the library it claims to describe: usage  tools/collect_round.sh r03
+r=${1:?round, e.g. r03}; src=gpurun_out/final; dst=profiles/$r; mkdir -p $dst
+lib=hirest_amd/lib/libhirest_hip.so
+newest_src=$(ls -t hirest_amd/csrc/*.hip hirest_amd/csrc/*.h include/*.h | head -1)
+if [ "$src/pmc_traffic.json" -ot "$newest_src" ]; then echo "STALE: $src/pmc_traffic.json is older than $newest_src: re-run tools/final_round.sh"; exit 1; fi
+for f in bench_n1.json bench_under_rocprofv3.json rocprofv3_kernel_stats_bench.csv rocprofv3_kernel_trace_by_shape.csv pmc_traffic.json \
+         pmc_bench_counters.txt pmc_table_bench.md secondary.json; do
+  [ -f $src/$f ] && cp $src/$f $dst/$f
+done
+tail -4 $src/pytest_gpu.log > $dst/pytest_gpu_tail.txt
+echo "collected into $dst:"; ls -la $dst | tail -n +2 | awk '{print "  " $NF, $5}'

@@ -6,7 +6,7 @@ out=${1:-gpurun_out/pmc_traffic.json}
 mkdir -p gpurun_out/pmct; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmct/$c -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-matched-recall > $GRAFT_REPO_ROOT/gpurun_out/pmct/$c.log 2>&1 )
+      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-matched-recall --no-secondary > $GRAFT_REPO_ROOT/gpurun_out/pmct/$c.log 2>&1 )
 done
 python - "$out" <<'PY'
 import csv, glob, collections, json, sys
