@@ -102,6 +102,7 @@ _SIGNATURES = {
     "hirest_gemm_debug_mode": (C.c_int, [C.c_int32]),
     "hirest_gemm_dispatch_name": (C.c_int, [C.POINTER(GemmArgs), C.c_char_p, C.c_int32]),
     "hirest_attention_select_kernel": (C.c_int, [C.c_int32]),
+    "hirest_attention_set_skew": (C.c_int, [C.c_int32]),
     "hirest_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                    C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_attention_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -338,10 +338,13 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 // =================================================================================================
 // NW waves per workgroup: 9 (17 query tiles = 2,2,...,2,1) or 12 (three waves on every SIMD instead of 3/2/2/2: the busiest SIMD
 // still owns 5 tiles, but every SIMD has a third instruction stream to cover softmax VALU and LDS latency with).
+__device__ __forceinline__ void sleep_n(int n) {   // ~64 n cycles
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
 template <int NW, int CPR> struct ROWS_PER_PIECE_OK { static constexpr bool value = (NW * 64 % CPR == 0) && ((NW * 64 / CPR) % 8 == 0); };
 template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9>   // FAST: not causal and N > 16*(NT-1): only the last key tile holds masked keys
 __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                          int N, int H, float scale_log2e, int causal, int dbg_bits, int nq) {
+                                                          int N, int H, float scale_log2e, int causal, int dbg_bits, int nq, int skew) {
     const int dbg = DBG ? dbg_bits : 0;   // timing-experiment switches fold away in the production instantiation
     using C = AttnCfg2<DH, DP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -519,6 +522,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
                 if (qvalid && d < DH) *reinterpret_cast<bf16x8*>(out + ((int64_t)b * N + q) * D + h * DH + d) = w.v;
             }
         };
+        // De-phasing (hirest_attention_set_skew): all waves leave barrier A together and would run S^T (MFMA), softmax (VALU) and P.V
+        // (MFMA) in step, so the second wave of a SIMD competes for the same pipe at every moment and nothing overlaps; parking
+        // it for about one S^T phase puts its MFMA phases under the first wave's softmax and vice versa.
+        if (skew > 0 && wave >= 4 && wave < 8) sleep_n(skew);
         if (wave < nqt) tile(wave, qa);
         if (wave + NW < nqt) tile(wave + NW, qb);
         if (!v_ready) {
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
 }
 
 int g_attn_dbg = 0;   // timing experiments only (hirest_attention_debug_mode)
+int g_attn_skew = 12; // de-phasing of the second wave of each SIMD, in units of ~64 cycles (hirest_attention_set_skew; results unchanged)
 int g_attn_variant = 3;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame, 9 waves; default for N > 80), 4 = v3 with 12 waves
 
 template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9>
@@ -540,7 +548,7 @@ int launch3_impl(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scal
     static HirestDevCfg cfg;
     auto kern = attention_kernel_v3<DH, DP, NT, FAST, DBG, NW>;
     if (int e = hirest_configure(kern, LDS, cfg)) return e;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg, nq);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg, nq, g_attn_skew);
     return hirest_launch_status();
 }
 
@@ -565,6 +573,12 @@ int launch2(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scale, in
 }  // namespace
 
 extern "C" int hirest_attention_debug_mode(int32_t bits) { g_attn_dbg = bits; return 0; }
+
+extern "C" int hirest_attention_set_skew(int32_t units) {
+    if (units < 0 || units > 64) return HIREST_E_BADARG;
+    g_attn_skew = units;
+    return 0;
+}
 
 extern "C" int hirest_attention_select_kernel(int32_t which) {
     if (which < 1 || which > 4) return HIREST_E_BADARG;

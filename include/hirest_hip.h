@@ -146,6 +146,9 @@ int hirest_attention_bf16_rows(const hirest_bf16* qkv, hirest_bf16* out,
  * per (frame, head), 3 (default) = 2's arithmetic in one persistent workgroup per frame (used for 80 < N <= 272 tokens
  * and >= 64 frames; other shapes fall back to 2).  For tests / A-B timing. */
 int hirest_attention_select_kernel(int32_t which);
+/* Persistent kernel: park waves 4-7 (the second wave of each SIMD) for ~64 * units cycles after the per-head barrier, so that
+ * their MFMA phases fall under the first wave's softmax (VALU) phase and vice versa.  0 = off.  Results are unchanged. */
+int hirest_attention_set_skew(int32_t units);
 /* TIMING EXPERIMENTS ONLY (results become wrong), persistent kernel: bit0 skip the S^T MFMAs, bit1 skip the softmax
  * exponentials, bit2 skip P.V, bit3 skip the K/V LDS-DMA.  0 restores normal operation. */
 int hirest_attention_debug_mode(int32_t bits);

@@ -9,6 +9,7 @@ ap.add_argument("--variants", type=int, nargs="*", default=[2, 3])
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--dbg", type=int, nargs="*", default=[0], help="hirest_attention_debug_mode bit sets to time (v3 only)")
+ap.add_argument("--skew", type=int, nargs="*", default=[0], help="hirest_attention_set_skew values to time")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B, N, H, dh = a.frames, 257, 16, 88
@@ -16,8 +17,9 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 qkv = torch.randn((B * N, 3 * H * dh), device=dev, generator=g).to(torch.bfloat16)
 out = torch.empty((B * N, H * dh), device=dev, dtype=torch.bfloat16)
 from hirest_amd import _lib  # noqa: E402
-for v, dbg in [(v, d) for v in a.variants for d in a.dbg]:
+for v, dbg, skew in [(v, d, k) for v in a.variants for d in a.dbg for k in a.skew]:
     _lib.load().hirest_attention_debug_mode(dbg)
+    _lib.load().hirest_attention_set_skew(skew)
     ops.attention_select_kernel(v)
     for _ in range(15):                                   # clocks / power state settle (the first timing in a process reads 10 % high)
         ops.attention(qkv, out, B, N, H, dh, False)
@@ -28,4 +30,4 @@ for v, dbg in [(v, d) for v in a.variants for d in a.dbg]:
         ops.attention(qkv, out, B, N, H, dh, False)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    print(f"attention variant {v} dbg {dbg}: {ms:.3f} ms  {4.0 * B * H * N * N * dh / ms / 1e9:.0f} TFLOP/s (algorithmic)", flush=True)
+    print(f"attention variant {v} dbg {dbg} skew {skew}: {ms:.3f} ms  {4.0 * B * H * N * N * dh / ms / 1e9:.0f} TFLOP/s (algorithmic)", flush=True)
