@@ -1297,7 +1297,6 @@ int launch256(GemmP p, hipStream_t s) {
 
 }  // namespace
 int g_gemm_dbg = 0;
-int hirest_launch_w4(int epi, const void* gemm_p, hipStream_t s, int flags);   // gemm_w4.hip
 int hirest_launch_d2(int epi, const void* gemm_p, hipStream_t s, int flags);   // gemm_d2.hip
 namespace {
 
@@ -1312,7 +1311,6 @@ int launch_fused(const GemmP& p, hipStream_t s) {
     if (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
     GemmP q = p; q.dbg = 0;
     if (g_force_kernel >= 18) return hirest_launch_d2(EPI, &q, s, g_force_kernel - 18);
-    if (g_force_kernel >= 9) return hirest_launch_w4(EPI, &q, s, g_force_kernel - 9);
     if (p.K >= 4096 && g_force_kernel != 6) return launch_pp256<EPI>(q, s);
     return launch_p256_impl<EPI, 64, false>(q, s);
 }
@@ -1327,7 +1325,6 @@ int launch(const GemmP& p, hipStream_t s) {
     if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
     if constexpr (EPI != HIREST_EPI_BIAS_QGELU_BF16 && EPI != HIREST_EPI_PATCH_POS_F32) {
         if (g_force_kernel >= 18 && big) return hirest_launch_d2(EPI, &p, s, g_force_kernel - 18);
-        if (g_force_kernel >= 9 && big) return hirest_launch_w4(EPI, &p, s, g_force_kernel - 9);
     }
     if (g_force_kernel == 8) return launch_pp256<EPI>(p, s);
     if (g_force_kernel == 5) return launch256q<EPI>(p, s);
@@ -1344,9 +1341,10 @@ int launch(const GemmP& p, hipStream_t s) {
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    // 10..15: w4 schedule experiments (9 + FLAGS, plain epilogue); 17: w4 schedule H; 18: d2 (two 256x128 workgroups per CU,
-    // gemm_d2.hip); 19: d2 without its LDS-DMA (timing experiment, plain epilogue)
-    if (which < 0 || which > 20) return HIREST_E_BADARG;   // 20: d2 addressing its operands as if K-blocked (timing experiment)
+    // 18: d2 (two 256x128 workgroups per CU, gemm_d2.hip); 19: d2 without its LDS-DMA (timing experiment, plain epilogue); 20: d2
+    // addressing its operands as if K-blocked (timing experiment).  9..17 were the 4-wave kernel gemm_w4 and its schedule
+    // experiments (round 2; measured 3-7 % slower than p256 / pp256 on every shape, retired in round 3: DESIGN 4.1c, git history).
+    if (which < 0 || which > 20 || (which >= 9 && which <= 17)) return HIREST_E_BADARG;
     g_force_kernel = which;
     return 0;
 }
@@ -1367,10 +1365,6 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (f >= 18 && big && (fused || w4_ok)) {
         snprintf(out, out_len, "gemm_d2<%d, %d>", epi, (f == 19 && epi == HIREST_EPI_BIAS_BF16) ? 1 :
                  (f == 20 && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_RESID_LNSTATS_F32)) ? 2 : 0);
-    } else if (f >= 9 && big && (fused || w4_ok)) {
-        int flags = f - 9;
-        if (flags != 8 && !(flags && epi == HIREST_EPI_BIAS_BF16 && (flags == 1 || flags == 2 || flags == 4 || flags == 6))) flags = 0;
-        snprintf(out, out_len, "gemm_w4<%d, %d>", epi, flags);
     } else if (fused) {
         if (a->K >= 4096 && f != 6) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
         else snprintf(out, out_len, "gemm_p256<%d, 64, false, 1>", epi);

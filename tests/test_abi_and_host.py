@@ -192,6 +192,7 @@ def test_profiled_kernels_are_the_dispatched_ones(lib):
     assert named, "no GEMM kernels found in the newest profile"
     assert named <= dispatched, f"profiled but no longer dispatched: {sorted(named - dispatched)}"
     # selection switches change the answer (the entry point mirrors the dispatch, it is not a constant table)
-    lib.hirest_gemm_select_kernel(17)
-    assert name(Mv, 6144, 1408, _lib.EPI_LNFOLD_GELU_BF16) == "gemm_w4<8, 8>"
+    lib.hirest_gemm_select_kernel(18)
+    assert name(Mv, 6144, 1408, _lib.EPI_LNFOLD_GELU_BF16) == "gemm_d2<8, 0>"
+    assert lib.hirest_gemm_select_kernel(9) != 0 and lib.hirest_gemm_select_kernel(17) != 0      # the retired 4-wave kernel
     lib.hirest_gemm_select_kernel(0)

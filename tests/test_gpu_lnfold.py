@@ -16,9 +16,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[0, 9, 17, 18], ids=["auto", "w4", "w4h", "d2"])
+@pytest.fixture(params=[0, 18], ids=["auto", "d2"])
 def fused_kernel(request):
-    """The LN-fold epilogues exist in the persistent kernels: the default dispatch and the 4-wave kernel (gemm_w4.hip)."""
+    """The LN-fold epilogues exist in the persistent kernels: the default dispatch (p256 / pp256) and the two-workgroup kernel (gemm_d2.hip)."""
     from hirest_amd import ops
     ops.gemm_select_kernel(request.param)
     yield request.param
