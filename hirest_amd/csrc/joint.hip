@@ -27,6 +27,24 @@ struct GemmF {
 
 constexpr int FK = 32, FLD = FK + 1;      // K is staged 32 deep; K itself only has to be a multiple of 16 (zero fill)
 
+// The one epilogue of every fp32 GEMM kernel below (same expressions -> same bits): four consecutive columns n .. n + 3 of row m.
+__device__ __forceinline__ void epilogue_store4(const GemmF& p, f32x4 v, int m, int n) {
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    } else if (p.act == 3) {                      // QuickGELU (model.py:175-177), the fp32 reference-precision towers
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-1.702f * v[e])));
+    }
+    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+    if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
+    *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+}
+
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     __shared__ float As[64 * FLD];
     __shared__ float Ws[64 * FLD];
@@ -98,21 +116,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     for (int g = 0; g < 4; ++g) {
         const int n = N0 + wn * 32 + 8 * g + 4 * (lane >> 5);
         if (n >= p.N) continue;
-        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-        } else if (p.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-        } else if (p.act == 3) {                      // QuickGELU (model.py:175-177), the fp32 reference-precision towers
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-1.702f * v[e])));
-        }
-        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
-        if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
-        *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+        epilogue_store4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, m, n);
     }
 }
 
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
 // LDS, so the result does not depend on timing.
 __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF p) {
     __shared__ float red[3][16][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar loop control
     const int row = lane & 31, khalf = lane >> 5;
     const int M0 = blockIdx.y * 32, N0 = blockIdx.x * 32;
     int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1;
@@ -174,22 +178,139 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF p) {
     for (int g = 0; g < 4; ++g) {
         const int n = N0 + 8 * g + 4 * khalf;
         if (n >= p.N) continue;
-        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-        } else if (p.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-        } else if (p.act == 3) {                      // QuickGELU (model.py:175-177), the fp32 reference-precision towers
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-1.702f * v[e])));
-        }
-        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
-        if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
-        *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+        epilogue_store4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, m, n);
     }
+}
+
+// At most 32 rows (one beam-search step: 5 videos x 3-5 beams).  Two things bound the kernel above there.  (i) ONE dependent chain
+// per wave: v_mfma_f32_32x32x2_f32 retires 2 k per 64 cycles, so a 192-deep K quarter is 6144 cycles, on 24 blocks.
+// v_mfma_f32_16x16x4_f32 adds its four k in slot order as one fused chain (tools/probes/fma_order_probe.hip: bit-identical to the
+// 32x32x2 stream when slots 0..3 carry k0+j, k0+16+j, k0+j+1, k0+16+j+1) at 11 cycles per k, on 16-column tiles: 48-1908 blocks.
+// (ii) lane = row operand loads touch 16-32 cache lines per instruction for 16 B each, and the vector L1 serves about one line per
+// four cycles whatever is used of it: the LM head (94 MB of weights) ran at 1.2-2.3 TB/s.  Here every operand slab (rows x 128 B)
+// goes global -> LDS by LDS-DMA as whole lines (8 rows per wave-instruction) into a WAVE-PRIVATE ring of DEPTH slabs — wave w owns
+// K quarter w of the block's column tiles, so nothing is shared and the loop has no barrier, only counted vmcnt waits — and the
+// fragments are read back with ds_read_b128 (chunk position XOR-swizzled by row pair: conflict-free for the real b128 lane groups).
+// MT row tiles x NT column tiles of 16 per wave; chains are independent, fragments shared.
+template <int MT, int NT, int DEPTH>
+__global__ __launch_bounds__(256) void gemm_f32_m16_kernel(GemmF p) {
+    constexpr int TILES = MT + NT, SLAB = TILES * 2048, L = 2 * TILES;          // bytes per slab, LDS-DMA instructions per slab
+    extern __shared__ __attribute__((aligned(16))) char smem[];                 // 4 waves x DEPTH x SLAB, then the reduction buffer
+    f32x4 (*red)[MT * NT][64] = reinterpret_cast<f32x4 (*)[MT * NT][64]>(smem + 4 * DEPTH * SLAB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar loop control
+    const int idx = lane & 15, slot = lane >> 4;
+    const int N0 = blockIdx.x * 16 * NT;
+    const bool odd = slot >> 1;
+    char* ring = smem + wave * DEPTH * SLAB;
+    auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
+    // LDS-DMA: instruction j of a slab moves rows 8 j .. 8 j + 7 of the stacked tiles (A row tiles first, then W column tiles);
+    // lane = (row r = lane / 8, LDS chunk position q = lane % 8) fetches global chunk q ^ swz(row in its tile)
+    const char* src[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int trow = 8 * (j & 1) + (lane >> 3), tile = j >> 1;
+        const int chunk = (lane & 7) ^ swz(trow);
+        if (tile < MT) {
+            int gm = 16 * tile + trow; gm = gm < p.M ? gm : p.M - 1;
+            src[j] = reinterpret_cast<const char*>(p.A + (int64_t)gm * p.lda) + 16 * chunk;
+        } else {
+            int gn = N0 + 16 * (tile - MT) + trow; gn = gn < p.N ? gn : p.N - 1;
+            src[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * chunk;
+        }
+    }
+    const int nslab = p.K / FK;                                         // K % 32 == 0 (launcher)
+    const int quarter = (nslab + 3) >> 2, first = wave * quarter;      // this wave's K quarter (see gemm_f32_kernel)
+    int cnt = nslab - first; cnt = cnt < 0 ? 0 : (cnt > quarter ? quarter : cnt);
+    auto dma = [&](int s, int ringslot) {                               // slab s of this wave's quarter (clamped: always a valid address)
+        const int64_t koff = (int64_t)(first + (s < cnt ? s : cnt - 1)) * (FK * 4);
+        char* dst = ring + ringslot * SLAB;
+#pragma unroll
+        for (int j = 0; j < L; ++j) glds16(src[j] + koff, dst + j * 1024);
+    };
+    // fragment addresses: row idx of a tile, chunk 4 (slot & 1) + c at position chunk ^ swz(idx)
+    int fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fo[c] = idx * 128 + (((4 * (slot & 1) + c) ^ swz(idx)) << 4);
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mm = [&](int ringslot) {
+        const char* base = ring + ringslot * SLAB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 aq[MT], wq[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) aq[t] = *reinterpret_cast<const f32x4*>(base + t * 2048 + fo[c]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) wq[u] = *reinterpret_cast<const f32x4*>(base + (MT + u) * 2048 + fo[c]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                               // instruction i = 2 c + e: slots carry k0 + 2 i + (slot >> 1) + 16 (slot & 1)
+                float a[MT], w[NT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[t] = odd ? aq[t][2 * e + 1] : aq[t][2 * e];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) w[u] = odd ? wq[u][2 * e + 1] : wq[u][2 * e];
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], a[t], acc[u][t], 0, 0, 0);
+            }
+        }
+    };
+    if (cnt > 0) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) dma(u, u);
+        int rs = 0;                                                     // ring slot of the slab being multiplied
+        for (int s = 0; s < cnt - DEPTH; ++s) {                         // steady state: DEPTH slabs in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * L) : "memory");
+            mm(rs);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot's fragment reads have returned before it is refilled
+            dma(s + DEPTH, rs);
+            rs = rs + 1 == DEPTH ? 0 : rs + 1;
+        }
+        const int base = cnt > DEPTH ? cnt - DEPTH : 0;                 // drain: DEPTH slabs outstanding, the first cnt - base of them wanted
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (base + u < cnt) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1 - u) * L) : "memory");
+                mm(rs);
+                rs = rs + 1 == DEPTH ? 0 : rs + 1;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (clamped duplicates of a short quarter)
+    if (wave > 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) red[wave - 1][u * MT + t][lane] = acc[u][t];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int n = N0 + 16 * u + 4 * slot;                           // D: column (row m of the output) = lane % 16, rows n = 4 (lane / 16) + r
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = 16 * t + idx;
+            if (m >= p.M) continue;
+            epilogue_store4(p, ((acc[u][t] + red[0][u * MT + t][lane]) + red[1][u * MT + t][lane]) + red[2][u * MT + t][lane], m, n);
+        }
+    }
+}
+
+template <int MT, int NT, int DEPTH>
+int launch_m16(const GemmF& p, hipStream_t s) {
+    static HirestDevCfg cfg;
+    auto kern = gemm_f32_m16_kernel<MT, NT, DEPTH>;
+    constexpr int LDS = 4 * DEPTH * (MT + NT) * 2048 + 3 * MT * NT * 1024;
+    static_assert(LDS <= 160 * 1024, "ring does not fit the LDS");
+    if (int e = hirest_configure(kern, LDS, cfg)) return e;
+    hipLaunchKernelGGL(kern, dim3((p.N + 16 * NT - 1) / (16 * NT)), dim3(256), LDS, s, p);
+    return hirest_launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,10 +636,12 @@ inline int grid1d(int64_t total, int cap = 4096) { int64_t g = (total + 255) / 2
 
 }  // namespace
 
-static bool g_f32_skinny = true;   // hirest_gemm_f32_select_kernel: A/B and tests
-extern "C" int hirest_gemm_f32_select_kernel(int32_t which) {   // 0 automatic (skinny for M <= 256), 1 always the 64x64 kernel
-    if (which < 0 || which > 1) return HIREST_E_BADARG;
-    g_f32_skinny = which == 0;
+static int g_f32_kernel = 0;       // hirest_gemm_f32_select_kernel: A/B and tests
+// 0 automatic (16-column kernel for M <= 32, split-K 32x32 kernel for M <= 256), 1 always the 64x64 kernel, 2 automatic without the
+// 16-column kernel
+extern "C" int hirest_gemm_f32_select_kernel(int32_t which) {
+    if (which < 0 || which > 2) return HIREST_E_BADARG;
+    g_f32_kernel = which;
     return 0;
 }
 
@@ -528,7 +651,13 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
-    if (M <= 256 && g_f32_skinny) {
+    if (M <= 32 && K % FK == 0 && g_f32_kernel == 0) {
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const bool wide = N >= 8192;                          // LM head: two column tiles per wave halve the re-reads of A
+        if (M <= 16) return wide ? launch_m16<1, 2, 6>(p, s) : launch_m16<1, 1, 8>(p, s);
+        return wide ? launch_m16<2, 2, 4>(p, s) : launch_m16<2, 1, 6>(p, s);
+    }
+    if (M <= 256 && g_f32_kernel != 1) {
         hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
         return hirest_launch_status();
     }

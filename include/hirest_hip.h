@@ -345,8 +345,9 @@ int hirest_text_forward_f32(const hirest_text_tower_f32* t, const int64_t* token
 int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                     const float* resid, int64_t ldr, const float* periodic, int32_t period,
                     float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
-/* 0 = automatic (problems of M <= 256 rows take the split-K "skinny" kernel: 32x32 tiles, four waves share K), 1 = always the
- * 64x64 kernel.  Both are exact fp32 MFMA; they differ in summation order only (tests / A-B timing). */
+/* 0 = automatic (M <= 32 rows and K % 32 == 0: 16-column tiles of v_mfma_f32_16x16x4_f32, four waves share K; M <= 256: the
+ * split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the 64x64 kernel, 2 = automatic without the 16-column
+ * kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */
 int hirest_gemm_f32_select_kernel(int32_t which);
 /* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*64]; no key masking (the
  * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3). */

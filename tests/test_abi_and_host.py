@@ -55,7 +55,7 @@ def test_argument_errors_without_gpu(lib):
     assert lib.hirest_attention_f32_varlen(None, None, None, 1, 1, 12, 64, 0.125, 0.0, None) == -1
     assert lib.hirest_pool_l2norm_varlen(None, None, None, 1, 384, None) == -1
     assert lib.hirest_embedding_pos_fwd_f32(None, None, None, None, None, 1, 384, None) == -1
-    assert lib.hirest_gemm_f32_select_kernel(2) == -1 and lib.hirest_gemm_f32_select_kernel(0) == 0
+    assert lib.hirest_gemm_f32_select_kernel(3) == -1 and lib.hirest_gemm_f32_select_kernel(0) == 0
 
 
 def test_workspace_size_formula(lib):

@@ -21,11 +21,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "64x64"])
+@pytest.mark.parametrize("kernel", [0, 1, 2], ids=["auto", "64x64", "auto-no-m16"])
 @pytest.mark.parametrize("M,N,K,act", [(64, 64, 16, 0), (193, 768, 768, 1), (300, 2304, 768, 0), (77, 512, 1024, 2), (130, 768, 3072, 0),
-                                       (25, 30528, 768, 0), (5, 768, 768, 1), (256, 100, 1504, 0), (33, 36, 48, 2)])
+                                       (25, 30528, 768, 0), (5, 768, 768, 1), (256, 100, 1504, 0), (33, 36, 48, 2), (15, 2304, 768, 3),
+                                       (32, 20, 64, 0), (17, 768, 3072, 1)])
 def test_gemm_f32(dev, M, N, K, act, kernel):
-    """M <= 256 takes the split-K 32x32 kernel in automatic mode, the 64x64 kernel otherwise / when forced"""
+    """automatic mode: M <= 32 takes the 16-column kernel (K % 32 == 0), M <= 256 the split-K 32x32 kernel, the rest the 64x64
+    kernel; mode 1 forces the 64x64 kernel, mode 2 is automatic without the 16-column kernel"""
     from hirest_amd import _lib
     from hirest_amd.moment_model import MomentModel
     _lib.check(_lib.load().hirest_gemm_f32_select_kernel(kernel), "select")
@@ -55,16 +57,17 @@ def test_gemm_f32_kernels_share_their_summation_order(dev):
     from hirest_amd import _lib
     from hirest_amd.moment_model import MomentModel
     lib = _lib.load()
-    for M, N, K in ((200, 768, 768), (25, 30528, 768), (256, 132, 3072), (77, 512, 1040)):
+    for M, N, K in ((200, 768, 768), (25, 30528, 768), (256, 132, 3072), (77, 512, 1040), (25, 768, 3072), (15, 2304, 768), (9, 36, 64),
+                    (32, 3072, 768), (16, 768, 96)):
         a = synth.tensor("jo.a", (M, K), 1.0, 2).to(dev)
         w = synth.tensor("jo.w", (N, K), 0.05, 2).to(dev)
         b = synth.tensor("jo.b", (N,), 0.3, 2).to(dev)
         outs = []
-        for kernel in (0, 1):
+        for kernel in (0, 1, 2):
             _lib.check(lib.hirest_gemm_f32_select_kernel(kernel), "select")
             outs.append(MomentModel._gemm(a, w, b, act=1))
         lib.hirest_gemm_f32_select_kernel(0)
-        assert torch.equal(outs[0], outs[1]), (M, N, K)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, N, K)
         big = torch.cat([a, a, a], 0)                              # 3 M > 256 rows: the 64x64 kernel in automatic mode
         if 3 * M > 256:
             assert torch.equal(MomentModel._gemm(big, w, b, act=1)[M:2 * M], outs[0]), (M, N, K)
@@ -81,6 +84,8 @@ def _gemm_f32_case(dev, M, N, K, act, MomentModel):
         ref = torch.nn.functional.gelu(ref)
     elif act == 2:
         ref = torch.tanh(ref)
+    elif act == 3:
+        ref = ref * torch.sigmoid(1.702 * ref)
     ref = ref + r.double() + pos.double()[torch.arange(M) % 50]
     out = MomentModel._gemm(a.to(dev), w.to(dev), b.to(dev), resid=r.to(dev), periodic=pos.to(dev), period=50, act=act)
     assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
