@@ -142,6 +142,13 @@ _SIGNATURES = {
     "hirest_caption_decode_step": (C.c_int, [C.POINTER(CaptionDecoder), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hirest_caption_decode_logits": (C.c_int, [C.POINTER(CaptionDecoder), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hirest_caption_beam_tail_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "hirest_caption_beam_tail": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hirest_attention_f32_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                               C.c_float, C.c_void_p]),
     "hirest_log_softmax_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

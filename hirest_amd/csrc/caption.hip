@@ -68,6 +68,175 @@ __global__ void beam_advance_kernel(const float* __restrict__ val, const int32_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tail of a beam-search step in two kernels (it used to be log-softmax, chunked top-k, merge, beam bookkeeping and a copy of
+// the done flags: 51 us of 270 per word).  Only the top `beam` of a sample's beam x vocabulary scores are ever read, so the
+// log-probabilities are not materialised.  tail_scan, grid (nsel + 4, rows): blocks c < nsel pick the top `beam` LOGITS of their
+// 4096-element chunk of a row (higher logit, then higher index: within a row the score is a monotone function of the logit);
+// blocks nsel + g, g < 4, produce the row's max and four of the sixteen partial exp sums of log_softmax_kernel — that kernel's 1024
+// threads are split over the four blocks thread for thread, so the log-sum-exp tail_select forms from them has the same bits.
+// tail_select, one block per sample: score = ((x - max) - lse) + row_add of the beam x nsel x beam candidates, their top `beam`
+// under topk_kernel's strict order (higher score, then higher flat index), then beam_advance_kernel's bookkeeping; the done flag
+// also goes to pinned host memory when asked to.  Equal to the separate kernels unless two of a row's leading logits round to
+// one score (the separate kernels then order the two by index, this one by logit).
+// ---------------------------------------------------------------------------------------------
+constexpr int TAIL_CHUNK = 4096, TAIL_STAT = 17;            // floats of statistics per row: 16 partial sums + the max
+__device__ __forceinline__ bool tail_better(float sa, int ta, float sb, int tb) { return sa > sb || (sa == sb && ta > tb); }
+
+// top k of (val, idx) pairs held 16 per thread by a 256-thread block; thread 0 reports pick j through put(j, val, idx)
+template <class Put>
+__device__ __forceinline__ void block_topk16(const float (&val)[16], const int (&idx)[16], int k, Put put) {
+    __shared__ float rs[4];
+    __shared__ int ri[4];
+    __shared__ float ps; __shared__ int pi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float prev_s = INFINITY; int prev_i = 0x7fffffff;
+    for (int j = 0; j < k; ++j) {
+        float bs = -INFINITY; int bi = -1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool take = idx[e] >= 0 && tail_better(prev_s, prev_i, val[e], idx[e]) && (bi < 0 || tail_better(val[e], idx[e], bs, bi));
+            bs = take ? val[e] : bs; bi = take ? idx[e] : bi;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            const bool take = oi >= 0 && (bi < 0 || tail_better(os, oi, bs, bi));
+            bs = take ? os : bs; bi = take ? oi : bi;
+        }
+        if (lane == 0) { rs[wave] = bs; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float sb = rs[0]; int ib = ri[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const bool take = ri[w] >= 0 && (ib < 0 || tail_better(rs[w], ri[w], sb, ib));
+                sb = take ? rs[w] : sb; ib = take ? ri[w] : ib;
+            }
+            put(j, sb, ib);                                  // ib < 0: fewer than j + 1 elements
+            ps = sb; pi = ib;
+        }
+        __syncthreads();
+        prev_s = ps; prev_i = pi;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict__ x, int64_t ldx, int V, int beam, int nsel,
+                                                       float* __restrict__ cx, int32_t* __restrict__ ci, float* __restrict__ stat) {
+    const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (int64_t)r * ldx;
+    const int V4 = V >> 2;
+    if (c < nsel) {
+        float val[16];
+        int idx[16];
+        const int flat0 = (r % beam) * V;                   // flat index inside the sample's beam x vocabulary row
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = c * (TAIL_CHUNK / 4) + tid + 256 * u;
+            const bool in = i < V4;
+            const f32x4 v = in ? *reinterpret_cast<const f32x4*>(xr + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { val[4 * u + e] = v[e]; idx[4 * u + e] = in ? flat0 + 4 * i + e : -1; }
+        }
+        const int64_t ob = ((int64_t)r * nsel + c) * beam;
+        block_topk16(val, idx, beam, [&](int j, float sv, int iv) { cx[ob + j] = sv; ci[ob + j] = iv; });
+        return;
+    }
+    // statistics block g: log_softmax_kernel's thread T = 256 g + tid (wave 4 g + wave) adds vectors T, T + 1024, ...
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int g = c - nsel;
+    constexpr int NM = 32;                                   // vectors per thread for the row max: V <= 32768 (launcher)
+    float mx = -INFINITY;
+    f32x4 mine[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * g + 1024 * j;
+        mine[j] = i < V4 ? *reinterpret_cast<const f32x4*>(xr + 4 * i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int i = tid + 256 * m;
+        if (i < V4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+            mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    mx = bc;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (tid + 256 * g + 1024 * j < V4)
+            s += (expf(mine[j][0] - mx) + expf(mine[j][1] - mx)) + (expf(mine[j][2] - mx) + expf(mine[j][3] - mx));
+    s = wave_sum(s);
+    if (lane == 0) stat[(int64_t)r * TAIL_STAT + 4 * g + wave] = s;
+    if (g == 0 && tid == 0) stat[(int64_t)r * TAIL_STAT + 16] = mx;
+}
+
+// one block per sample: scores of its beam x nsel x beam candidates, their top `beam`, then beam_advance_kernel's bookkeeping
+__global__ __launch_bounds__(256) void tail_select_kernel(const float* __restrict__ cx, const int32_t* __restrict__ ci,
+                                                         const float* __restrict__ stat, const float* __restrict__ row_add, int nsel,
+                                                         int beam, int vocab, int step, int max_steps, int eos, float* __restrict__ scores,
+                                                         int32_t* __restrict__ tokens, int32_t* __restrict__ backptr,
+                                                         int32_t* __restrict__ n_steps, int32_t* __restrict__ done,
+                                                         int32_t* __restrict__ next_ids, int32_t* __restrict__ next_parents,
+                                                         float* __restrict__ next_add, int32_t* __restrict__ done_host) {
+    __shared__ float top_s[16];
+    __shared__ int top_i[16];
+    __shared__ float row_mx[16], row_lse[16], row_ad[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (done[b] != 0) {                                      // (block-uniform: written only by this block, in an earlier launch)
+        if (tid < beam) { const int row = b * beam + tid; next_ids[row] = eos; next_parents[row] = row; next_add[row] = 0.f; }
+        if (tid == 0 && done_host) done_host[b] = 1;
+        return;
+    }
+    if (tid < beam) {
+        const float* st = stat + (int64_t)(b * beam + tid) * TAIL_STAT;
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += st[w];            // log_softmax_kernel's fixed order
+        row_lse[tid] = logf(t); row_mx[tid] = st[16]; row_ad[tid] = row_add[b * beam + tid];
+    }
+    __syncthreads();
+    const int per_row = nsel * beam, ncand = beam * per_row;  // <= 16 * 8 * 16 = 2048 = 8 per thread; 16 slots
+    float val[16];
+    int idx[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int v = tid + 256 * u;
+        int iv = -1; float sv = 0.f;
+        if (v < ncand) {
+            iv = ci[(int64_t)b * ncand + v];
+            const int rr = v / per_row;
+            sv = ((cx[(int64_t)b * ncand + v] - row_mx[rr]) - row_lse[rr]) + row_ad[rr];
+        }
+        val[u] = sv; idx[u] = iv;
+    }
+    block_topk16(val, idx, beam, [&](int j, float sv, int iv) { top_s[j] = sv; top_i[j] = iv; });
+    if (tid < beam) {                                        // beam_advance_kernel, thread k = beam k
+        const int k = tid, row = b * beam + k;
+        const int flat = top_i[k];
+        const int prev = flat / vocab, word = flat - prev * vocab;
+        const float v = top_s[k];
+        scores[row] = v;
+        tokens[((int64_t)b * max_steps + step) * beam + k] = word;
+        backptr[((int64_t)b * max_steps + step) * beam + k] = prev;
+        next_ids[row] = word; next_parents[row] = b * beam + prev; next_add[row] = v;
+        if (k == 0) {
+            n_steps[b] = step + 1;
+            const int fin = word == eos ? 1 : 0;
+            if (fin) done[b] = 1;                            // read by the NEXT launch only
+            if (done_host) done_host[b] = fin;
+        }
+    }
+}
+
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws { size_t x, qkv, ctx, a, b, mid, logits, pos, total; };
@@ -95,11 +264,12 @@ extern "C" size_t hirest_caption_step_workspace_bytes(const hirest_caption_decod
 
 #define CK(call) do { if (int e_ = (call)) return e_; } while (0)
 
-extern "C" int hirest_caption_decode_step(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
-                                          const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
-                                          const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
-    if (!d || !d->layer || !last_ids || !kv_out || !enc_kv || !logp || !workspace || R <= 0 || F <= 0) return HIREST_E_BADARG;
+// logp != NULL: log_softmax + row_add into logp; logits_out != NULL: the raw LM-head logits there instead (hirest_caption_beam_tail)
+static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
+                       const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
+                       const float* const* enc_kv, int32_t F, const float* row_add, float* logp, float* logits_out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !d->layer || !last_ids || !kv_out || !enc_kv || (!logp && !logits_out) || !workspace || R <= 0 || F <= 0) return HIREST_E_BADARG;
     if (position < 0 || position >= d->max_pos || (position > 0 && (!kv_in || !parent_rows))) return HIREST_E_BADARG;
     const int D = d->hidden, H = d->heads;
     if (D % H != 0 || D / H != 64 || D % 4 != 0 || d->vocab_padded % 4 != 0) return HIREST_E_SHAPE;
@@ -112,7 +282,7 @@ extern "C" int hirest_caption_decode_step(const hirest_caption_decoder* d, int32
     float* a = reinterpret_cast<float*>(base + w.a);
     float* b = reinterpret_cast<float*>(base + w.b);
     float* mid = reinterpret_cast<float*>(base + w.mid);
-    float* logits = reinterpret_cast<float*>(base + w.logits);
+    float* logits = logits_out ? logits_out : reinterpret_cast<float*>(base + w.logits);
     int32_t* pos = reinterpret_cast<int32_t*>(base + w.pos);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const float eps = 1e-12f, scale = 0.125f;            // BertLayerNorm eps; 1 / sqrt(64)
@@ -145,10 +315,54 @@ extern "C" int hirest_caption_decode_step(const hirest_caption_decoder* d, int32
     CK(hirest_gemm_f32(x, D, d->tr_w, D, d->tr_b, nullptr, 0, nullptr, 0, a, D, R, D, D, 1, stream));
     CK(hirest_layernorm(a, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
     CK(hirest_gemm_f32(b, D, d->lm_w, D, d->lm_b, nullptr, 0, nullptr, 0, logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
-    CK(hirest_log_softmax_f32(logits, d->vocab_padded, row_add, logp, d->vocab_padded, R, d->vocab_padded, stream));
+    if (logp) CK(hirest_log_softmax_f32(logits, d->vocab_padded, row_add, logp, d->vocab_padded, R, d->vocab_padded, stream));
     return hirest_launch_status();
 }
 
+extern "C" int hirest_caption_decode_step(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
+                                          const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
+                                          const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!logp) return HIREST_E_BADARG;
+    return decode_step(d, R, position, last_ids, parent_rows, kv_in, kv_out, enc_kv, F, row_add, logp, nullptr, workspace, workspace_bytes,
+                       stream);
+}
+
+extern "C" int hirest_caption_decode_logits(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
+                                            const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
+                                            const float* const* enc_kv, int32_t F, float* logits, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    if (!logits) return HIREST_E_BADARG;
+    return decode_step(d, R, position, last_ids, parent_rows, kv_in, kv_out, enc_kv, F, nullptr, nullptr, logits, workspace,
+                       workspace_bytes, stream);
+}
+
+extern "C" size_t hirest_caption_beam_tail_workspace_bytes(int32_t B, int32_t beam, int32_t vocab) {
+    if (B <= 0 || beam <= 0 || vocab <= 0) return 0;
+    const size_t nsel = ((size_t)vocab + TAIL_CHUNK - 1) / TAIL_CHUNK, R = (size_t)B * beam;
+    return R * nsel * beam * 8 + R * TAIL_STAT * 4;
+}
+
+extern "C" int hirest_caption_beam_tail(const float* logits, int64_t ldx, const float* row_add, int32_t B, int32_t beam, int32_t vocab,
+                                        int32_t step, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens,
+                                        int32_t* backptr, int32_t* n_steps, int32_t* done, int32_t* next_ids, int32_t* next_parents,
+                                        float* next_add, int32_t* done_host, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!logits || !row_add || !scores || !tokens || !backptr || !n_steps || !done || !next_ids || !next_parents || !next_add || !workspace)
+        return HIREST_E_BADARG;
+    if (B <= 0 || beam <= 0 || beam > 16 || vocab <= 0 || step < 0 || step >= max_steps) return HIREST_E_BADARG;
+    if (vocab % 4 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(logits) & 15) != 0 || beam > vocab || vocab > 32768) return HIREST_E_SHAPE;
+    if (workspace_bytes < hirest_caption_beam_tail_workspace_bytes(B, beam, vocab)) return HIREST_E_WORKSPACE;
+    const int nsel = (vocab + TAIL_CHUNK - 1) / TAIL_CHUNK;
+    const int64_t n = (int64_t)B * beam * nsel * beam;
+    float* cx = reinterpret_cast<float*>(workspace);
+    int32_t* ci = reinterpret_cast<int32_t*>(cx + n);
+    float* stat = reinterpret_cast<float*>(ci + n);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(tail_scan_kernel, dim3(nsel + 4, B * beam), dim3(256), 0, s, logits, ldx, vocab, beam, nsel, cx, ci, stat);
+    hipLaunchKernelGGL(tail_select_kernel, dim3(B), dim3(256), 0, s, cx, ci, stat, row_add, nsel, beam, vocab, step, max_steps, eos_id,
+                       scores, tokens, backptr, n_steps, done, next_ids, next_parents, next_add, done_host);
+    return hirest_launch_status();
+}
 extern "C" int hirest_beam_advance(const float* val, const int32_t* idx, int32_t B, int32_t beam, int32_t vocab, int32_t step,
                                    int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr, int32_t* n_steps,
                                    int32_t* done, int32_t* next_ids, int32_t* next_parents, float* next_add, void* stream) {

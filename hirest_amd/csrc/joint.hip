@@ -7,6 +7,7 @@
 // (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, 1/16 of the bf16 rate) — at 10-90 GFLOP per video the
 // whole model is still a few hundred microseconds.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_f32_m16_kernel(GemmF p) {
     f32x4 (*red)[MT * NT][64] = reinterpret_cast<f32x4 (*)[MT * NT][64]>(smem + 4 * DEPTH * SLAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar loop control
     const int idx = lane & 15, slot = lane >> 4;
-    const int N0 = blockIdx.x * 16 * NT;
+    const int N0 = blockIdx.x * 16 * NT, M0 = blockIdx.y * 16 * MT;
     const bool odd = slot >> 1;
     char* ring = smem + wave * DEPTH * SLAB;
     auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_f32_m16_kernel(GemmF p) {
         const int trow = 8 * (j & 1) + (lane >> 3), tile = j >> 1;
         const int chunk = (lane & 7) ^ swz(trow);
         if (tile < MT) {
-            int gm = 16 * tile + trow; gm = gm < p.M ? gm : p.M - 1;
+            int gm = M0 + 16 * tile + trow; gm = gm < p.M ? gm : p.M - 1;
             src[j] = reinterpret_cast<const char*>(p.A + (int64_t)gm * p.lda) + 16 * chunk;
         } else {
             int gn = N0 + 16 * (tile - MT) + trow; gn = gn < p.N ? gn : p.N - 1;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_f32_m16_kernel(GemmF p) {
         if (n >= p.N) continue;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const int m = 16 * t + idx;
+            const int m = M0 + 16 * t + idx;
             if (m >= p.M) continue;
             epilogue_store4(p, ((acc[u][t] + red[0][u * MT + t][lane]) + red[1][u * MT + t][lane]) + red[2][u * MT + t][lane], m, n);
         }
@@ -309,7 +310,7 @@ int launch_m16(const GemmF& p, hipStream_t s) {
     constexpr int LDS = 4 * DEPTH * (MT + NT) * 2048 + 3 * MT * NT * 1024;
     static_assert(LDS <= 160 * 1024, "ring does not fit the LDS");
     if (int e = hirest_configure(kern, LDS, cfg)) return e;
-    hipLaunchKernelGGL(kern, dim3((p.N + 16 * NT - 1) / (16 * NT)), dim3(256), LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3((p.N + 16 * NT - 1) / (16 * NT), (p.M + 16 * MT - 1) / (16 * MT)), dim3(256), LDS, s, p);
     return hirest_launch_status();
 }
 
@@ -653,9 +654,21 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
     if (M <= 32 && K % FK == 0 && g_f32_kernel == 0) {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        const bool wide = N >= 8192;                          // LM head: two column tiles per wave halve the re-reads of A
-        if (M <= 16) return wide ? launch_m16<1, 2, 6>(p, s) : launch_m16<1, 1, 8>(p, s);
-        return wide ? launch_m16<2, 2, 4>(p, s) : launch_m16<2, 1, 6>(p, s);
+        // few column tiles (the decoder's 768- / 3072-wide layers): one row tile per block, so 2 x N / 16 blocks share the
+        // operand traffic; LM head: both row tiles and two column tiles per wave halve the re-reads of A
+        static const int v_mid = getenv("HIREST_M16_MID") ? atoi(getenv("HIREST_M16_MID")) : 0;     // tuning experiments
+        static const int v_lm = getenv("HIREST_M16_LM") ? atoi(getenv("HIREST_M16_LM")) : 0;
+        if (N < 2048) return launch_m16<1, 1, 8>(p, s);
+        if (N < 8192) {
+            if (v_mid == 1) return launch_m16<1, 1, 8>(p, s);
+            if (v_mid == 2) return launch_m16<1, 2, 6>(p, s);
+            if (v_mid == 3) return launch_m16<1, 2, 3>(p, s);
+            return launch_m16<1, 1, 3>(p, s);
+        }
+        if (M <= 16) return launch_m16<1, 2, 6>(p, s);
+        if (v_lm == 1) return launch_m16<2, 2, 4>(p, s);
+        if (v_lm == 2) return launch_m16<2, 1, 3>(p, s);
+        return launch_m16<2, 2, 2>(p, s);
     }
     if (M <= 256 && g_f32_kernel != 1) {
         hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);

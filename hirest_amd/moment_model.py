@@ -543,18 +543,33 @@ class MomentModel(nn.Module):
         val = torch.empty((B, num_beams), dtype=torch.float32, device=dev)
         idx = torch.empty((B, num_beams), dtype=torch.int32, device=dev)
         st = ops.stream_ptr()
+        fused_tail = bool(getattr(self, "caption_fused_tail", True)) and num_beams <= 16
+        if fused_tail:
+            tail_ws = torch.empty(max(int(lib.hirest_caption_beam_tail_workspace_bytes(B, num_beams, Vp)), 16), dtype=torch.uint8,
+                                  device=dev)
         for t in range(1, max_words + 1):
-            _lib.check(lib.hirest_caption_decode_step(
-                C.byref(desc), R, t - 1, ids.data_ptr(), parents.data_ptr() if t > 1 else None,
-                ptrs[t & 1] if t > 1 else None, ptrs[(t + 1) & 1], enc_ptrs, F, add.data_ptr(), logp.data_ptr(),
-                ws.data_ptr(), ws.numel(), st), "hirest_caption_decode_step")
-            _lib.check(lib.hirest_topk_f32_ws(logp.data_ptr(), None, B, num_beams * Vp, num_beams, idx.data_ptr(), val.data_ptr(),
-                                              tk_ws.data_ptr(), tk_ws.numel(), st), "hirest_topk_f32_ws")
-            _lib.check(lib.hirest_beam_advance(val.data_ptr(), idx.data_ptr(), B, num_beams, Vp, t - 1, max_words, EOS_ID,
-                                               scores.data_ptr(), tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(),
-                                               done.data_ptr(), ids.data_ptr(), parents.data_ptr(), add.data_ptr(), st),
-                       "hirest_beam_advance")
-            done_host[t - 1].copy_(done, non_blocking=True)
+            if fused_tail:
+                # LM-head logits, then log-softmax + beam score + top-k + bookkeeping + the done flags to pinned memory: 2 kernels
+                _lib.check(lib.hirest_caption_decode_logits(
+                    C.byref(desc), R, t - 1, ids.data_ptr(), parents.data_ptr() if t > 1 else None,
+                    ptrs[t & 1] if t > 1 else None, ptrs[(t + 1) & 1], enc_ptrs, F, logp.data_ptr(),
+                    ws.data_ptr(), ws.numel(), st), "hirest_caption_decode_logits")
+                _lib.check(lib.hirest_caption_beam_tail(
+                    logp.data_ptr(), Vp, add.data_ptr(), B, num_beams, Vp, t - 1, max_words, EOS_ID, scores.data_ptr(),
+                    tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(), done.data_ptr(), ids.data_ptr(), parents.data_ptr(),
+                    add.data_ptr(), done_host[t - 1].data_ptr(), tail_ws.data_ptr(), tail_ws.numel(), st), "hirest_caption_beam_tail")
+            else:
+                _lib.check(lib.hirest_caption_decode_step(
+                    C.byref(desc), R, t - 1, ids.data_ptr(), parents.data_ptr() if t > 1 else None,
+                    ptrs[t & 1] if t > 1 else None, ptrs[(t + 1) & 1], enc_ptrs, F, add.data_ptr(), logp.data_ptr(),
+                    ws.data_ptr(), ws.numel(), st), "hirest_caption_decode_step")
+                _lib.check(lib.hirest_topk_f32_ws(logp.data_ptr(), None, B, num_beams * Vp, num_beams, idx.data_ptr(), val.data_ptr(),
+                                                  tk_ws.data_ptr(), tk_ws.numel(), st), "hirest_topk_f32_ws")
+                _lib.check(lib.hirest_beam_advance(val.data_ptr(), idx.data_ptr(), B, num_beams, Vp, t - 1, max_words, EOS_ID,
+                                                   scores.data_ptr(), tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(),
+                                                   done.data_ptr(), ids.data_ptr(), parents.data_ptr(), add.data_ptr(), st),
+                           "hirest_beam_advance")
+                done_host[t - 1].copy_(done, non_blocking=True)
             copied[t - 1].record()
             if t >= 3:                                   # look at the flags of two steps ago: never waits for the GPU
                 copied[t - 3].synchronize()

@@ -411,6 +411,22 @@ int hirest_caption_decode_step(const hirest_caption_decoder* d, int32_t R, int32
                                const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same step up to the LM head: raw logits [R, vocab_padded] instead of log-probabilities (input of hirest_caption_beam_tail). */
+int hirest_caption_decode_logits(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
+                                 const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
+                                 const float* const* enc_kv, int32_t F, float* logits, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+/* The rest of a beam-search step in two kernels: log_softmax(logits) + row_add (train.py:563-564, beam.py:76; same bits as
+ * hirest_log_softmax_f32), the top `beam` of every sample's beam x vocab scores (same strict order as hirest_topk_f32: higher
+ * score, then higher flat index) and hirest_beam_advance's bookkeeping — without materialising the log-probabilities.  logits:
+ * [B * beam, vocab] with row stride ldx, 16-byte aligned, vocab % 4 == 0, beam <= 16.  done_host (optional): pinned host int32 [B]
+ * that receives this step's done flags.  The other arguments are hirest_beam_advance's. */
+size_t hirest_caption_beam_tail_workspace_bytes(int32_t B, int32_t beam, int32_t vocab);
+int hirest_caption_beam_tail(const float* logits, int64_t ldx, const float* row_add, int32_t B, int32_t beam, int32_t vocab,
+                             int32_t step, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr,
+                             int32_t* n_steps, int32_t* done, int32_t* next_ids, int32_t* next_parents, float* next_add,
+                             int32_t* done_host, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Beam bookkeeping of one decoding step on the device (clip4caption/modules/beam.py:70-92): val / idx = the sorted top-`beam` of
  * every sample's beam x vocab scores ([B, beam]; idx = source_beam * vocab + word).  Per sample b that is not done: scores <- val,
  * tokens[b][step][k] / backptr[b][step][k] record (word, source beam), n_steps[b] = step + 1, done[b] = 1 once the best beam emits

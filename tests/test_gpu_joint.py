@@ -178,6 +178,9 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     # default = decoding with the self-attention K / V of earlier positions kept per beam; recomputing the whole prefix every
     # step, as the reference does (train.py:547-566), gives the same tokens
     assert model.caption_kv_cache
+    model.caption_fused_tail = False        # log-softmax, top-k and beam bookkeeping as separate kernels
+    assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
+    model.caption_fused_tail = True
     model.caption_kv_cache = False
     assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
     # greedy decoding (one beam) and a wider beam through both paths
@@ -186,6 +189,56 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
         ref = model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"]
         model.caption_kv_cache = True
         assert model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"] == ref, nb
+
+
+@pytest.mark.parametrize("B,beam,step", [(5, 5, 3), (5, 3, 0), (2, 7, 1), (3, 1, 2)])
+def test_beam_tail_equals_log_softmax_topk_advance(dev, B, beam, step):
+    """hirest_caption_beam_tail (two kernels, log-probabilities never materialised) against hirest_log_softmax_f32 +
+    hirest_topk_f32_ws + hirest_beam_advance: every output bit for bit, with duplicated logits (ties), one sample already done
+    and one beam emitting [SEP]"""
+    import ctypes as C
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    Vp, R, max_steps, eos = 30528, B * beam, 8, 102
+    x = synth.tensor(f"bt.{B}.{beam}", (R, Vp), 3.0, 5)
+    x[:, 30522:] = -1.0e30                                     # padded vocabulary entries
+    x[0, 777] = x[0, 12345] = x[0].max() + 1.0                 # an exact tie at the top of one row
+    x[R - beam, eos] = x[R - beam].max() + 20.0                # the last sample's best continuation (from its beam 0) is [SEP]
+    x = x.to(dev)
+    add = synth.tensor("bt.add", (R,), 2.0, 5).to(dev)
+    if step == 0:
+        add = torch.full((B, beam), -3.0e38); add[:, 0] = 0.0; add = add.reshape(-1).to(dev)
+    def state():
+        done = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if B > 2:
+            done[1] = 1
+        return dict(scores=torch.zeros((R,), device=dev), tokens=torch.full((B, max_steps, beam), -7, dtype=torch.int32, device=dev),
+                    backptr=torch.full((B, max_steps, beam), -7, dtype=torch.int32, device=dev),
+                    n_steps=torch.zeros((B,), dtype=torch.int32, device=dev), done=done,
+                    ids=torch.full((R,), -7, dtype=torch.int32, device=dev), parents=torch.full((R,), -7, dtype=torch.int32, device=dev),
+                    nadd=torch.full((R,), -7.0, device=dev))
+    a, b = state(), state()
+    st = ops.stream_ptr()
+    logp = torch.empty_like(x)
+    _lib.check(lib.hirest_log_softmax_f32(x.data_ptr(), Vp, add.data_ptr(), logp.data_ptr(), Vp, R, Vp, st), "ls")
+    tk = torch.empty(max(int(lib.hirest_topk_workspace_bytes(B, beam * Vp, beam)), 16), dtype=torch.uint8, device=dev)
+    val = torch.empty((B, beam), device=dev); idx = torch.empty((B, beam), dtype=torch.int32, device=dev)
+    _lib.check(lib.hirest_topk_f32_ws(logp.data_ptr(), None, B, beam * Vp, beam, idx.data_ptr(), val.data_ptr(), tk.data_ptr(), tk.numel(),
+                                      st), "topk")
+    _lib.check(lib.hirest_beam_advance(val.data_ptr(), idx.data_ptr(), B, beam, Vp, step, max_steps, eos, a["scores"].data_ptr(),
+                                       a["tokens"].data_ptr(), a["backptr"].data_ptr(), a["n_steps"].data_ptr(), a["done"].data_ptr(),
+                                       a["ids"].data_ptr(), a["parents"].data_ptr(), a["nadd"].data_ptr(), st), "advance")
+    ws = torch.empty(max(int(lib.hirest_caption_beam_tail_workspace_bytes(B, beam, Vp)), 16), dtype=torch.uint8, device=dev)
+    host = torch.full((B,), -1, dtype=torch.int32).pin_memory()
+    _lib.check(lib.hirest_caption_beam_tail(x.data_ptr(), Vp, add.data_ptr(), B, beam, Vp, step, max_steps, eos, b["scores"].data_ptr(),
+                                            b["tokens"].data_ptr(), b["backptr"].data_ptr(), b["n_steps"].data_ptr(), b["done"].data_ptr(),
+                                            b["ids"].data_ptr(), b["parents"].data_ptr(), b["nadd"].data_ptr(), host.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), st), "tail")
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(host, a["done"].cpu())
+    assert a["done"][B - 1].item() == 1                         # [SEP] on the best beam finished the last sample
 
 
 def test_clip_text_ids_path_equals_text_feat_path(dev, golden_dir):
