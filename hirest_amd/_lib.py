@@ -135,6 +135,9 @@ _SIGNATURES = {
     "hirest_attention_f32_qkv": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hirest_gemm_f32_select_kernel": (C.c_int, [C.c_int32]),
+    "hirest_gemm_f32_ln": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_caption_step_workspace_bytes": (C.c_size_t, [C.POINTER(CaptionDecoder), C.c_int32]),
     "hirest_beam_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -145,6 +148,7 @@ _SIGNATURES = {
     "hirest_caption_decode_logits": (C.c_int, [C.POINTER(CaptionDecoder), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hirest_caption_select": (C.c_int, [C.c_int32]),
     "hirest_caption_beam_tail_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "hirest_caption_beam_tail": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

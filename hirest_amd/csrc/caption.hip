@@ -98,12 +98,19 @@ __device__ __forceinline__ void block_topk16(const float (&val)[16], const int (
             const bool take = idx[e] >= 0 && tail_better(prev_s, prev_i, val[e], idx[e]) && (bi < 0 || tail_better(val[e], idx[e], bs, bi));
             bs = take ? val[e] : bs; bi = take ? idx[e] : bi;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float os = __shfl_xor(bs, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            const bool take = oi >= 0 && (bi < 0 || tail_better(os, oi, bs, bi));
-            bs = take ? os : bs; bi = take ? oi : bi;
+        {   // best of the wave on the cross-lane data paths (common.h: wave_max_x), the pair (score, index) moving together
+            auto pick = [](float& s1, int& i1, float s2, int i2) {
+                const bool second = i2 >= 0 && (i1 < 0 || tail_better(s2, i2, s1, i1));
+                s1 = second ? s2 : s1; i1 = second ? i2 : i1;
+            };
+            float s2 = bs; int i2 = bi;
+            lane_swap32(bs, s2); lane_swap32(bi, i2); pick(bs, bi, s2, i2);
+            s2 = bs; i2 = bi;
+            lane_swap16(bs, s2); lane_swap16(bi, i2); pick(bs, bi, s2, i2);
+            pick(bs, bi, lane_dpp<0x128>(bs), lane_dpp<0x128>(bi));
+            pick(bs, bi, lane_dpp<0x124>(bs), lane_dpp<0x124>(bi));
+            pick(bs, bi, lane_dpp<0x4E>(bs), lane_dpp<0x4E>(bi));
+            pick(bs, bi, lane_dpp<0xB1>(bs), lane_dpp<0xB1>(bi));
         }
         if (lane == 0) { rs[wave] = bs; ri[wave] = bi; }
         __syncthreads();
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict_
             mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
         }
     }
-    mx = wave_max(mx);
+    mx = wave_max_x(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict_
     for (int j = 0; j < 8; ++j)
         if (tid + 256 * g + 1024 * j < V4)
             s += (expf(mine[j][0] - mx) + expf(mine[j][1] - mx)) + (expf(mine[j][2] - mx) + expf(mine[j][3] - mx));
-    s = wave_sum(s);
+    s = wave_sum_x(s);
     if (lane == 0) stat[(int64_t)r * TAIL_STAT + 4 * g + wave] = s;
     if (g == 0 && tid == 0) stat[(int64_t)r * TAIL_STAT + 16] = mx;
 }
@@ -264,6 +271,13 @@ extern "C" size_t hirest_caption_step_workspace_bytes(const hirest_caption_decod
 
 #define CK(call) do { if (int e_ = (call)) return e_; } while (0)
 
+static int g_caption_mode = 0;     // hirest_caption_select: A/B and tests
+extern "C" int hirest_caption_select(int32_t mode) {   // 0 = LayerNorms / embedding inside the GEMMs, 1 = as separate kernels
+    if (mode < 0 || mode > 1) return HIREST_E_BADARG;
+    g_caption_mode = mode;
+    return 0;
+}
+
 // logp != NULL: log_softmax + row_add into logp; logits_out != NULL: the raw LM-head logits there instead (hirest_caption_beam_tail)
 static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
                        const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
@@ -287,33 +301,68 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const float eps = 1e-12f, scale = 0.125f;            // BertLayerNorm eps; 1 / sqrt(64)
 
-    hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, s, pos, R, position);
-    CK(hirest_embedding_pos_fwd_f32(last_ids, pos, d->word_emb, d->pos_emb, a, R, D, stream));
-    CK(hirest_layernorm(a, D, nullptr, d->emb_ln_g, d->emb_ln_b, eps, x, D, 1, R, D, stream));
-    for (int i = 0; i < d->layers; ++i) {
-        const hirest_caption_layer& L = d->layer[i];
-        CK(hirest_gemm_f32(x, D, L.qkv_w, D, L.qkv_b, nullptr, 0, nullptr, 0, qkv, 3 * D, R, 3 * D, D, 0, stream));
-        {
-            const int64_t n4 = (int64_t)R * (position + 1) * (D / 4);
-            hipLaunchKernelGGL(kv_gather_append_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
-                               position > 0 ? kv_in[2 * i] : nullptr, position > 0 ? kv_in[2 * i + 1] : nullptr,
-                               position > 0 ? parent_rows : nullptr, qkv, kv_out[2 * i], kv_out[2 * i + 1], R, position, D);
+    const bool fused_ln = g_caption_mode == 0 && R <= 32 && D % 256 == 0 && D <= 1024;
+    if (fused_ln) {
+        // every LayerNorm (and the token + position embedding) is the prologue of the GEMM that consumes it (hirest_gemm_f32_ln):
+        // a = the pre-LayerNorm sum of the previous sub-layer, x / b = the normalised rows (written by the GEMM, residual of the next)
+        const float* pos_row = d->pos_emb + (int64_t)position * D;
+        float* q2 = qkv;                                              // [R, D]: the packed q | k | v rows are dead after the self-attention
+        for (int i = 0; i < d->layers; ++i) {
+            const hirest_caption_layer& L = d->layer[i];
+            if (i == 0) CK(hirest_gemm_f32_ln(nullptr, 0, last_ids, d->word_emb, pos_row, d->emb_ln_g, d->emb_ln_b, eps, x, D, L.qkv_w, D, L.qkv_b,
+                                              nullptr, 0, qkv, 3 * D, R, 3 * D, D, 0, stream));
+            else CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, d->layer[i - 1].ff_ln_g, d->layer[i - 1].ff_ln_b, eps, x, D, L.qkv_w, D,
+                                       L.qkv_b, nullptr, 0, qkv, 3 * D, R, 3 * D, D, 0, stream));
+            {
+                const int64_t n4 = (int64_t)R * (position + 1) * (D / 4);
+                hipLaunchKernelGGL(kv_gather_append_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                                   position > 0 ? kv_in[2 * i] : nullptr, position > 0 ? kv_in[2 * i + 1] : nullptr,
+                                   position > 0 ? parent_rows : nullptr, qkv, kv_out[2 * i], kv_out[2 * i + 1], R, position, D);
+            }
+            CK(hirest_attention_f32_qkv(qkv, 3 * D, kv_out[2 * i], kv_out[2 * i + 1], D, ctx, R, 1, position + 1, H, 64, scale, 0.f, 0.f,
+                                        stream));
+            CK(hirest_gemm_f32(ctx, D, L.so_w, D, L.so_b, x, D, nullptr, 0, a, D, R, D, D, 0, stream));
+            CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, L.so_ln_g, L.so_ln_b, eps, b, D, L.cq_w, D, L.cq_b, nullptr, 0, q2, D, R, D, D,
+                                  0, stream));                                                                  // s1 = b
+            CK(hirest_attention_f32_qkv(q2, D, enc_kv[i], enc_kv[i] + D, 2 * D, ctx, R, 1, F, H, 64, scale, -10000.f, 0.f, stream));
+            CK(hirest_gemm_f32(ctx, D, L.co_w, D, L.co_b, b, D, nullptr, 0, a, D, R, D, D, 0, stream));
+            CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, L.co_ln_g, L.co_ln_b, eps, b, D, L.ff1_w, D, L.ff1_b, nullptr, 0, mid,
+                                  d->inter, R, d->inter, D, 1, stream));                                        // d = b
+            CK(hirest_gemm_f32(mid, d->inter, L.ff2_w, d->inter, L.ff2_b, b, D, nullptr, 0, a, D, R, D, d->inter, 0, stream));
         }
-        // self-attention of the newest position (Tq = 1 per beam) over its position + 1 kept keys; nothing lies in the future
-        CK(hirest_attention_f32_qkv(qkv, 3 * D, kv_out[2 * i], kv_out[2 * i + 1], D, ctx, R, 1, position + 1, H, 64, scale, 0.f, 0.f,
-                                    stream));
-        CK(hirest_gemm_f32(ctx, D, L.so_w, D, L.so_b, x, D, nullptr, 0, a, D, R, D, D, 0, stream));
-        CK(hirest_layernorm(a, D, nullptr, L.so_ln_g, L.so_ln_b, eps, b, D, 1, R, D, stream));                  // s1 = b
-        CK(hirest_gemm_f32(b, D, L.cq_w, D, L.cq_b, nullptr, 0, nullptr, 0, a, D, R, D, D, 0, stream));         // q2 = a
-        CK(hirest_attention_f32_qkv(a, D, enc_kv[i], enc_kv[i] + D, 2 * D, ctx, R, 1, F, H, 64, scale, -10000.f, 0.f, stream));
-        CK(hirest_gemm_f32(ctx, D, L.co_w, D, L.co_b, b, D, nullptr, 0, a, D, R, D, D, 0, stream));
-        CK(hirest_layernorm(a, D, nullptr, L.co_ln_g, L.co_ln_b, eps, b, D, 1, R, D, stream));                  // d = b
-        CK(hirest_gemm_f32(b, D, L.ff1_w, D, L.ff1_b, nullptr, 0, nullptr, 0, mid, d->inter, R, d->inter, D, 1, stream));
-        CK(hirest_gemm_f32(mid, d->inter, L.ff2_w, d->inter, L.ff2_b, b, D, nullptr, 0, a, D, R, D, d->inter, 0, stream));
-        CK(hirest_layernorm(a, D, nullptr, L.ff_ln_g, L.ff_ln_b, eps, x, D, 1, R, D, stream));
+        const hirest_caption_layer& Z = d->layer[d->layers - 1];
+        CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, Z.ff_ln_g, Z.ff_ln_b, eps, nullptr, 0, d->tr_w, D, d->tr_b, nullptr, 0, x, D, R, D,
+                              D, 1, stream));
+        CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
+    } else {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, s, pos, R, position);
+        CK(hirest_embedding_pos_fwd_f32(last_ids, pos, d->word_emb, d->pos_emb, a, R, D, stream));
+        CK(hirest_layernorm(a, D, nullptr, d->emb_ln_g, d->emb_ln_b, eps, x, D, 1, R, D, stream));
+        for (int i = 0; i < d->layers; ++i) {
+            const hirest_caption_layer& L = d->layer[i];
+            CK(hirest_gemm_f32(x, D, L.qkv_w, D, L.qkv_b, nullptr, 0, nullptr, 0, qkv, 3 * D, R, 3 * D, D, 0, stream));
+            {
+                const int64_t n4 = (int64_t)R * (position + 1) * (D / 4);
+                hipLaunchKernelGGL(kv_gather_append_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                                   position > 0 ? kv_in[2 * i] : nullptr, position > 0 ? kv_in[2 * i + 1] : nullptr,
+                                   position > 0 ? parent_rows : nullptr, qkv, kv_out[2 * i], kv_out[2 * i + 1], R, position, D);
+            }
+            // self-attention of the newest position (Tq = 1 per beam) over its position + 1 kept keys; nothing lies in the future
+            CK(hirest_attention_f32_qkv(qkv, 3 * D, kv_out[2 * i], kv_out[2 * i + 1], D, ctx, R, 1, position + 1, H, 64, scale, 0.f, 0.f,
+                                        stream));
+            CK(hirest_gemm_f32(ctx, D, L.so_w, D, L.so_b, x, D, nullptr, 0, a, D, R, D, D, 0, stream));
+            CK(hirest_layernorm(a, D, nullptr, L.so_ln_g, L.so_ln_b, eps, b, D, 1, R, D, stream));                  // s1 = b
+            CK(hirest_gemm_f32(b, D, L.cq_w, D, L.cq_b, nullptr, 0, nullptr, 0, a, D, R, D, D, 0, stream));         // q2 = a
+            CK(hirest_attention_f32_qkv(a, D, enc_kv[i], enc_kv[i] + D, 2 * D, ctx, R, 1, F, H, 64, scale, -10000.f, 0.f, stream));
+            CK(hirest_gemm_f32(ctx, D, L.co_w, D, L.co_b, b, D, nullptr, 0, a, D, R, D, D, 0, stream));
+            CK(hirest_layernorm(a, D, nullptr, L.co_ln_g, L.co_ln_b, eps, b, D, 1, R, D, stream));                  // d = b
+            CK(hirest_gemm_f32(b, D, L.ff1_w, D, L.ff1_b, nullptr, 0, nullptr, 0, mid, d->inter, R, d->inter, D, 1, stream));
+            CK(hirest_gemm_f32(mid, d->inter, L.ff2_w, d->inter, L.ff2_b, b, D, nullptr, 0, a, D, R, D, d->inter, 0, stream));
+            CK(hirest_layernorm(a, D, nullptr, L.ff_ln_g, L.ff_ln_b, eps, x, D, 1, R, D, stream));
+        }
+        CK(hirest_gemm_f32(x, D, d->tr_w, D, d->tr_b, nullptr, 0, nullptr, 0, a, D, R, D, D, 1, stream));
+        CK(hirest_layernorm(a, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
     }
-    CK(hirest_gemm_f32(x, D, d->tr_w, D, d->tr_b, nullptr, 0, nullptr, 0, a, D, R, D, D, 1, stream));
-    CK(hirest_layernorm(a, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
     CK(hirest_gemm_f32(b, D, d->lm_w, D, d->lm_b, nullptr, 0, nullptr, 0, logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
     if (logp) CK(hirest_log_softmax_f32(logits, d->vocab_padded, row_add, logp, d->vocab_padded, R, d->vocab_padded, stream));
     return hirest_launch_status();

@@ -94,6 +94,62 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
+// The same two reductions on the cross-lane data paths instead of six ds_bpermute round trips (136 vs 680 cycles, same bits:
+// tools/probes/wave_sum_probe.hip).  v_permlane32_swap / v_permlane16_swap put a lane's own value and its xor-32 / xor-16 partner's
+// into the two registers; the xor-8 / xor-4 steps use DPP row rotations, whose partner lane differs from lane ^ 8 / lane ^ 4 but holds
+// the same number (by then a value only depends on the lane index mod 16 / mod 8); xor-2 / xor-1 are DPP quad permutations.  The
+// swaps are inline assembly: the builtin, given one value as both operands, reads both results from one register (hipcc 7.2).
+__device__ __forceinline__ void lane_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap32(int& a, int& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap16(int& a, int& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+template <int CTRL> __device__ __forceinline__ float lane_dpp(float v) {      // 0x128 row_ror:8, 0x124 row_ror:4, 0x4E / 0xB1 quad xor 2 / 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int lane_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_sum_x(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b); v = a + b;
+    a = v; b = v;
+    lane_swap16(a, b); v = a + b;
+    v += lane_dpp<0x128>(v); v += lane_dpp<0x124>(v); v += lane_dpp<0x4E>(v); v += lane_dpp<0xB1>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_max_x(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b); v = fmaxf(a, b);
+    a = v; b = v;
+    lane_swap16(a, b); v = fmaxf(a, b);
+    v = fmaxf(v, lane_dpp<0x128>(v)); v = fmaxf(v, lane_dpp<0x124>(v)); v = fmaxf(v, lane_dpp<0x4E>(v)); v = fmaxf(v, lane_dpp<0xB1>(v));
+    return v;
+}
+
+// LayerNorm of one row held by one wave (lane owns float4 number lane + 64 i of the row, zeros past the row's nv = D / 4 vectors):
+// two-pass statistics in fp32 like nn.LayerNorm's definition.  Shared by layernorm_rows and the GEMMs that normalise their
+// operand rows themselves, so that both give the same bits.
+template <int NV>
+__device__ __forceinline__ void ln_wave_stats(const f32x4 (&v)[NV], int nv, int D, float eps, int lane, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    mean = wave_sum_x(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    rstd = 1.0f / sqrtf(wave_sum_x(q) / (float)D + eps);
+}
+__device__ __forceinline__ f32x4 ln_apply(const f32x4& v, float mean, float rstd, const f32x4& g, const f32x4& b) {
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * g[e] + b[e];
+    return y;
+}
+
 // Async global -> LDS copy of 16 bytes per lane (LDS-DMA).  `lds_wave_base` must be
 // wave-uniform; lane i's 16 bytes land at lds_wave_base + 16*i.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

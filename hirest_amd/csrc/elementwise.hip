@@ -21,37 +21,18 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
     const float* xr = x + src * ldx;
     const int nv = D >> 2;
     f32x4 v[NV];
-    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
-        if (c < nv) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        } else {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        v[i] = c < nv ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
+    float mean, rstd;
+    ln_wave_stats<NV>(v, nv, D, eps, lane, mean, rstd);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            const f32x4 y = ln_apply(v[i], mean, rstd, *reinterpret_cast<const f32x4*>(gamma + 4 * c), *reinterpret_cast<const f32x4*>(beta + 4 * c));
             if constexpr (OUT_F32) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)row * ldo + 4 * c) = y;
             } else {

@@ -314,6 +314,165 @@ int launch_m16(const GemmF& p, hipStream_t s) {
     return hirest_launch_status();
 }
 
+// The same kernel for a layer whose input is LayerNorm(X) (the post-LN decoder: every second GEMM of a step): each block
+// normalises its 16 rows itself — four rows per wave with layernorm_rows' own arithmetic (ln_wave_stats / ln_apply), X optionally
+// being word_table[ids[row]] + pos_row, the step's embedding — into an LDS image the fragments are read from, while the W slabs
+// of the whole K quarter are already on their way (LDS-DMA issued first).  Column block 0 also writes the normalised rows out
+// (`ln_out`: the residual a later GEMM adds).  Saves a LayerNorm launch (and the embedding's two) per GEMM: 4-5 us each at 25 rows.
+struct GemmLN {
+    GemmF g;                                                 // g.A unused
+    const float* X; int64_t ldx;                             // rows to normalise, or
+    const int32_t* ids; const float* table; const float* pos_row;   // X[r] = table[ids[r]] + pos_row
+    const float* gamma; const float* beta; float eps;
+    float* ln_out; int64_t ldl;
+};
+
+template <int NV, int DEPTH>
+__global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
+    const GemmF& p = q.g;
+    constexpr int SLAB = 2048, L = 2;                        // W only: 16 rows x 128 B per slab, two LDS-DMA instructions
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A image (16 rows x astride), 4 x DEPTH x SLAB of W, reduction buffer
+    const int astride = p.K * 4 + 128;                       // odd multiple of 128 B: row parity picks the bank half, as in the ring
+    char* aimg = smem;
+    char* ringbase = smem + 16 * astride;
+    f32x4 (*red)[64] = reinterpret_cast<f32x4 (*)[64]>(ringbase + 4 * DEPTH * SLAB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15, slot = lane >> 4;
+    const int N0 = blockIdx.x * 16, M0 = blockIdx.y * 16;
+    const bool odd = slot >> 1;
+    char* ring = ringbase + wave * DEPTH * SLAB;
+    auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
+    const char* src[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int trow = 8 * j + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(trow);
+        int gn = N0 + trow; gn = gn < p.N ? gn : p.N - 1;
+        src[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * chunk;
+    }
+    const int nslab = p.K / FK;
+    const int quarter = (nslab + 3) >> 2, first = wave * quarter;
+    int cnt = nslab - first; cnt = cnt < 0 ? 0 : (cnt > quarter ? quarter : cnt);
+    auto dma = [&](int s, int ringslot) {
+        const int64_t koff = (int64_t)(first + (s < cnt ? s : cnt - 1)) * (FK * 4);
+        char* dst = ring + ringslot * SLAB;
+#pragma unroll
+        for (int j = 0; j < L; ++j) glds16(src[j] + koff, dst + j * 1024);
+    };
+    if (cnt > 0) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) dma(u, u);
+    }
+    // LayerNorm of rows M0 + 4 wave .. + 3 by this wave (lane owns float4 number lane + 64 i of a row; K = 256 NV, so every lane of
+    // every vector is inside the row).  All loads are unconditional (rows past M re-read row M - 1) and issued before the first
+    // reduction: guarded loads end up one memory round trip each.
+    {
+        const int nv = p.K >> 2;
+        f32x4 v[4][NV], gam[NV], bet[NV];
+        if (q.ids) {
+            f32x4 pe[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) pe[i] = *reinterpret_cast<const f32x4*>(q.pos_row + 4 * (lane + 64 * i));
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int m = M0 + 4 * wave + rr; m = m < p.M ? m : p.M - 1;
+                const float* tr = q.table + (int64_t)q.ids[m] * p.K;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(tr + 4 * (lane + 64 * i));
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[rr][i] += pe[i];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int m = M0 + 4 * wave + rr; m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(q.X + (int64_t)m * q.ldx + 4 * (lane + 64 * i));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            gam[i] = *reinterpret_cast<const f32x4*>(q.gamma + 4 * (lane + 64 * i));
+            bet[i] = *reinterpret_cast<const f32x4*>(q.beta + 4 * (lane + 64 * i));
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int rl = 4 * wave + rr, m = M0 + rl;
+            float mean, rstd;
+            ln_wave_stats<NV>(v[rr], nv, p.K, q.eps, lane, mean, rstd);
+            const bool store = q.ln_out && blockIdx.x == 0 && m < p.M;          // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                const f32x4 y = ln_apply(v[rr][i], mean, rstd, gam[i], bet[i]);     // rows past M: a copy of row M - 1, never stored
+                if (store) *reinterpret_cast<f32x4*>(q.ln_out + (int64_t)m * q.ldl + 4 * c) = y;
+                *reinterpret_cast<f32x4*>(aimg + rl * astride + (c >> 3) * 128 + (((c & 7) ^ swz(rl)) << 4)) = y;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the W prologue (and the ln_out stores) — they had the LayerNorm to land
+    __syncthreads();
+    int fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fo[c] = ((4 * (slot & 1) + c) ^ swz(idx)) << 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto mm = [&](int s, int ringslot) {
+        const char* wb = ring + ringslot * SLAB + idx * 128;
+        const char* ab = aimg + idx * astride + (first + s) * 128;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 aq = *reinterpret_cast<const f32x4*>(ab + fo[c]);
+            const f32x4 wq = *reinterpret_cast<const f32x4*>(wb + fo[c]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float a = odd ? aq[2 * e + 1] : aq[2 * e];
+                const float w = odd ? wq[2 * e + 1] : wq[2 * e];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, a, acc, 0, 0, 0);
+            }
+        }
+    };
+    if (cnt > 0) {
+        int rs = 0;
+        for (int s = 0; s < cnt - DEPTH; ++s) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * L) : "memory");
+            mm(s, rs);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma(s + DEPTH, rs);
+            rs = rs + 1 == DEPTH ? 0 : rs + 1;
+        }
+        const int base = cnt > DEPTH ? cnt - DEPTH : 0;
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (base + u < cnt) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1 - u) * L) : "memory");
+                mm(base + u, rs);
+                rs = rs + 1 == DEPTH ? 0 : rs + 1;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0) return;
+    const int n = N0 + 4 * slot, m = M0 + idx;
+    if (n >= p.N || m >= p.M) return;
+    epilogue_store4(p, ((acc + red[0][lane]) + red[1][lane]) + red[2][lane], m, n);
+}
+
+template <int NV, int DEPTH>
+int launch_m16ln(const GemmLN& q, hipStream_t s) {
+    static HirestDevCfg cfg;
+    auto kern = gemm_f32_m16ln_kernel<NV, DEPTH>;
+    constexpr int LDS_MAX = 16 * (NV * 1024 + 128) + 4 * DEPTH * 2048 + 3 * 1024;
+    static_assert(LDS_MAX <= 160 * 1024, "does not fit the LDS");
+    if (int e = hirest_configure(kern, LDS_MAX, cfg)) return e;
+    const int lds = 16 * (q.g.K * 4 + 128) + 4 * DEPTH * 2048 + 3 * 1024;
+    hipLaunchKernelGGL(kern, dim3((q.g.N + 15) / 16, (q.g.M + 15) / 16), dim3(256), lds, s, q);
+    return hirest_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 flash attention, head dim 64, full (unmasked) attention over T keys with the reference's uniform
 // additive constant: s = fl(fl(q.k * scale) + add_const) (module_visual.py:164-176 with the all-zeros mask
@@ -676,6 +835,23 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     }
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     return hirest_launch_status();
+}
+
+extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* ids, const float* table, const float* pos_row,
+                                  const float* gamma, const float* beta, float eps, float* ln_out, int64_t ldl, const float* W,
+                                  int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M,
+                                  int32_t N, int32_t K, int32_t act, void* stream) {
+    if ((!X && !(ids && table && pos_row)) || !gamma || !beta || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
+    if (M > 32 || K % 256 != 0 || K > 1024 || N % 4 != 0 || ldw % 4 != 0 || (X && ldx % 4 != 0) || (ln_out && ldl % 4 != 0)) return HIREST_E_SHAPE;
+    GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act}, X, ldx, ids, table, pos_row, gamma, beta, eps,
+             ln_out, ldl};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (K / 256) {                                        // the whole K quarter of W in flight (K / 128 slabs per wave)
+        case 1: return launch_m16ln<1, 2>(q, s);
+        case 2: return launch_m16ln<2, 4>(q, s);
+        case 3: return N >= 2048 ? launch_m16ln<3, 3>(q, s) : launch_m16ln<3, 6>(q, s);   // many column tiles: two blocks per CU
+        default: return launch_m16ln<4, 8>(q, s);
+    }
 }
 
 extern "C" int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,

@@ -349,6 +349,15 @@ int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, co
  * split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the 64x64 kernel, 2 = automatic without the 16-column
  * kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */
 int hirest_gemm_f32_select_kernel(int32_t which);
+/* out = act(LayerNorm(X; gamma, beta, eps) @ W^T + bias) (+ resid) for M <= 32 rows, K % 256 == 0, K <= 1024: the rows are
+ * normalised inside the GEMM with hirest_layernorm's own arithmetic (same bits as the two calls), and written to ln_out as well
+ * when it is not NULL.  With ids != NULL, X[r] = table[ids[r]] + pos_row (table rows of K floats): a decoding step's token +
+ * position embedding (module_decoder.py embeddings + LayerNorm).  Replaces hirest_layernorm + hirest_gemm_f32 (and
+ * hirest_embedding_pos_fwd_f32) in the step-captioning decoder, where a launch costs as much as the arithmetic. */
+int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* ids, const float* table, const float* pos_row,
+                       const float* gamma, const float* beta, float eps, float* ln_out, int64_t ldl, const float* W, int64_t ldw,
+                       const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M, int32_t N, int32_t K,
+                       int32_t act, void* stream);
 /* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*64]; no key masking (the
  * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3). */
 int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,
@@ -411,6 +420,9 @@ int hirest_caption_decode_step(const hirest_caption_decoder* d, int32_t R, int32
                                const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* 0 (default) = the decoder step runs its LayerNorms and the token embedding as prologues of the GEMMs that consume them
+ * (hirest_gemm_f32_ln), 1 = as separate kernels.  Same bits either way (tests / A-B timing). */
+int hirest_caption_select(int32_t mode);
 /* The same step up to the LM head: raw logits [R, vocab_padded] instead of log-probabilities (input of hirest_caption_beam_tail). */
 int hirest_caption_decode_logits(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
                                  const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,

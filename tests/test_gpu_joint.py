@@ -181,6 +181,12 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     model.caption_fused_tail = False        # log-softmax, top-k and beam bookkeeping as separate kernels
     assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
     model.caption_fused_tail = True
+    from hirest_amd import _lib
+    _lib.check(_lib.load().hirest_caption_select(1), "select")    # LayerNorms / embedding as separate kernels
+    try:
+        assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
+    finally:
+        _lib.load().hirest_caption_select(0)
     model.caption_kv_cache = False
     assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
     # greedy decoding (one beam) and a wider beam through both paths
@@ -189,6 +195,43 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
         ref = model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"]
         model.caption_kv_cache = True
         assert model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"] == ref, nb
+
+
+@pytest.mark.parametrize("M,N,K,act,embed", [(25, 2304, 768, 0, True), (25, 768, 768, 0, False), (15, 3072, 768, 1, False), (7, 100, 256, 2, False),
+                                             (32, 768, 1024, 3, True), (1, 36, 512, 0, False)])
+def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
+    """hirest_gemm_f32_ln (LayerNorm / token + position embedding as the GEMM's prologue) against hirest_embedding_pos_fwd_f32 +
+    hirest_layernorm + hirest_gemm_f32: output and the normalised rows bit for bit"""
+    from hirest_amd import _lib, ops
+    from hirest_amd.moment_model import MomentModel
+    lib, st = _lib.load(), ops.stream_ptr()
+    w = synth.tensor("gl.w", (N, K), 0.05, 3).to(dev)
+    bias = synth.tensor("gl.b", (N,), 0.3, 3).to(dev)
+    resid = synth.tensor("gl.r", (M, N), 1.0, 3).to(dev)
+    g = (1.0 + synth.tensor("gl.g", (K,), 0.2, 3)).to(dev)
+    be = synth.tensor("gl.be", (K,), 0.2, 3).to(dev)
+    if embed:
+        table = synth.tensor("gl.t", (500, K), 1.0, 3).to(dev)
+        pos = synth.tensor("gl.p", (48, K), 0.5, 3).to(dev)
+        ids = ((torch.arange(M) * 37 + 11) % 500).to(torch.int32).to(dev)
+        pids = torch.full((M,), 9, dtype=torch.int32, device=dev)
+        x = torch.empty((M, K), device=dev)
+        _lib.check(lib.hirest_embedding_pos_fwd_f32(ids.data_ptr(), pids.data_ptr(), table.data_ptr(), pos.data_ptr(), x.data_ptr(), M, K, st), "emb")
+    else:
+        x = synth.tensor("gl.x", (M, K), 2.0, 3).to(dev)
+    ln = torch.empty((M, K), device=dev)
+    _lib.check(lib.hirest_layernorm(x.data_ptr(), K, None, g.data_ptr(), be.data_ptr(), 1e-12, ln.data_ptr(), K, 1, M, K, st), "ln")
+    ref = MomentModel._gemm(ln, w, bias, resid=resid, act=act)
+    out = torch.empty((M, N), device=dev)
+    ln2 = torch.empty((M, K), device=dev)
+    _lib.check(lib.hirest_gemm_f32_ln(None if embed else x.data_ptr(), K, ids.data_ptr() if embed else None,
+                                      table.data_ptr() if embed else None, pos[9].data_ptr() if embed else None, g.data_ptr(), be.data_ptr(),
+                                      1e-12, ln2.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), resid.data_ptr(), N, out.data_ptr(), N, M, N, K,
+                                      act, st), "gemm_ln")
+    assert torch.equal(ln2, ln)
+    assert torch.equal(out, ref)
+    assert lib.hirest_gemm_f32_ln(x.data_ptr(), K, None, None, None, g.data_ptr(), be.data_ptr(), 1e-12, None, 0, w.data_ptr(), K, None, None, 0,
+                                  out.data_ptr(), N, 33, N, K, act, st) == -2          # more than 32 rows: HIREST_E_SHAPE
 
 
 @pytest.mark.parametrize("B,beam,step", [(5, 5, 3), (5, 3, 0), (2, 7, 1), (3, 1, 2)])

@@ -4,7 +4,7 @@
    python tools/word_timeline.py gpurun_out/capt/x_kernel_trace.csv [which_word]"""
 import csv, re, sys
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))))
-marks = [i for i, r in enumerate(rows) if "fill_i32_kernel" in r[2]]
+marks = [i + 1 for i, r in enumerate(rows) if "tail_select_kernel" in r[2] or "beam_advance_kernel" in r[2]]   # a word ends with the beam bookkeeping
 w = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) // 2
 a, b = marks[w], marks[w + 1]
 def short(n):
