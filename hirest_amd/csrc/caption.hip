@@ -83,13 +83,17 @@ __global__ void beam_advance_kernel(const float* __restrict__ val, const int32_t
 constexpr int TAIL_CHUNK = 4096, TAIL_STAT = 17;            // floats of statistics per row: 16 partial sums + the max
 __device__ __forceinline__ bool tail_better(float sa, int ta, float sb, int tb) { return sa > sb || (sa == sb && ta > tb); }
 
-// top k of (val, idx) pairs held 16 per thread by a 256-thread block; thread 0 reports pick j through put(j, val, idx)
+// top k of (val, idx) pairs held 16 per thread by a 256-thread block; thread 0 reports pick j through put(j, val, idx).
+// One barrier per pick: the four wave winners go through a two-deep LDS buffer and every thread reduces them itself.
 template <class Put>
 __device__ __forceinline__ void block_topk16(const float (&val)[16], const int (&idx)[16], int k, Put put) {
-    __shared__ float rs[4];
-    __shared__ int ri[4];
-    __shared__ float ps; __shared__ int pi;
+    __shared__ float rs[2][4];
+    __shared__ int ri[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto pick = [](float& s1, int& i1, float s2, int i2) {
+        const bool second = i2 >= 0 && (i1 < 0 || tail_better(s2, i2, s1, i1));
+        s1 = second ? s2 : s1; i1 = second ? i2 : i1;
+    };
     float prev_s = INFINITY; int prev_i = 0x7fffffff;
     for (int j = 0; j < k; ++j) {
         float bs = -INFINITY; int bi = -1;
@@ -99,10 +103,6 @@ __device__ __forceinline__ void block_topk16(const float (&val)[16], const int (
             bs = take ? val[e] : bs; bi = take ? idx[e] : bi;
         }
         {   // best of the wave on the cross-lane data paths (common.h: wave_max_x), the pair (score, index) moving together
-            auto pick = [](float& s1, int& i1, float s2, int i2) {
-                const bool second = i2 >= 0 && (i1 < 0 || tail_better(s2, i2, s1, i1));
-                s1 = second ? s2 : s1; i1 = second ? i2 : i1;
-            };
             float s2 = bs; int i2 = bi;
             lane_swap32(bs, s2); lane_swap32(bi, i2); pick(bs, bi, s2, i2);
             s2 = bs; i2 = bi;
@@ -112,21 +112,13 @@ __device__ __forceinline__ void block_topk16(const float (&val)[16], const int (
             pick(bs, bi, lane_dpp<0x4E>(bs), lane_dpp<0x4E>(bi));
             pick(bs, bi, lane_dpp<0xB1>(bs), lane_dpp<0xB1>(bi));
         }
-        if (lane == 0) { rs[wave] = bs; ri[wave] = bi; }
+        if (lane == 0) { rs[j & 1][wave] = bs; ri[j & 1][wave] = bi; }
         __syncthreads();
-        if (tid == 0) {
-            float sb = rs[0]; int ib = ri[0];
+        float sb = rs[j & 1][0]; int ib = ri[j & 1][0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const bool take = ri[w] >= 0 && (ib < 0 || tail_better(rs[w], ri[w], sb, ib));
-                sb = take ? rs[w] : sb; ib = take ? ri[w] : ib;
-            }
-            put(j, sb, ib);                                  // ib < 0: fewer than j + 1 elements
-            ps = sb; pi = ib;
-        }
-        __syncthreads();
-        prev_s = ps; prev_i = pi;
-        __syncthreads();
+        for (int w = 1; w < 4; ++w) pick(sb, ib, rs[j & 1][w], ri[j & 1][w]);
+        if (tid == 0) put(j, sb, ib);                        // ib < 0: fewer than j + 1 elements
+        prev_s = sb; prev_i = ib;
     }
 }
 
@@ -272,7 +264,8 @@ extern "C" size_t hirest_caption_step_workspace_bytes(const hirest_caption_decod
 #define CK(call) do { if (int e_ = (call)) return e_; } while (0)
 
 static int g_caption_mode = 0;     // hirest_caption_select: A/B and tests
-extern "C" int hirest_caption_select(int32_t mode) {   // 0 = LayerNorms / embedding inside the GEMMs, 1 = as separate kernels
+// 0 = LayerNorms / embedding inside the GEMMs and one-query attention kernels, 1 = separate LayerNorm / embedding / K-V gather kernels
+extern "C" int hirest_caption_select(int32_t mode) {
     if (mode < 0 || mode > 1) return HIREST_E_BADARG;
     g_caption_mode = mode;
     return 0;
@@ -313,18 +306,16 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
                                               nullptr, 0, qkv, 3 * D, R, 3 * D, D, 0, stream));
             else CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, d->layer[i - 1].ff_ln_g, d->layer[i - 1].ff_ln_b, eps, x, D, L.qkv_w, D,
                                        L.qkv_b, nullptr, 0, qkv, 3 * D, R, 3 * D, D, 0, stream));
-            {
-                const int64_t n4 = (int64_t)R * (position + 1) * (D / 4);
-                hipLaunchKernelGGL(kv_gather_append_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
-                                   position > 0 ? kv_in[2 * i] : nullptr, position > 0 ? kv_in[2 * i + 1] : nullptr,
-                                   position > 0 ? parent_rows : nullptr, qkv, kv_out[2 * i], kv_out[2 * i + 1], R, position, D);
-            }
-            CK(hirest_attention_f32_qkv(qkv, 3 * D, kv_out[2 * i], kv_out[2 * i + 1], D, ctx, R, 1, position + 1, H, 64, scale, 0.f, 0.f,
-                                        stream));
+            // self-attention of the newest position over the parent beam's kept keys + its own, which also writes this beam's
+            // history for the next step (one wave per (row, head): hirest_attention_f32_decode)
+            CK(hirest_attention_f32_decode(qkv, 3 * D, position > 0 ? kv_in[2 * i] : nullptr, position > 0 ? kv_in[2 * i + 1] : nullptr, D,
+                                           position > 0 ? parent_rows : nullptr, position, qkv + D, qkv + 2 * D, 3 * D, kv_out[2 * i],
+                                           kv_out[2 * i + 1], ctx, R, H, scale, 0.f, 0.f, stream));
             CK(hirest_gemm_f32(ctx, D, L.so_w, D, L.so_b, x, D, nullptr, 0, a, D, R, D, D, 0, stream));
             CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, L.so_ln_g, L.so_ln_b, eps, b, D, L.cq_w, D, L.cq_b, nullptr, 0, q2, D, R, D, D,
                                   0, stream));                                                                  // s1 = b
-            CK(hirest_attention_f32_qkv(q2, D, enc_kv[i], enc_kv[i] + D, 2 * D, ctx, R, 1, F, H, 64, scale, -10000.f, 0.f, stream));
+            CK(hirest_attention_f32_decode(q2, D, enc_kv[i], enc_kv[i] + D, 2 * D, nullptr, F, nullptr, nullptr, 0, nullptr, nullptr, ctx, R, H,
+                                           scale, -10000.f, 0.f, stream));
             CK(hirest_gemm_f32(ctx, D, L.co_w, D, L.co_b, b, D, nullptr, 0, a, D, R, D, D, 0, stream));
             CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, L.co_ln_g, L.co_ln_b, eps, b, D, L.ff1_w, D, L.ff1_b, nullptr, 0, mid,
                                   d->inter, R, d->inter, D, 1, stream));                                        // d = b

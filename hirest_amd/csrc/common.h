@@ -98,7 +98,8 @@ __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf
 // tools/probes/wave_sum_probe.hip).  v_permlane32_swap / v_permlane16_swap put a lane's own value and its xor-32 / xor-16 partner's
 // into the two registers; the xor-8 / xor-4 steps use DPP row rotations, whose partner lane differs from lane ^ 8 / lane ^ 4 but holds
 // the same number (by then a value only depends on the lane index mod 16 / mod 8); xor-2 / xor-1 are DPP quad permutations.  The
-// swaps are inline assembly: the builtin, given one value as both operands, reads both results from one register (hipcc 7.2).
+// swaps are inline assembly: the builtin, given one value as both operands, reads both results from one register (hipcc 7.2) —
+// and `asm volatile`: without it one LayerNorm row in a thousand came out one ulp off in the four-rows-per-wave prologue.
 __device__ __forceinline__ void lane_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lane_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lane_swap32(int& a, int& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }

@@ -338,7 +338,10 @@ __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
     f32x4 (*red)[64] = reinterpret_cast<f32x4 (*)[64]>(ringbase + 4 * DEPTH * SLAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15, slot = lane >> 4;
-    const int N0 = blockIdx.x * 16, M0 = blockIdx.y * 16;
+    // with ln_out, one extra column block (the last) only normalises its rows and writes them out: a store's round trip in a block
+    // that also multiplies would be waited for together with its W slabs
+    const bool ln_only = q.ln_out && blockIdx.x == gridDim.x - 1;
+    const int N0 = ln_only ? 0 : blockIdx.x * 16, M0 = blockIdx.y * 16;
     const bool odd = slot >> 1;
     char* ring = ringbase + wave * DEPTH * SLAB;
     auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
 #pragma unroll
         for (int j = 0; j < L; ++j) glds16(src[j] + koff, dst + j * 1024);
     };
-    if (cnt > 0) {
+    if (cnt > 0 && !ln_only) {
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) dma(u, u);
     }
@@ -399,20 +402,21 @@ __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int rl = 4 * wave + rr, m = M0 + rl;
+            const int rl = 4 * wave + rr;
             float mean, rstd;
             ln_wave_stats<NV>(v[rr], nv, p.K, q.eps, lane, mean, rstd);
-            const bool store = q.ln_out && blockIdx.x == 0 && m < p.M;          // (wave-uniform)
+            const bool store = ln_only && M0 + rl < p.M;                          // (wave-uniform)
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = lane + 64 * i;
                 const f32x4 y = ln_apply(v[rr][i], mean, rstd, gam[i], bet[i]);     // rows past M: a copy of row M - 1, never stored
-                if (store) *reinterpret_cast<f32x4*>(q.ln_out + (int64_t)m * q.ldl + 4 * c) = y;
+                if (store) *reinterpret_cast<f32x4*>(q.ln_out + (int64_t)(M0 + rl) * q.ldl + 4 * c) = y;
                 *reinterpret_cast<f32x4*>(aimg + rl * astride + (c >> 3) * 128 + (((c & 7) ^ swz(rl)) << 4)) = y;
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the W prologue (and the ln_out stores) — they had the LayerNorm to land
+    if (ln_only) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the W prologue: it had the LayerNorm to land
     __syncthreads();
     int fo[4];
 #pragma unroll
@@ -469,7 +473,7 @@ int launch_m16ln(const GemmLN& q, hipStream_t s) {
     static_assert(LDS_MAX <= 160 * 1024, "does not fit the LDS");
     if (int e = hirest_configure(kern, LDS_MAX, cfg)) return e;
     const int lds = 16 * (q.g.K * 4 + 128) + 4 * DEPTH * 2048 + 3 * 1024;
-    hipLaunchKernelGGL(kern, dim3((q.g.N + 15) / 16, (q.g.M + 15) / 16), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(kern, dim3((q.g.N + 15) / 16 + (q.ln_out ? 1 : 0), (q.g.M + 15) / 16), dim3(256), lds, s, q);
     return hirest_launch_status();
 }
 
@@ -482,6 +486,14 @@ int launch_m16ln(const GemmLN& q, hipStream_t s) {
 //   O^T = V^T.P^T  P is reused in place as the B operand: k-step r pairs key kap(r,0) (lanes < 32) with
 //                  kap(r,1) = kap(r,0)+4 (lanes >= 32), which is exactly what each half-wave holds in reg r.
 // ---------------------------------------------------------------------------------------------
+// (shared by the two attention kernels so that both contract the same way)
+__device__ __forceinline__ float attn_score(float st, float scale, float addc, bool valid) {
+    float sv = st * scale;
+    sv = sv + addc;                                           // additive masks, exactly as the reference adds them
+    return valid ? sv : -3.0e38f;
+}
+__device__ __forceinline__ float attn_lsum(float lrun, float alpha, float psum) { return lrun * alpha + psum; }
+
 // DHP = head dim padded to a multiple of 32 (64, or 96 for EVA-CLIP's 88-wide heads: the fp32 reference-precision tower);
 // dh = the real head dim (the packed layouts are addressed with it; padded dims are zeros and their outputs are not stored).
 template <int DHP>
@@ -541,9 +553,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float sv = st[r] * scale;
-            sv = sv + (key > q ? add_const + causal_penalty : add_const);   // additive masks, exactly as the reference adds them
-            sv = key < T ? sv : -3.0e38f;
+            const float sv = attn_score(st[r], scale, key > q ? add_const + causal_penalty : add_const, key < T);
             st[r] = sv;
             tmax = fmaxf(tmax, sv);
         }
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float pz = __expf(st[r] - mnew); st[r] = pz; psum += pz; }
         psum += __shfl_xor(psum, 32, 64);
-        lrun = lrun * alpha + psum;
+        lrun = attn_lsum(lrun, alpha, psum);
         mrun = mnew;
 #pragma unroll
         for (int j = 0; j < NO; ++j)
@@ -579,6 +589,107 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             if (d < dh)
                 *reinterpret_cast<f32x4*>(orow + d) = f32x4{o[j][4 * g] * inv, o[j][4 * g + 1] * inv, o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv};
         }
+}
+
+// One query per (row, head) — a beam-search step: the kernel above spends a 32 x 32 MFMA tile (two dependent chains of 32 + 32
+// v_mfma_f32_32x32x2_f32 = 4096 cycles per key tile) on a single query column, after a separate kernel has re-gathered every
+// beam's K / V history by parent row.  Here one wave owns (row, head) and does the same arithmetic in the same order with vector
+// FMAs (an fp32 MFMA is its k-ordered fma chain: tools/probes/fma_order_probe.hip): scores with lane = key (chain over d = 0..63),
+// the 32-key tile's max / exp / ordered sums as in the kernel above, P.V with lane = d (chain over the keys in the MFMA's order:
+// k-step r pairs key kap(r) = (r & 3) + 8 (r >> 2) with kap(r) + 4).  The history is read in place through the parent row (and the
+// newest key from the packed q | k | v rows); the gathered + appended K / V rows are written out on the way, which is all that
+// kv_gather_append_kernel did.
+struct AttnDec {
+    const float* q; int64_t ldq;
+    const float* k_hist; const float* v_hist; int64_t ld_hist; const int32_t* parent; int t_hist;
+    const float* k_new; const float* v_new; int64_t ld_new;
+    float* k_out; float* v_out;
+    float* out;
+    int H; float scale, add_const, causal_penalty;
+};
+
+__global__ __launch_bounds__(64) void attention_f32_decode_kernel(AttnDec p) {
+    constexpr int KLD = 68;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * KLD];
+    __shared__ __attribute__((aligned(16))) float Qs[64];
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x / p.H, h = blockIdx.x - r * p.H;
+    const int D = p.H * 64, T = p.t_hist + (p.k_new ? 1 : 0);
+    const int64_t src = p.parent ? p.parent[r] : r;
+    Qs[lane] = p.q[(int64_t)r * p.ldq + h * 64 + lane];
+    float mrun = -3.0e38f, lrun = 0.f, o = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 64) {
+        __syncthreads();
+        // K rows k0 .. k0 + 63 -> LDS (4 keys x 16 float4 per pass), V column d = lane of the same keys -> registers.  Every load is
+        // unconditional (keys past T re-read key T - 1) and issued before the first use; then both are written out as the row's new
+        // history (a store interleaved with its load costs the load's round trip each time).
+        f32x4 kreg[16];
+        float vv[64];
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int key = k0 + ps * 4 + (lane >> 4), kk = key < T ? key : T - 1;
+            const float* kp = kk < p.t_hist ? p.k_hist + (src * p.t_hist + kk) * p.ld_hist : p.k_new + (int64_t)r * p.ld_new;
+            kreg[ps] = *reinterpret_cast<const f32x4*>(kp + h * 64 + 4 * (lane & 15));
+        }
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int key = k0 + j, kk = key < T ? key : T - 1;
+            const float* vp = kk < p.t_hist ? p.v_hist + (src * p.t_hist + kk) * p.ld_hist : p.v_new + (int64_t)r * p.ld_new;
+            vv[j] = vp[h * 64 + lane];
+        }
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) *reinterpret_cast<f32x4*>(Ks + (ps * 4 + (lane >> 4)) * KLD + 4 * (lane & 15)) = kreg[ps];
+        if (p.k_out) {
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) {
+                const int key = k0 + ps * 4 + (lane >> 4);
+                if (key < T) *reinterpret_cast<f32x4*>(p.k_out + ((int64_t)r * T + key) * D + h * 64 + 4 * (lane & 15)) = kreg[ps];
+            }
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                if (k0 + j < T) p.v_out[((int64_t)r * T + k0 + j) * D + h * 64 + lane] = vv[j];
+        }
+        __syncthreads();
+        float st = 0.f;                                       // lane = key k0 + lane: q . k, d = 0 .. 63 in order
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 k4 = *reinterpret_cast<const f32x4*>(Ks + lane * KLD + 4 * c);
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(Qs + 4 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_fmaf(k4[e], q4[e], st);
+        }
+        const int key = k0 + lane;
+        const float sv = attn_score(st, p.scale, key > 0 ? p.add_const + p.causal_penalty : p.add_const, key < T);
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+            if (k0 + 32 * tile >= T) break;                   // (uniform)
+            // max of the tile's 32 scores: rows of 16 by DPP, the two rows by a swap (lanes 0-31 = tile 0, 32-63 = tile 1)
+            float t = sv;
+            t = fmaxf(t, lane_dpp<0x128>(t)); t = fmaxf(t, lane_dpp<0x124>(t)); t = fmaxf(t, lane_dpp<0x4E>(t)); t = fmaxf(t, lane_dpp<0xB1>(t));
+            { float a = t, b = t; lane_swap16(a, b); t = fmaxf(a, b); }
+            const float tmax = fmaxf(-3.0e38f, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 32 * tile)));
+            const float mnew = fmaxf(mrun, tmax);
+            const float alpha = __expf(mrun - mnew);
+            const float pz = __expf(sv - mnew);               // (meaningful in this tile's lanes)
+            float pk[32];                                     // the tile's probabilities, wave-uniform
+#pragma unroll
+            for (int j = 0; j < 32; ++j) pk[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), 32 * tile + j));
+            float ps0 = 0.f, ps1 = 0.f;                       // the two half-waves' sums of the kernel above, each in its register order
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) { const int kap = (rr & 3) + 8 * (rr >> 2); ps0 += pk[kap]; ps1 += pk[kap + 4]; }
+            lrun = attn_lsum(lrun, alpha, ps0 + ps1);
+            mrun = mnew;
+            o *= alpha;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int kap = (rr & 3) + 8 * (rr >> 2);
+                o = __builtin_fmaf(vv[32 * tile + kap], pk[kap], o);
+                o = __builtin_fmaf(vv[32 * tile + kap + 4], pk[kap + 4], o);
+            }
+        }
+    }
+    const float inv = 1.0f / lrun;
+    p.out[(int64_t)r * D + h * 64 + lane] = o * inv;
 }
 
 // dh 64 -> the 64-wide instantiation (the joint model, the sentence encoder's padded heads), 64 < dh <= 96 -> the 96-wide one
@@ -880,6 +991,18 @@ extern "C" int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float
     const int qblocks = (Tq + 127) / 128;
     return launch_attention_f32(dh, dim3(B * H * qblocks), reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk,
                                 (int)H, (int)dh, scale, add_const, causal_penalty, (const int32_t*)nullptr);
+}
+
+extern "C" int hirest_attention_f32_decode(const float* q, int64_t ldq, const float* k_hist, const float* v_hist, int64_t ld_hist,
+                                           const int32_t* parent, int32_t t_hist, const float* k_new, const float* v_new, int64_t ld_new,
+                                           float* k_out, float* v_out, float* out, int32_t R, int32_t H, float scale, float add_const,
+                                           float causal_penalty, void* stream) {
+    if (!q || !out || R <= 0 || H <= 0 || t_hist < 0 || (t_hist > 0 && (!k_hist || !v_hist)) || (!k_new != !v_new) || (!k_out != !v_out)) return HIREST_E_BADARG;
+    if (t_hist == 0 && !k_new) return HIREST_E_BADARG;
+    if (ldq % 4 != 0 || ld_hist % 4 != 0 || ld_new % 4 != 0) return HIREST_E_SHAPE;
+    AttnDec p{q, ldq, k_hist, v_hist, ld_hist, parent, t_hist, k_new, v_new, ld_new, k_out, v_out, out, H, scale, add_const, causal_penalty};
+    hipLaunchKernelGGL(attention_f32_decode_kernel, dim3(R * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return hirest_launch_status();
 }
 
 // out[r][v] = x[r][v] - logsumexp(x[r]) + row_add[r]   (log_softmax of train.py:563-564 fused with the beam score add of beam.py:76)

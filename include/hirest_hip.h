@@ -420,8 +420,18 @@ int hirest_caption_decode_step(const hirest_caption_decoder* d, int32_t R, int32
                                const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* hirest_attention_f32_qkv for ONE query per row (a decoding step), head width 64, one wave per (row, head), same bits.  Keys of
+ * row r: j < t_hist at k_hist / v_hist + ((parent ? parent[r] : r) * t_hist + j) * ld_hist, then (k_new != NULL) one more at
+ * k_new / v_new + r * ld_new.  k_out / v_out (optional): [R, T, H * 64] receive the keys / values used, T = t_hist (+ 1) — the beam's
+ * history re-gathered by parent row with the newest position appended.  The score of key j gets add_const (+ causal_penalty for
+ * j > 0, as hirest_attention_f32_qkv does for query 0). */
+int hirest_attention_f32_decode(const float* q, int64_t ldq, const float* k_hist, const float* v_hist, int64_t ld_hist,
+                                const int32_t* parent, int32_t t_hist, const float* k_new, const float* v_new, int64_t ld_new,
+                                float* k_out, float* v_out, float* out, int32_t R, int32_t H, float scale, float add_const,
+                                float causal_penalty, void* stream);
 /* 0 (default) = the decoder step runs its LayerNorms and the token embedding as prologues of the GEMMs that consume them
- * (hirest_gemm_f32_ln), 1 = as separate kernels.  Same bits either way (tests / A-B timing). */
+ * (hirest_gemm_f32_ln) and its attentions as hirest_attention_f32_decode (history read in place), 1 = LayerNorm, embedding, K / V
+ * gather and hirest_attention_f32_qkv as separate kernels.  Same bits either way (tests / A-B timing). */
 int hirest_caption_select(int32_t mode);
 /* The same step up to the LM head: raw logits [R, vocab_padded] instead of log-probabilities (input of hirest_caption_beam_tail). */
 int hirest_caption_decode_logits(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,

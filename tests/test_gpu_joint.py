@@ -197,6 +197,38 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
         assert model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"] == ref, nb
 
 
+@pytest.mark.parametrize("t_hist,newkey,addc", [(0, True, 0.0), (5, True, 0.0), (31, True, 0.0), (32, True, 0.0), (47, True, 0.0), (70, True, 0.0),
+                                                 (20, False, -10000.0), (64, False, -10000.0)])
+def test_attention_f32_decode_equals_gather_then_attention(dev, t_hist, newkey, addc):
+    """hirest_attention_f32_decode (one wave per (row, head), history read through the parent row, vector FMAs in the MFMA's order)
+    against the gathered history + hirest_attention_f32_qkv: context rows and the re-gathered K / V bit for bit"""
+    from hirest_amd import _lib, ops
+    lib, st = _lib.load(), ops.stream_ptr()
+    R, H, D = 25, 12, 768
+    T = t_hist + (1 if newkey else 0)
+    qkv = synth.tensor(f"ad.q.{t_hist}", (R, 3 * D), 1.5, 4).to(dev)
+    kh = synth.tensor(f"ad.k.{t_hist}", (R, max(t_hist, 1), D), 1.5, 4).to(dev)
+    vh = synth.tensor(f"ad.v.{t_hist}", (R, max(t_hist, 1), D), 1.5, 4).to(dev)
+    parent = ((torch.arange(R) * 7 + 3) % R).to(torch.int32).to(dev) if newkey else None
+    # reference: gather the history by parent row, append the newest key, run the general kernel with Tq = 1
+    src = parent.long() if parent is not None else torch.arange(R, device=dev)
+    kcat = kh[src][:, :t_hist]; vcat = vh[src][:, :t_hist]
+    if newkey:
+        kcat = torch.cat([kcat, qkv[:, None, D:2 * D]], 1); vcat = torch.cat([vcat, qkv[:, None, 2 * D:]], 1)
+    kcat, vcat = kcat.contiguous(), vcat.contiguous()
+    ref = torch.empty((R, D), device=dev)
+    _lib.check(lib.hirest_attention_f32_qkv(qkv.data_ptr(), 3 * D, kcat.data_ptr(), vcat.data_ptr(), D, ref.data_ptr(), R, 1, T, H, 64, 0.125,
+                                            addc, 0.0, st), "attention")
+    out = torch.empty((R, D), device=dev)
+    ko = torch.full((R, T, D), 7.0, device=dev); vo = torch.full((R, T, D), 7.0, device=dev)
+    _lib.check(lib.hirest_attention_f32_decode(qkv.data_ptr(), 3 * D, kh.data_ptr() if t_hist else None, vh.data_ptr() if t_hist else None, D,
+                                               parent.data_ptr() if parent is not None else None, t_hist,
+                                               qkv.data_ptr() + 4 * D if newkey else None, qkv.data_ptr() + 8 * D if newkey else None, 3 * D,
+                                               ko.data_ptr(), vo.data_ptr(), out.data_ptr(), R, H, 0.125, addc, 0.0, st), "decode attention")
+    assert torch.equal(out, ref)
+    assert torch.equal(ko, kcat) and torch.equal(vo, vcat)
+
+
 @pytest.mark.parametrize("M,N,K,act,embed", [(25, 2304, 768, 0, True), (25, 768, 768, 0, False), (15, 3072, 768, 1, False), (7, 100, 256, 2, False),
                                              (32, 768, 1024, 3, True), (1, 36, 512, 0, False)])
 def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
