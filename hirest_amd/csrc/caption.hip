@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = c * (TAIL_CHUNK / 4) + tid + 256 * u;
-            const bool in = i < V4;
-            const f32x4 v = in ? *reinterpret_cast<const f32x4*>(xr + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool in = i < V4;                          // (loads are unconditional on a clamped index: a guarded load is a round trip of its own)
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * (in ? i : V4 - 1));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { val[4 * u + e] = v[e]; idx[4 * u + e] = in ? flat0 + 4 * i + e : -1; }
         }
@@ -149,20 +149,19 @@ __global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict_
     const int g = c - nsel;
     constexpr int NM = 32;                                   // vectors per thread for the row max: V <= 32768 (launcher)
     float mx = -INFINITY;
-    f32x4 mine[8];
+    f32x4 mine[8], all[NM];                                  // every load unconditional (clamped index) and issued before the first use
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = tid + 256 * g + 1024 * j;
-        mine[j] = i < V4 ? *reinterpret_cast<const f32x4*>(xr + 4 * i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        mine[j] = *reinterpret_cast<const f32x4*>(xr + 4 * (i < V4 ? i : V4 - 1));
     }
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         const int i = tid + 256 * m;
-        if (i < V4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
-            mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-        }
+        all[m] = *reinterpret_cast<const f32x4*>(xr + 4 * (i < V4 ? i : V4 - 1));
     }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) mx = fmaxf(fmaxf(mx, fmaxf(all[m][0], all[m][1])), fmaxf(all[m][2], all[m][3]));   // (a repeated element changes no max)
     mx = wave_max_x(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256) void tail_select_kernel(const float* __restric
     const int b = blockIdx.x, tid = threadIdx.x;
     if (done[b] != 0) {                                      // (block-uniform: written only by this block, in an earlier launch)
         if (tid < beam) { const int row = b * beam + tid; next_ids[row] = eos; next_parents[row] = row; next_add[row] = 0.f; }
-        if (tid == 0 && done_host) done_host[b] = 1;
+        if (tid == 0 && done_host) done_host[b] = ((step + 1) << 1) | 1;
         return;
     }
     if (tid < beam) {
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(256) void tail_select_kernel(const float* __restric
             n_steps[b] = step + 1;
             const int fin = word == eos ? 1 : 0;
             if (fin) done[b] = 1;                            // read by the NEXT launch only
-            if (done_host) done_host[b] = fin;
+            if (done_host) done_host[b] = ((step + 1) << 1) | fin;   // stamped: the host polls the word itself, no event per step
         }
     }
 }

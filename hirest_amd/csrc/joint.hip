@@ -960,7 +960,13 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
     switch (K / 256) {                                        // the whole K quarter of W in flight (K / 128 slabs per wave)
         case 1: return launch_m16ln<1, 2>(q, s);
         case 2: return launch_m16ln<2, 4>(q, s);
-        case 3: return N >= 2048 ? launch_m16ln<3, 3>(q, s) : launch_m16ln<3, 6>(q, s);   // many column tiles: two blocks per CU
+        case 3: {
+            static const int v_ln = getenv("HIREST_M16_LN") ? atoi(getenv("HIREST_M16_LN")) : 0;     // tuning experiments
+            if (v_ln == 1) return launch_m16ln<3, 6>(q, s);
+            if (v_ln == 2) return launch_m16ln<3, 3>(q, s);
+            if (v_ln == 3) return launch_m16ln<3, 2>(q, s);
+            return launch_m16ln<3, 2>(q, s);   // two slabs in flight per wave: 66 KB of LDS, two blocks per CU (measured best of 2 / 3 / 6)
+        }
         default: return launch_m16ln<4, 8>(q, s);
     }
 }

@@ -570,6 +570,11 @@ class MomentModel(nn.Module):
                                                    done.data_ptr(), ids.data_ptr(), parents.data_ptr(), add.data_ptr(), st),
                            "hirest_beam_advance")
                 done_host[t - 1].copy_(done, non_blocking=True)
+            if fused_tail:
+                # the kernel stamps each sample's word with its step: read whatever has arrived of two steps ago, never wait
+                if t >= 3 and all((v >> 1) == t - 2 and (v & 1) for v in done_host[t - 3].tolist()):
+                    break
+                continue
             copied[t - 1].record()
             if t >= 3:                                   # look at the flags of two steps ago: never waits for the GPU
                 copied[t - 3].synchronize()

@@ -442,7 +442,8 @@ int hirest_caption_decode_logits(const hirest_caption_decoder* d, int32_t R, int
  * hirest_log_softmax_f32), the top `beam` of every sample's beam x vocab scores (same strict order as hirest_topk_f32: higher
  * score, then higher flat index) and hirest_beam_advance's bookkeeping — without materialising the log-probabilities.  logits:
  * [B * beam, vocab] with row stride ldx, 16-byte aligned, vocab % 4 == 0, beam <= 16.  done_host (optional): pinned host int32 [B]
- * that receives this step's done flags.  The other arguments are hirest_beam_advance's. */
+ * that receives, per sample, ((step + 1) << 1) | done — one 4-byte store each, so a host that finds the stamp of step s in all B words
+ * has that step's flags without recording an event.  The other arguments are hirest_beam_advance's. */
 size_t hirest_caption_beam_tail_workspace_bytes(int32_t B, int32_t beam, int32_t vocab);
 int hirest_caption_beam_tail(const float* logits, int64_t ldx, const float* row_add, int32_t B, int32_t beam, int32_t vocab,
                              int32_t step, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr,

@@ -312,7 +312,7 @@ def test_beam_tail_equals_log_softmax_topk_advance(dev, B, beam, step):
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], b[k]), k
-    assert torch.equal(host, a["done"].cpu())
+    assert torch.equal(host & 1, a["done"].cpu()) and bool(((host >> 1) == step + 1).all())   # stamped with the step
     assert a["done"][B - 1].item() == 1                         # [SEP] on the best beam finished the last sample
 
 
