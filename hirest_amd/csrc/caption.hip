@@ -323,7 +323,18 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
         const hirest_caption_layer& Z = d->layer[d->layers - 1];
         CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, Z.ff_ln_g, Z.ff_ln_b, eps, nullptr, 0, d->tr_w, D, d->tr_b, nullptr, 0, x, D, R, D,
                               D, 1, stream));
-        CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
+        if (R <= 16) {
+            // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU).  With
+            // two row tiles per wave (R > 16) the persistent form has one wave per SIMD and nothing to cover its LDS round trips with:
+            // 40 us against 26 + 5 for the two kernels, so those keep the separate LayerNorm.
+            CK(hirest_gemm_f32_ln(x, D, nullptr, nullptr, nullptr, d->tr_ln_g, d->tr_ln_b, eps, nullptr, 0, d->lm_w, D, d->lm_b, nullptr, 0,
+                                  logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
+        } else {
+            CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
+            CK(hirest_gemm_f32(b, D, d->lm_w, D, d->lm_b, nullptr, 0, nullptr, 0, logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
+        }
+        if (logp) CK(hirest_log_softmax_f32(logits, d->vocab_padded, row_add, logp, d->vocab_padded, R, d->vocab_padded, stream));
+        return hirest_launch_status();
     } else {
         hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, s, pos, R, position);
         CK(hirest_embedding_pos_fwd_f32(last_ids, pos, d->word_emb, d->pos_emb, a, R, D, stream));

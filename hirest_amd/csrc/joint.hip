@@ -327,30 +327,30 @@ struct GemmLN {
     float* ln_out; int64_t ldl;
 };
 
-template <int NV, int DEPTH>
+template <int NV, int NT, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
     const GemmF& p = q.g;
-    constexpr int SLAB = 2048, L = 2;                        // W only: 16 rows x 128 B per slab, two LDS-DMA instructions
+    constexpr int SLAB = NT * 2048, L = 2 * NT;              // W only: NT x 16 rows x 128 B per slab, two LDS-DMA instructions per column tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A image (16 rows x astride), 4 x DEPTH x SLAB of W, reduction buffer
     const int astride = p.K * 4 + 128;                       // odd multiple of 128 B: row parity picks the bank half, as in the ring
     char* aimg = smem;
     char* ringbase = smem + 16 * astride;
-    f32x4 (*red)[64] = reinterpret_cast<f32x4 (*)[64]>(ringbase + 4 * DEPTH * SLAB);
+    f32x4 (*red)[NT][64] = reinterpret_cast<f32x4 (*)[NT][64]>(ringbase + 4 * DEPTH * SLAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15, slot = lane >> 4;
     // with ln_out, one extra column block (the last) only normalises its rows and writes them out: a store's round trip in a block
     // that also multiplies would be waited for together with its W slabs
     const bool ln_only = q.ln_out && blockIdx.x == gridDim.x - 1;
-    const int N0 = ln_only ? 0 : blockIdx.x * 16, M0 = blockIdx.y * 16;
+    const int N0 = ln_only ? 0 : blockIdx.x * 16 * NT, M0 = blockIdx.y * 16;
     const bool odd = slot >> 1;
     char* ring = ringbase + wave * DEPTH * SLAB;
     auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
     const char* src[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
-        const int trow = 8 * j + (lane >> 3);
+        const int trow = 8 * (j & 1) + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(trow);
-        int gn = N0 + trow; gn = gn < p.N ? gn : p.N - 1;
+        int gn = N0 + 16 * (j >> 1) + trow; gn = gn < p.N ? gn : p.N - 1;
         src[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * chunk;
     }
     const int nslab = p.K / FK;
@@ -421,19 +421,26 @@ __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
     int fo[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) fo[c] = ((4 * (slot & 1) + c) ^ swz(idx)) << 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto mm = [&](int s, int ringslot) {
         const char* wb = ring + ringslot * SLAB + idx * 128;
         const char* ab = aimg + idx * astride + (first + s) * 128;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const f32x4 aq = *reinterpret_cast<const f32x4*>(ab + fo[c]);
-            const f32x4 wq = *reinterpret_cast<const f32x4*>(wb + fo[c]);
+            f32x4 wq[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) wq[u] = *reinterpret_cast<const f32x4*>(wb + u * 2048 + fo[c]);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float a = odd ? aq[2 * e + 1] : aq[2 * e];
-                const float w = odd ? wq[2 * e + 1] : wq[2 * e];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, a, acc, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const float w = odd ? wq[u][2 * e + 1] : wq[u][2 * e];
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, a, acc[u], 0, 0, 0);
+                }
             }
         }
     };
@@ -457,23 +464,195 @@ __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave > 0) red[wave - 1][lane] = acc;
+    if (wave > 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) red[wave - 1][u][lane] = acc[u];
+    }
     __syncthreads();
     if (wave > 0) return;
-    const int n = N0 + 4 * slot, m = M0 + idx;
-    if (n >= p.N || m >= p.M) return;
-    epilogue_store4(p, ((acc + red[0][lane]) + red[1][lane]) + red[2][lane], m, n);
+    const int m = M0 + idx;
+    if (m >= p.M) return;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int n = N0 + 16 * u + 4 * slot;
+        if (n < p.N) epilogue_store4(p, ((acc[u] + red[0][u][lane]) + red[1][u][lane]) + red[2][u][lane], m, n);
+    }
 }
 
-template <int NV, int DEPTH>
+template <int NV, int NT, int DEPTH>
 int launch_m16ln(const GemmLN& q, hipStream_t s) {
     static HirestDevCfg cfg;
-    auto kern = gemm_f32_m16ln_kernel<NV, DEPTH>;
-    constexpr int LDS_MAX = 16 * (NV * 1024 + 128) + 4 * DEPTH * 2048 + 3 * 1024;
+    auto kern = gemm_f32_m16ln_kernel<NV, NT, DEPTH>;
+    constexpr int LDS_MAX = 16 * (NV * 1024 + 128) + 4 * DEPTH * NT * 2048 + 3 * NT * 1024;
     static_assert(LDS_MAX <= 160 * 1024, "does not fit the LDS");
     if (int e = hirest_configure(kern, LDS_MAX, cfg)) return e;
-    const int lds = 16 * (q.g.K * 4 + 128) + 4 * DEPTH * 2048 + 3 * 1024;
-    hipLaunchKernelGGL(kern, dim3((q.g.N + 15) / 16 + (q.ln_out ? 1 : 0), (q.g.M + 15) / 16), dim3(256), lds, s, q);
+    const int lds = 16 * (q.g.K * 4 + 128) + 4 * DEPTH * NT * 2048 + 3 * NT * 1024;
+    hipLaunchKernelGGL(kern, dim3((q.g.N + 16 * NT - 1) / (16 * NT) + (q.ln_out ? 1 : 0), (q.g.M + 15) / 16), dim3(256), lds, s, q);
+    return hirest_launch_status();
+}
+
+// The LM head (N = 30 522 columns): one PERSISTENT block per CU normalises the MT x 16 rows once, keeps them in LDS and walks its
+// share of the 32-column tiles with one continuous W stream per wave (the ring never drains between tiles; a block per tile
+// spent a third of its life in launch, first-slab latency and drain).  MT row tiles x 2 column tiles per wave; at a tile's end the
+// four K quarters meet in LDS and wave 0 stores while the others already multiply the next tile.
+template <int NV, int MT, int DEPTH>
+__global__ __launch_bounds__(256) void gemm_f32_m16ln_stream_kernel(GemmLN q) {
+    const GemmF& p = q.g;
+    constexpr int NT = 2, SLAB = NT * 2048, L = 2 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A image (M rows), 4 x DEPTH x SLAB of W, reduction buffer
+    const int astride = p.K * 4 + 128;
+    char* aimg = smem;
+    char* ringbase = smem + p.M * astride;                   // only the M real rows are kept: what that frees is W slabs in flight
+    f32x4 (*red)[MT * NT][64] = reinterpret_cast<f32x4 (*)[MT * NT][64]>(ringbase + 4 * DEPTH * SLAB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15, slot = lane >> 4;
+    const bool odd = slot >> 1;
+    char* ring = ringbase + wave * DEPTH * SLAB;
+    auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
+    const int ntile = (p.N + 16 * NT - 1) / (16 * NT);
+    const int mine = ((int)blockIdx.x < ntile) ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // tiles blockIdx.x + i gridDim.x
+    const int nslab = p.K / FK;
+    const int quarter = (nslab + 3) >> 2, first = wave * quarter;
+    int cnt = nslab - first; cnt = cnt < 0 ? 0 : (cnt > quarter ? quarter : cnt);
+    const int items = mine * cnt;                           // this wave's stream: (tile i, slab s), i-major
+    const int trow0 = lane >> 3, chunk_lane = lane & 7;
+    auto dma = [&](int it) {                                // item it -> ring slot it % DEPTH
+        const int i = it / cnt, sl = it - i * cnt;
+        const int N0 = ((int)blockIdx.x + i * (int)gridDim.x) * 16 * NT;
+        char* dst = ring + (it % DEPTH) * SLAB;
+        const int64_t koff = (int64_t)(first + sl) * (FK * 4);
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int trow = 8 * (j & 1) + trow0;
+            int gn = N0 + 16 * (j >> 1) + trow; gn = gn < p.N ? gn : p.N - 1;
+            glds16(reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * (chunk_lane ^ swz(trow)) + koff, dst + j * 1024);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)
+        if (u < items) dma(u);
+    // LayerNorm of rows 4 (MT wave + b) .. + 3, b < MT, by this wave (see gemm_f32_m16ln_kernel)
+    {
+        const int nv = p.K >> 2;
+        f32x4 gam[NV], bet[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            gam[i] = *reinterpret_cast<const f32x4*>(q.gamma + 4 * (lane + 64 * i));
+            bet[i] = *reinterpret_cast<const f32x4*>(q.beta + 4 * (lane + 64 * i));
+        }
+#pragma unroll
+        for (int bt = 0; bt < MT; ++bt) {
+            f32x4 v[4][NV];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int m = 4 * (MT * wave + bt) + rr; m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(q.X + (int64_t)m * q.ldx + 4 * (lane + 64 * i));
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int rl = 4 * (MT * wave + bt) + rr;
+                float mean, rstd;
+                ln_wave_stats<NV>(v[rr], nv, p.K, q.eps, lane, mean, rstd);
+                if (rl < p.M) {                                  // (wave-uniform)
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        const int c = lane + 64 * i;
+                        *reinterpret_cast<f32x4*>(aimg + rl * astride + (c >> 3) * 128 + (((c & 7) ^ swz(rl)) << 4)) =
+                            ln_apply(v[rr][i], mean, rstd, gam[i], bet[i]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fo[c] = ((4 * (slot & 1) + c) ^ swz(idx)) << 4;
+    f32x4 acc[NT][MT];
+    int arow[MT];                                            // rows past M read row M - 1 (same swizzle class is not needed: never stored)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { const int m = 16 * t + idx; arow[t] = (m < p.M ? m : p.M - 1) * astride; }
+    int fa[MT][4];                                           // fragment offsets inside the A image: the swizzle follows the row actually read
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = 16 * t + idx, mr = m < p.M ? m : p.M - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fa[t][c] = arow[t] + (((4 * (slot & 1) + c) ^ swz(mr)) << 4);
+    }
+    auto mm = [&](int sl, int ringslot) {
+        const char* wb = ring + ringslot * SLAB + idx * 128;
+        const char* ab = aimg + (first + sl) * 128;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 aq[MT], wq[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) aq[t] = *reinterpret_cast<const f32x4*>(ab + fa[t][c]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) wq[u] = *reinterpret_cast<const f32x4*>(wb + u * 2048 + fo[c]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float a[MT], w[NT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[t] = odd ? aq[t][2 * e + 1] : aq[t][2 * e];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) w[u] = odd ? wq[u][2 * e + 1] : wq[u][2 * e];
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], a[t], acc[u][t], 0, 0, 0);
+            }
+        }
+    };
+    int it = 0;
+    for (int i = 0; i < mine; ++i) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < cnt; ++sl, ++it) {
+            // slabs it .. min(it + DEPTH, items) - 1 are in flight, in order: the oldest has landed once at most the others are pending
+            if (items - it >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            mm(sl, it % DEPTH);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's fragment reads have returned before it is refilled
+            if (it + DEPTH < items) dma(it + DEPTH);
+        }
+        __syncthreads();                                     // the previous tile's sums have been read
+        if (wave > 0) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) red[wave - 1][u * MT + t][lane] = acc[u][t];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int N0 = ((int)blockIdx.x + i * (int)gridDim.x) * 16 * NT;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int n = N0 + 16 * u + 4 * slot;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int m = 16 * t + idx;
+                    if (m < p.M) epilogue_store4(p, ((acc[u][t] + red[0][u * MT + t][lane]) + red[1][u * MT + t][lane]) + red[2][u * MT + t][lane], m, n);
+                }
+            }
+        }
+    }
+}
+
+template <int NV, int MT, int DEPTH, int MMAX>
+int launch_m16ln_stream(const GemmLN& q, hipStream_t s) {
+    static HirestDevCfg cfg;
+    int cus = 0;
+    auto kern = gemm_f32_m16ln_stream_kernel<NV, MT, DEPTH>;
+    constexpr int LDS_MAX = MMAX * (NV * 1024 + 128) + 4 * DEPTH * 4096 + 3 * MT * 2 * 1024;
+    static_assert(LDS_MAX <= 160 * 1024, "does not fit the LDS");
+    if (int e = hirest_configure(kern, LDS_MAX, cfg, &cus)) return e;
+    const int lds = q.g.M * (q.g.K * 4 + 128) + 4 * DEPTH * 4096 + 3 * MT * 2 * 1024;
+    const int ntile = (q.g.N + 31) / 32;
+    hipLaunchKernelGGL(kern, dim3(ntile < cus ? ntile : cus), dim3(256), lds, s, q);
     return hirest_launch_status();
 }
 
@@ -957,17 +1136,19 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
     GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act}, X, ldx, ids, table, pos_row, gamma, beta, eps,
              ln_out, ldl};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (K / 256) {                                        // the whole K quarter of W in flight (K / 128 slabs per wave)
-        case 1: return launch_m16ln<1, 2>(q, s);
-        case 2: return launch_m16ln<2, 4>(q, s);
-        case 3: {
-            static const int v_ln = getenv("HIREST_M16_LN") ? atoi(getenv("HIREST_M16_LN")) : 0;     // tuning experiments
-            if (v_ln == 1) return launch_m16ln<3, 6>(q, s);
-            if (v_ln == 2) return launch_m16ln<3, 3>(q, s);
-            if (v_ln == 3) return launch_m16ln<3, 2>(q, s);
-            return launch_m16ln<3, 2>(q, s);   // two slabs in flight per wave: 66 KB of LDS, two blocks per CU (measured best of 2 / 3 / 6)
-        }
-        default: return launch_m16ln<4, 8>(q, s);
+    static const int v_ln = getenv("HIREST_M16_LN") ? atoi(getenv("HIREST_M16_LN")) : 0;     // tuning experiments
+    if (N >= 8192 && K == 768 && !ids && !ln_out && v_ln != 3)          // the LM head: persistent blocks, rows normalised once per CU
+        return M <= 16 ? launch_m16ln_stream<3, 1, 6, 16>(q, s) : M <= 26 ? launch_m16ln_stream<3, 2, 4, 26>(q, s) : launch_m16ln_stream<3, 2, 3, 32>(q, s);
+    if (N >= 8192) return HIREST_E_SHAPE;
+    switch (K / 256) {
+        case 1: return launch_m16ln<1, 1, 2>(q, s);
+        case 2: return launch_m16ln<2, 1, 2>(q, s);
+        case 3:
+            // two W slabs in flight per wave (66 KB of LDS, two blocks per CU: measured best of 2 / 3 / 6; two column tiles per wave
+            // for the wide layers: no better)
+            if (v_ln == 2) return launch_m16ln<3, 2, 2>(q, s);
+            return launch_m16ln<3, 1, 2>(q, s);
+        default: return launch_m16ln<4, 1, 2>(q, s);
     }
 }
 

@@ -229,7 +229,7 @@ def test_attention_f32_decode_equals_gather_then_attention(dev, t_hist, newkey, 
     assert torch.equal(ko, kcat) and torch.equal(vo, vcat)
 
 
-@pytest.mark.parametrize("M,N,K,act,embed", [(25, 2304, 768, 0, True), (25, 768, 768, 0, False), (15, 3072, 768, 1, False), (7, 100, 256, 2, False),
+@pytest.mark.parametrize("M,N,K,act,embed", [(25, 30528, 768, 0, False), (15, 30528, 768, 0, False), (32, 8200, 768, 1, False), (25, 2304, 768, 0, True), (25, 768, 768, 0, False), (15, 3072, 768, 1, False), (7, 100, 256, 2, False),
                                              (32, 768, 1024, 3, True), (1, 36, 512, 0, False)])
 def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
     """hirest_gemm_f32_ln (LayerNorm / token + position embedding as the GEMM's prologue) against hirest_embedding_pos_fwd_f32 +
@@ -256,11 +256,12 @@ def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
     ref = MomentModel._gemm(ln, w, bias, resid=resid, act=act)
     out = torch.empty((M, N), device=dev)
     ln2 = torch.empty((M, K), device=dev)
+    want_ln = N < 8192                                          # the LM-head form (persistent blocks) is taken without ln_out
     _lib.check(lib.hirest_gemm_f32_ln(None if embed else x.data_ptr(), K, ids.data_ptr() if embed else None,
                                       table.data_ptr() if embed else None, pos[9].data_ptr() if embed else None, g.data_ptr(), be.data_ptr(),
-                                      1e-12, ln2.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), resid.data_ptr(), N, out.data_ptr(), N, M, N, K,
-                                      act, st), "gemm_ln")
-    assert torch.equal(ln2, ln)
+                                      1e-12, ln2.data_ptr() if want_ln else None, K, w.data_ptr(), K, bias.data_ptr(), resid.data_ptr(), N,
+                                      out.data_ptr(), N, M, N, K, act, st), "gemm_ln")
+    assert not want_ln or torch.equal(ln2, ln)
     assert torch.equal(out, ref)
     assert lib.hirest_gemm_f32_ln(x.data_ptr(), K, None, None, None, g.data_ptr(), be.data_ptr(), 1e-12, None, 0, w.data_ptr(), K, None, None, 0,
                                   out.data_ptr(), N, 33, N, K, act, st) == -2          # more than 32 rows: HIREST_E_SHAPE
