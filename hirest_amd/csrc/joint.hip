@@ -491,168 +491,176 @@ int launch_m16ln(const GemmLN& q, hipStream_t s) {
     return hirest_launch_status();
 }
 
-// The LM head (N = 30 522 columns): one PERSISTENT block per CU normalises the MT x 16 rows once, keeps them in LDS and walks its
-// share of the 32-column tiles with one continuous W stream per wave (the ring never drains between tiles; a block per tile
-// spent a third of its life in launch, first-slab latency and drain).  MT row tiles x 2 column tiles per wave; at a tile's end the
-// four K quarters meet in LDS and wave 0 stores while the others already multiply the next tile.
-template <int NV, int MT, int DEPTH>
-__global__ __launch_bounds__(256) void gemm_f32_m16ln_stream_kernel(GemmLN q) {
+// The LM head (N = 30 522 columns, 94 MB of weights per word): one PERSISTENT block per CU.  It normalises the rows once (four per
+// wave, through an LDS image), and every wave then takes the A fragments of ITS K quarter into registers for good (MT x 48 floats,
+// already selected for the lane's k slots) — the rows are the same for every column tile.  From there on only W moves: each wave
+// streams its quarter of the block's 16-column tiles through a private LDS-DMA ring that never drains between tiles, D0 slabs of
+// it in a fixed region that starts filling at launch, D1 more in the space the A image occupied.  With 25 rows that is 8 slabs
+// (16 KB) in flight per wave against 2-3 for a kernel that keeps A in LDS, a third of its LDS reads and no per-tile launch,
+// first-slab latency and drain.  G groups of four waves (the K quarters) own separate tile sequences; G = MT, so the 4 G waves hold
+// the 16 MT rows of the LayerNorm prologue.  At a tile's end a group's quarters meet in LDS and its wave 0 stores while the others
+// already multiply the next tile.
+template <int NV, int MT, int D0, int D1>
+__global__ __launch_bounds__(256 * MT) void gemm_f32_m16ln_stream_kernel(GemmLN q) {
     const GemmF& p = q.g;
-    constexpr int NT = 2, SLAB = NT * 2048, L = 2 * NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // A image (M rows), 4 x DEPTH x SLAB of W, reduction buffer
+    constexpr int G = MT, SLAB = 2048, L = 2, DEPTH = D0 + D1, NS = 2 * NV;   // NS slabs per K quarter (K = 256 NV)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A image (M rows; later D1 slabs per wave), 4 G x D0 slabs, reduction buffers
     const int astride = p.K * 4 + 128;
     char* aimg = smem;
-    char* ringbase = smem + p.M * astride;                   // only the M real rows are kept: what that frees is W slabs in flight
-    f32x4 (*red)[MT * NT][64] = reinterpret_cast<f32x4 (*)[MT * NT][64]>(ringbase + 4 * DEPTH * SLAB);
+    char* fixed = smem + p.M * astride;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, kq = wave & 3;
+    f32x4 (*red)[MT][64] = reinterpret_cast<f32x4 (*)[MT][64]>(fixed + 4 * G * D0 * SLAB) + 3 * grp;
     const int idx = lane & 15, slot = lane >> 4;
     const bool odd = slot >> 1;
-    char* ring = ringbase + wave * DEPTH * SLAB;
+    char* ring0 = fixed + wave * D0 * SLAB;                  // ring slots 0 .. D0 - 1
+    char* ring1 = aimg + wave * D1 * SLAB;                   // ring slots D0 .. DEPTH - 1 (once the image has been read)
+    auto slot_ptr = [&](int rs) { return rs < D0 ? ring0 + rs * SLAB : ring1 + (rs - D0) * SLAB; };
     auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
-    const int ntile = (p.N + 16 * NT - 1) / (16 * NT);
-    const int mine = ((int)blockIdx.x < ntile) ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // tiles blockIdx.x + i gridDim.x
-    const int nslab = p.K / FK;
-    const int quarter = (nslab + 3) >> 2, first = wave * quarter;
-    int cnt = nslab - first; cnt = cnt < 0 ? 0 : (cnt > quarter ? quarter : cnt);
-    const int items = mine * cnt;                           // this wave's stream: (tile i, slab s), i-major
+    const int ntile = (p.N + 15) / 16;
+    const int tile0 = (int)blockIdx.x * G + grp, tstep = (int)gridDim.x * G;      // this group's tiles: tile0 + i tstep
+    const int mine = tile0 < ntile ? (ntile - 1 - tile0) / tstep + 1 : 0;
+    const int most = (int)blockIdx.x * G < ntile ? (ntile - 1 - (int)blockIdx.x * G) / tstep + 1 : 0;   // group 0's count = the block's barrier count
+    const int first = kq * NS;
+    const int items = mine * NS;                             // this wave's stream: (tile i, slab sl), i-major
+    // producer side of the stream: the next item to request is slab psl of tile pi, into ring slot prs.  The two row pointers of a
+    // lane (LDS-DMA instruction j moves rows 8 j .. 8 j + 7 of the tile) change once per tile; per slab only the k offset moves.
     const int trow0 = lane >> 3, chunk_lane = lane & 7;
-    auto dma = [&](int it) {                                // item it -> ring slot it % DEPTH
-        const int i = it / cnt, sl = it - i * cnt;
-        const int N0 = ((int)blockIdx.x + i * (int)gridDim.x) * 16 * NT;
-        char* dst = ring + (it % DEPTH) * SLAB;
-        const int64_t koff = (int64_t)(first + sl) * (FK * 4);
+    const char* wrow[L];
+    auto tile_rows = [&](int i) {
 #pragma unroll
         for (int j = 0; j < L; ++j) {
-            const int trow = 8 * (j & 1) + trow0;
-            int gn = N0 + 16 * (j >> 1) + trow; gn = gn < p.N ? gn : p.N - 1;
-            glds16(reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * (chunk_lane ^ swz(trow)) + koff, dst + j * 1024);
+            const int trow = 8 * j + trow0;
+            int gn = (tile0 + i * tstep) * 16 + trow; gn = gn < p.N ? gn : p.N - 1;
+            wrow[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * (chunk_lane ^ swz(trow)) + (int64_t)first * (FK * 4);
         }
     };
+    int psl = 0, pi = 0, prs = 0, issued = 0;
+    tile_rows(0);
+    auto dma = [&]() {
+        char* dst = slot_ptr(prs);
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u)
-        if (u < items) dma(u);
-    // LayerNorm of rows 4 (MT wave + b) .. + 3, b < MT, by this wave (see gemm_f32_m16ln_kernel)
+        for (int j = 0; j < L; ++j) glds16(wrow[j] + psl * (FK * 4), dst + j * 1024);
+        ++issued;
+        prs = prs + 1 == DEPTH ? 0 : prs + 1;
+        if (++psl == NS) { psl = 0; ++pi; tile_rows(pi); }   // (rows past the last tile are clamped: never requested)
+    };
+#pragma unroll
+    for (int u = 0; u < D0; ++u)
+        if (issued < items) dma();
+    // LayerNorm of rows 4 wave .. 4 wave + 3 by this wave (see gemm_f32_m16ln_kernel)
     {
         const int nv = p.K >> 2;
-        f32x4 gam[NV], bet[NV];
+        f32x4 gam[NV], bet[NV], v[4][NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             gam[i] = *reinterpret_cast<const f32x4*>(q.gamma + 4 * (lane + 64 * i));
             bet[i] = *reinterpret_cast<const f32x4*>(q.beta + 4 * (lane + 64 * i));
         }
 #pragma unroll
-        for (int bt = 0; bt < MT; ++bt) {
-            f32x4 v[4][NV];
+        for (int rr = 0; rr < 4; ++rr) {
+            int m = 4 * wave + rr; m = m < p.M ? m : p.M - 1;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                int m = 4 * (MT * wave + bt) + rr; m = m < p.M ? m : p.M - 1;
+            for (int i = 0; i < NV; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(q.X + (int64_t)m * q.ldx + 4 * (lane + 64 * i));
+        }
 #pragma unroll
-                for (int i = 0; i < NV; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(q.X + (int64_t)m * q.ldx + 4 * (lane + 64 * i));
-            }
+        for (int rr = 0; rr < 4; ++rr) {
+            const int rl = 4 * wave + rr;
+            float mean, rstd;
+            ln_wave_stats<NV>(v[rr], nv, p.K, q.eps, lane, mean, rstd);
+            if (rl < p.M) {                                  // (wave-uniform)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int rl = 4 * (MT * wave + bt) + rr;
-                float mean, rstd;
-                ln_wave_stats<NV>(v[rr], nv, p.K, q.eps, lane, mean, rstd);
-                if (rl < p.M) {                                  // (wave-uniform)
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        const int c = lane + 64 * i;
-                        *reinterpret_cast<f32x4*>(aimg + rl * astride + (c >> 3) * 128 + (((c & 7) ^ swz(rl)) << 4)) =
-                            ln_apply(v[rr][i], mean, rstd, gam[i], bet[i]);
-                    }
+                for (int i = 0; i < NV; ++i) {
+                    const int c = lane + 64 * i;
+                    *reinterpret_cast<f32x4*>(aimg + rl * astride + (c >> 3) * 128 + (((c & 7) ^ swz(rl)) << 4)) =
+                        ln_apply(v[rr][i], mean, rstd, gam[i], bet[i]);
                 }
             }
         }
     }
     __syncthreads();
-    int fo[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) fo[c] = ((4 * (slot & 1) + c) ^ swz(idx)) << 4;
-    f32x4 acc[NT][MT];
-    int arow[MT];                                            // rows past M read row M - 1 (same swizzle class is not needed: never stored)
-#pragma unroll
-    for (int t = 0; t < MT; ++t) { const int m = 16 * t + idx; arow[t] = (m < p.M ? m : p.M - 1) * astride; }
-    int fa[MT][4];                                           // fragment offsets inside the A image: the swizzle follows the row actually read
+    // this wave's A fragments for good: row tile t, slab sl, instruction 2 c + e -> the lane's k slot (rows past M read row M - 1)
+    float af[MT][NS][8];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = 16 * t + idx, mr = m < p.M ? m : p.M - 1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) fa[t][c] = arow[t] + (((4 * (slot & 1) + c) ^ swz(mr)) << 4);
+        for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 aq = *reinterpret_cast<const f32x4*>(aimg + mr * astride + (first + sl) * 128 + (((4 * (slot & 1) + c) ^ swz(mr)) << 4));
+                af[t][sl][2 * c] = odd ? aq[1] : aq[0];
+                af[t][sl][2 * c + 1] = odd ? aq[3] : aq[2];
+            }
     }
-    auto mm = [&](int sl, int ringslot) {
-        const char* wb = ring + ringslot * SLAB + idx * 128;
-        const char* ab = aimg + (first + sl) * 128;
+    __syncthreads();                                         // the image is dead: its space becomes ring slots D0 .. DEPTH - 1
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x4 aq[MT], wq[NT];
+    for (int u = D0; u < DEPTH; ++u)
+        if (issued < items) dma();
+    // W fragment of instruction 2 c + e: the lane's k slot is element 2 e + odd of chunk 4 (slot & 1) + c -> two dwords 8 B apart
+    // from a per-lane address (one ds_read2_b32, no select)
+    int fo[4];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) aq[t] = *reinterpret_cast<const f32x4*>(ab + fa[t][c]);
+    for (int c = 0; c < 4; ++c) fo[c] = idx * 128 + (((4 * (slot & 1) + c) ^ swz(idx)) << 4) + (odd ? 4 : 0);
+    f32x4 acc[MT];
+    int it = 0, rs = 0;
+    for (int i = 0; i < most; ++i) {
+        const bool have = i < mine;                          // (group-uniform; a group without a tile i still meets the barriers)
 #pragma unroll
-            for (int u = 0; u < NT; ++u) wq[u] = *reinterpret_cast<const f32x4*>(wb + u * 2048 + fo[c]);
+        for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (have) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float a[MT], w[NT];
+            for (int sl = 0; sl < NS; ++sl, ++it) {
+                // slabs it .. min(it + DEPTH, items) - 1 are in flight, in order: the oldest has landed once at most the others are pending
+                if (items - it >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const char* wb = slot_ptr(rs);
+                float wq[4][2];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) a[t] = odd ? aq[t][2 * e + 1] : aq[t][2 * e];
+                for (int c = 0; c < 4; ++c) {
+                    const float* wp = reinterpret_cast<const float*>(wb + fo[c]);
+                    wq[c][0] = wp[0]; wq[c][1] = wp[2];
+                }
 #pragma unroll
-                for (int u = 0; u < NT; ++u) w[u] = odd ? wq[u][2 * e + 1] : wq[u][2 * e];
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int u = 0; u < NT; ++u)
+                    for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], a[t], acc[u][t], 0, 0, 0);
+                        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c][e], af[t][sl][2 * c + e], acc[t], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's fragment reads have returned before it is refilled
+                rs = rs + 1 == DEPTH ? 0 : rs + 1;
+                if (issued < items) dma();
             }
         }
-    };
-    int it = 0;
-    for (int i = 0; i < mine; ++i) {
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int sl = 0; sl < cnt; ++sl, ++it) {
-            // slabs it .. min(it + DEPTH, items) - 1 are in flight, in order: the oldest has landed once at most the others are pending
-            if (items - it >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * L) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            mm(sl, it % DEPTH);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's fragment reads have returned before it is refilled
-            if (it + DEPTH < items) dma(it + DEPTH);
-        }
         __syncthreads();                                     // the previous tile's sums have been read
-        if (wave > 0) {
+        if (have && kq > 0) {
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
-#pragma unroll
-                for (int t = 0; t < MT; ++t) red[wave - 1][u * MT + t][lane] = acc[u][t];
+            for (int t = 0; t < MT; ++t) red[kq - 1][t][lane] = acc[t];
         }
         __syncthreads();
-        if (wave == 0) {
-            const int N0 = ((int)blockIdx.x + i * (int)gridDim.x) * 16 * NT;
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                const int n = N0 + 16 * u + 4 * slot;
-                if (n >= p.N) continue;
+        if (have && kq == 0) {
+            const int n = (tile0 + i * tstep) * 16 + 4 * slot;
+            if (n < p.N) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const int m = 16 * t + idx;
-                    if (m < p.M) epilogue_store4(p, ((acc[u][t] + red[0][u * MT + t][lane]) + red[1][u * MT + t][lane]) + red[2][u * MT + t][lane], m, n);
+                    if (m < p.M) epilogue_store4(p, ((acc[t] + red[0][t][lane]) + red[1][t][lane]) + red[2][t][lane], m, n);
                 }
             }
         }
     }
 }
 
-template <int NV, int MT, int DEPTH, int MMAX>
-int launch_m16ln_stream(const GemmLN& q, hipStream_t s) {
+template <int NV, int MT, int D0, int D1>
+int launch_m16ln_stream(const GemmLN& q, hipStream_t s, int lds_max) {
     static HirestDevCfg cfg;
     int cus = 0;
-    auto kern = gemm_f32_m16ln_stream_kernel<NV, MT, DEPTH>;
-    constexpr int LDS_MAX = MMAX * (NV * 1024 + 128) + 4 * DEPTH * 4096 + 3 * MT * 2 * 1024;
-    static_assert(LDS_MAX <= 160 * 1024, "does not fit the LDS");
-    if (int e = hirest_configure(kern, LDS_MAX, cfg, &cus)) return e;
-    const int lds = q.g.M * (q.g.K * 4 + 128) + 4 * DEPTH * 4096 + 3 * MT * 2 * 1024;
-    const int ntile = (q.g.N + 31) / 32;
-    hipLaunchKernelGGL(kern, dim3(ntile < cus ? ntile : cus), dim3(256), lds, s, q);
+    auto kern = gemm_f32_m16ln_stream_kernel<NV, MT, D0, D1>;
+    if (int e = hirest_configure(kern, lds_max, cfg, &cus)) return e;
+    const int lds = q.g.M * (q.g.K * 4 + 128) + 4 * MT * D0 * 2048 + 3 * MT * MT * 1024;
+    if (lds > lds_max || 4 * MT * D1 * 2048 > q.g.M * (q.g.K * 4 + 128)) return HIREST_E_SHAPE;
+    const int ntile = (q.g.N + 15) / 16, nblk = (ntile + MT - 1) / MT;
+    hipLaunchKernelGGL(kern, dim3(nblk < cus ? nblk : cus), dim3(256 * MT), lds, s, q);
     return hirest_launch_status();
 }
 
@@ -1138,7 +1146,19 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const int v_ln = getenv("HIREST_M16_LN") ? atoi(getenv("HIREST_M16_LN")) : 0;     // tuning experiments
     if (N >= 8192 && K == 768 && !ids && !ln_out && v_ln != 3)          // the LM head: persistent blocks, rows normalised once per CU
-        return M <= 16 ? launch_m16ln_stream<3, 1, 6, 16>(q, s) : M <= 26 ? launch_m16ln_stream<3, 2, 4, 26>(q, s) : launch_m16ln_stream<3, 2, 3, 32>(q, s);
+    {
+        // ring depth: D0 slabs per wave in the fixed region + D1 in the space of the A image (M rows x 3200 B shared by 4 MT waves)
+        constexpr int MAXLDS = 160 * 1024;
+        if (M <= 2) return launch_m16ln_stream<3, 1, 8, 0>(q, s, MAXLDS);
+        if (M <= 5) return launch_m16ln_stream<3, 1, 8, 1>(q, s, MAXLDS);
+        if (M <= 7) return launch_m16ln_stream<3, 1, 8, 2>(q, s, MAXLDS);
+        if (M <= 10) return launch_m16ln_stream<3, 1, 8, 3>(q, s, MAXLDS);
+        if (M <= 12) return launch_m16ln_stream<3, 1, 8, 4>(q, s, MAXLDS);
+        if (M <= 16) return launch_m16ln_stream<3, 1, 8, 5>(q, s, MAXLDS);
+        if (M <= 20) return launch_m16ln_stream<3, 2, 4, 3>(q, s, MAXLDS);
+        if (M <= 26) return launch_m16ln_stream<3, 2, 4, 4>(q, s, MAXLDS);
+        return launch_m16ln_stream<3, 2, 2, 5>(q, s, MAXLDS);
+    }
     if (N >= 8192) return HIREST_E_SHAPE;
     switch (K / 256) {
         case 1: return launch_m16ln<1, 1, 2>(q, s);

@@ -20,7 +20,7 @@ batch = {"tasks": ["step_captioning"], "vis_feats": vis.to(dev), "vis_mask": vis
 beams = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 model.test_step(batch, num_beams=beams)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-reps = 10
+reps = int(os.environ.get("CAPTION_REPS", "10"))
 for _ in range(reps):
     model.test_step(batch, num_beams=beams)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
