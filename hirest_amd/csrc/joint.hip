@@ -8,6 +8,7 @@
 // whole model is still a few hundred microseconds.
 #include "common.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -1109,6 +1110,8 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
+    static const bool log_shapes = getenv("HIREST_GEMM_LOG") != nullptr;   // which problems a workload issues (stderr)
+    if (log_shapes) fprintf(stderr, "gemm_f32 M %d N %d K %d\n", M, N, K);
     if (M <= 32 && K % FK == 0 && g_f32_kernel == 0) {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         // few column tiles (the decoder's 768- / 3072-wide layers): one row tile per block, so 2 x N / 16 blocks share the

@@ -56,6 +56,16 @@ def test_argument_errors_without_gpu(lib):
     assert lib.hirest_pool_l2norm_varlen(None, None, None, 1, 384, None) == -1
     assert lib.hirest_embedding_pos_fwd_f32(None, None, None, None, None, 1, 384, None) == -1
     assert lib.hirest_gemm_f32_select_kernel(3) == -1 and lib.hirest_gemm_f32_select_kernel(0) == 0
+    # round 3: the step-captioning decode kernels
+    assert lib.hirest_caption_select(2) == -1 and lib.hirest_caption_select(0) == 0
+    assert lib.hirest_caption_decode_logits(ctypes.byref(d), 25, 0, None, None, None, None, None, 20, None, None, 0, None) == -1
+    assert lib.hirest_caption_beam_tail_workspace_bytes(5, 5, 30528) == 25 * 8 * 5 * 8 + 25 * 17 * 4     # candidates (score, index) + row statistics
+    assert lib.hirest_caption_beam_tail_workspace_bytes(0, 5, 30528) == 0
+    assert lib.hirest_caption_beam_tail(None, 30528, None, 5, 5, 30528, 0, 48, 102, None, None, None, None, None, None, None, None, None, None, 0,
+                                        None) == -1
+    assert lib.hirest_gemm_f32_ln(None, 768, None, None, None, None, None, 1e-12, None, 0, None, 768, None, None, 0, None, 768, 25, 768, 768, 0,
+                                  None) == -1
+    assert lib.hirest_attention_f32_decode(None, 768, None, None, 768, None, 0, None, None, 0, None, None, None, 25, 12, 0.125, 0.0, 0.0, None) == -1
 
 
 def test_workspace_size_formula(lib):

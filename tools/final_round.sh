@@ -15,4 +15,9 @@ bash tools/pmc_traffic.sh $out/pmc_traffic.json > $out/pmc_traffic.log 2>&1; hea
 bash tools/pmc_sq.sh $out/pmcsq "gemm_|attention_kernel" -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-matched-recall --no-secondary > $out/pmc_bench_counters.txt 2>&1
 python tools/pmc_summary.py $out/pmc_bench_counters.txt > $out/pmc_table_bench.md; rm -rf $out/pmcsq; cat $out/pmc_table_bench.md | cut -c1-200
 python tools/secondary_bench.py > $out/secondary.json 2> $out/secondary.err; head -c 400 $out/secondary.json
+# step captioning: captions/s (3 runs), kernel timeline of one word, SQ counters of its kernels; the two probes its kernels rest on
+bash tools/caption_round.sh > $out/caption_round.log 2>&1; cp gpurun_out/capt/word_timeline.txt $out/caption_word_timeline.txt; cp gpurun_out/capt/captions.txt $out/caption_captions_per_s.txt
+CAPTION_REPS=1 bash tools/pmc_sq.sh $out/pmccap "m16|attention_f32_decode|tail_" -- python $GRAFT_REPO_ROOT/tools/caption_profile.py 5 > $out/pmc_caption_kernels.txt 2>&1; rm -rf $out/pmccap
+for pr in fma_order_probe wave_sum_probe lane_path_probe; do hipcc --offload-arch=gfx950 -O2 -w -o /tmp/$pr tools/probes/$pr.hip && timeout 60 /tmp/$pr > $out/$pr.txt 2>&1; done
+timeout 120 python tools/lm_head_probe.py > $out/lm_head_probe.txt 2>&1
 date +%s > $out/collected_at
