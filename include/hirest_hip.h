@@ -345,9 +345,9 @@ int hirest_text_forward_f32(const hirest_text_tower_f32* t, const int64_t* token
 int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                     const float* resid, int64_t ldr, const float* periodic, int32_t period,
                     float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
-/* 0 = automatic (M <= 32 rows and K % 32 == 0: 16-column tiles of v_mfma_f32_16x16x4_f32, four waves share K; M <= 256: the
- * split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the 64x64 kernel, 2 = automatic without the 16-column
- * kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */
+/* 0 = automatic (M <= 256 rows and K % 32 == 0 [and N < 8192 above 32 rows]: 16-column tiles of v_mfma_f32_16x16x4_f32, four waves
+ * share K, operands by LDS-DMA; other M <= 256: the split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the
+ * 64x64 kernel, 2 = automatic without the 16-column kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */
 int hirest_gemm_f32_select_kernel(int32_t which);
 /* out = act(LayerNorm(X; gamma, beta, eps) @ W^T + bias) (+ resid) for M <= 32 rows, K % 256 == 0, K <= 1024: the rows are
  * normalised inside the GEMM with hirest_layernorm's own arithmetic (same bits as the two calls), and written to ln_out as well

@@ -26,8 +26,8 @@ def dev():
                                        (25, 30528, 768, 0), (5, 768, 768, 1), (256, 100, 1504, 0), (33, 36, 48, 2), (15, 2304, 768, 3),
                                        (32, 20, 64, 0), (17, 768, 3072, 1)])
 def test_gemm_f32(dev, M, N, K, act, kernel):
-    """automatic mode: M <= 32 takes the 16-column kernel (K % 32 == 0), M <= 256 the split-K 32x32 kernel, the rest the 64x64
-    kernel; mode 1 forces the 64x64 kernel, mode 2 is automatic without the 16-column kernel"""
+    """automatic mode: M <= 256 takes the 16-column kernel when K % 32 == 0 (N < 8192 above 32 rows), else the split-K 32x32 kernel,
+    the rest the 64x64 kernel; mode 1 forces the 64x64 kernel, mode 2 is automatic without the 16-column kernel"""
     from hirest_amd import _lib
     from hirest_amd.moment_model import MomentModel
     _lib.check(_lib.load().hirest_gemm_f32_select_kernel(kernel), "select")
