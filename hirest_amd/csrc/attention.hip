@@ -453,8 +453,9 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
                 }
                 mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // (the lane ^ 16 / lane ^ 32 partners through v_permlane16_swap / v_permlane32_swap instead of two ds_bpermute round trips
+            //  on the LDS pipe this kernel keeps busy: common.h, wave_max_x)
+            { float pa = mx, pb = mx; lane_swap16(pa, pb); mx = fmaxf(pa, pb); pa = mx; pb = mx; lane_swap32(pa, pb); mx = fmaxf(pa, pb); }
             // p = 2^(s*c - mx*c): one fma + one v_exp_f32 per score (arguments are <= 0; underflow flushes to 0)
             const float nmc = -mx * scale_log2e;
             float sum = 0.f;
@@ -477,8 +478,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel_v3(const bf16_t* __r
                     }
                 }
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            { float pa = sum, pb = sum; lane_swap16(pa, pb); sum = pa + pb; pa = sum; pb = sum; lane_swap32(pa, pb); sum = pa + pb; }
             const float inv = 1.0f / sum;
             if (!v_ready) {
                 wait_vm_le(nk_next);                 // V(h) pieces are older than the K(h+1) pieces (and the new Q loads)

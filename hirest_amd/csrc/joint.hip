@@ -30,20 +30,33 @@ struct GemmF {
 constexpr int FK = 32, FLD = FK + 1;      // K is staged 32 deep; K itself only has to be a multiple of 16 (zero fill)
 
 // The one epilogue of every fp32 GEMM kernel below (same expressions -> same bits): four consecutive columns n .. n + 3 of row m.
-__device__ __forceinline__ void epilogue_store4(const GemmF& p, f32x4 v, int m, int n) {
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+// Its operands are fetched apart from their use — unconditionally, on clamped indices — so that a kernel can have all of them
+// travelling at once, or from its first instruction: fetched where they are used, every `if (p.bias) v += load` is a memory round
+// trip of its own at the very end of a kernel (two per tile: 1-2 us of a 5-us decode GEMM).
+struct Epi4 { f32x4 bias, resid, periodic; };
+__device__ __forceinline__ Epi4 epilogue_fetch4(const GemmF& p, int m, int n) {      // m, n may lie outside: the values are then unused
+    Epi4 e;
+    const int mc = m < p.M ? m : p.M - 1, nc = n + 4 <= p.N ? n : p.N - 4;            // N % 4 == 0
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    e.bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : zero;
+    e.resid = p.resid ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)mc * p.ldr + nc) : zero;
+    e.periodic = p.periodic ? *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(mc % p.period) * p.N + nc) : zero;
+    return e;
+}
+__device__ __forceinline__ void epilogue_apply4(const GemmF& p, f32x4 v, const Epi4& e, int m, int n) {
+    if (p.bias) v += e.bias;
     if (p.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        for (int e_ = 0; e_ < 4; ++e_) v[e_] = 0.5f * v[e_] * (1.0f + erff(v[e_] * 0.70710678118654752440f));
     } else if (p.act == 2) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        for (int e_ = 0; e_ < 4; ++e_) v[e_] = tanhf(v[e_]);
     } else if (p.act == 3) {                      // QuickGELU (model.py:175-177), the fp32 reference-precision towers
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-1.702f * v[e])));
+        for (int e_ = 0; e_ < 4; ++e_) v[e_] = v[e_] * (1.0f / (1.0f + expf(-1.702f * v[e_])));
     }
-    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
-    if (p.periodic) v += *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(m % p.period) * p.N + n);
+    if (p.resid) v += e.resid;
+    if (p.periodic) v += e.periodic;
     *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
 }
 
@@ -113,12 +126,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
         }
     }
     const int m = M0 + wm * 32 + (lane & 31);
+    Epi4 ep[4];                                              // the four column groups' operands in one burst
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ep[g] = epilogue_fetch4(p, m, N0 + wn * 32 + 8 * g + 4 * (lane >> 5));
     if (m >= p.M) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int n = N0 + wn * 32 + 8 * g + 4 * (lane >> 5);
         if (n >= p.N) continue;
-        epilogue_store4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, m, n);
+        epilogue_apply4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, ep[g], m, n);
     }
 }
 
@@ -175,12 +191,15 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = ((acc[e] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
     const int m = M0 + row;
+    Epi4 ep[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ep[g] = epilogue_fetch4(p, m, N0 + 8 * g + 4 * khalf);
     if (m >= p.M) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int n = N0 + 8 * g + 4 * khalf;
         if (n >= p.N) continue;
-        epilogue_store4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, m, n);
+        epilogue_apply4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, ep[g], m, n);
     }
 }
 
@@ -219,6 +238,13 @@ __global__ __launch_bounds__(256) void gemm_f32_m16_kernel(GemmF p) {
             int gn = N0 + 16 * (tile - MT) + trow; gn = gn < p.N ? gn : p.N - 1;
             src[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * chunk;
         }
+    }
+    Epi4 ep[NT][MT];                                                    // wave 0 stores: its epilogue operands start travelling now
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) ep[u][t] = epilogue_fetch4(p, M0 + 16 * t + idx, N0 + 16 * u + 4 * slot);
     }
     const int nslab = p.K / FK;                                         // K % 32 == 0 (launcher)
     const int quarter = (nslab + 3) >> 2, first = wave * quarter;      // this wave's K quarter (see gemm_f32_kernel)
@@ -299,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_f32_m16_kernel(GemmF p) {
         for (int t = 0; t < MT; ++t) {
             const int m = M0 + 16 * t + idx;
             if (m >= p.M) continue;
-            epilogue_store4(p, ((acc[u][t] + red[0][u * MT + t][lane]) + red[1][u * MT + t][lane]) + red[2][u * MT + t][lane], m, n);
+            epilogue_apply4(p, ((acc[u][t] + red[0][u * MT + t][lane]) + red[1][u * MT + t][lane]) + red[2][u * MT + t][lane], ep[u][t], m, n);
         }
     }
 }
@@ -353,6 +379,11 @@ __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
         const int chunk = (lane & 7) ^ swz(trow);
         int gn = N0 + 16 * (j >> 1) + trow; gn = gn < p.N ? gn : p.N - 1;
         src[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * chunk;
+    }
+    Epi4 ep[NT];                                             // wave 0 stores: its epilogue operands start travelling now
+    if (wave == 0 && !ln_only) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) ep[u] = epilogue_fetch4(p, M0 + idx, N0 + 16 * u + 4 * slot);
     }
     const int nslab = p.K / FK;
     const int quarter = (nslab + 3) >> 2, first = wave * quarter;
@@ -476,7 +507,7 @@ __global__ __launch_bounds__(256) void gemm_f32_m16ln_kernel(GemmLN q) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const int n = N0 + 16 * u + 4 * slot;
-        if (n < p.N) epilogue_store4(p, ((acc[u] + red[0][u][lane]) + red[1][u][lane]) + red[2][u][lane], m, n);
+        if (n < p.N) epilogue_apply4(p, ((acc[u] + red[0][u][lane]) + red[1][u][lane]) + red[2][u][lane], ep[u], m, n);
     }
 }
 
@@ -609,6 +640,11 @@ __global__ __launch_bounds__(256 * MT) void gemm_f32_m16ln_stream_kernel(GemmLN 
         const bool have = i < mine;                          // (group-uniform; a group without a tile i still meets the barriers)
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Epi4 ep[MT];                                         // the storing wave's epilogue operands travel under the tile's slabs
+        if (have && kq == 0) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) ep[t] = epilogue_fetch4(p, 16 * t + idx, (tile0 + i * tstep) * 16 + 4 * slot);
+        }
         if (have) {
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl, ++it) {
@@ -645,7 +681,7 @@ __global__ __launch_bounds__(256 * MT) void gemm_f32_m16ln_stream_kernel(GemmLN 
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const int m = 16 * t + idx;
-                    if (m < p.M) epilogue_store4(p, ((acc[t] + red[0][t][lane]) + red[1][t][lane]) + red[2][t][lane], m, n);
+                    if (m < p.M) epilogue_apply4(p, ((acc[t] + red[0][t][lane]) + red[1][t][lane]) + red[2][t][lane], ep[t], m, n);
                 }
             }
         }
@@ -710,9 +746,15 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const int q = qb * 128 + wave * 32 + l31;
     const bool qvalid = q < Tq;
     // Q^T fragments: B operand [k = d][j = query]: lane holds Q[q][2s + half] for s = 0..DHP/2-1
+    // (every load unconditional on a clamped index, the zero chosen afterwards: a guarded load is a memory round trip of its own)
     float qf[DHP / 2];
+    const float* qrow = qbase + (int64_t)(qvalid ? q : Tq - 1) * ldq;
 #pragma unroll
-    for (int s = 0; s < DHP / 2; ++s) qf[s] = (qvalid && 2 * s + half < dh) ? qbase[(int64_t)q * ldq + 2 * s + half] : 0.f;
+    for (int s = 0; s < DHP / 2; ++s) {
+        const int d = 2 * s + half;
+        const float v = qrow[d < dh ? d : dh - 1];
+        qf[s] = (qvalid && d < dh) ? v : 0.f;
+    }
     f32x16 o[NO];    // O^T rows d = 32 j .. 32 j + 31, column = query
 #pragma unroll
     for (int j = 0; j < NO; ++j)
@@ -725,8 +767,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         for (int i = tid; i < 32 * (DHP / 4); i += 256) {   // 32 keys x DHP/4 float4
             const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
             const int key = k0 + kr < T ? k0 + kr : T - 1;
-            const f32x4 kv = c < dh ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + c) : zero4;
-            const f32x4 vv = c < dh ? *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + c) : zero4;
+            const int cc = c < dh ? c : dh - 4;                  // (dh % 4 == 0: a 4-vector is inside or outside the head as a whole)
+            f32x4 kv = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + cc);
+            f32x4 vv = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + cc);
+            if (c >= dh) { kv = zero4; vv = zero4; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Ks[kr * ALD + c + e] = kv[e]; Vs[kr * ALD + c + e] = vv[e]; }
         }
@@ -745,13 +789,13 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             st[r] = sv;
             tmax = fmaxf(tmax, sv);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        { float pa = tmax, pb = tmax; lane_swap32(pa, pb); tmax = fmaxf(pa, pb); }   // the other half-wave's keys (common.h: wave_max_x)
         const float mnew = fmaxf(mrun, tmax);
         const float alpha = __expf(mrun - mnew);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float pz = __expf(st[r] - mnew); st[r] = pz; psum += pz; }
-        psum += __shfl_xor(psum, 32, 64);
+        { float pa = psum, pb = psum; lane_swap32(pa, pb); psum = pa + pb; }
         lrun = attn_lsum(lrun, alpha, psum);
         mrun = mnew;
 #pragma unroll
