@@ -113,20 +113,59 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float* dr = dy + (int64_t)row * D;
     float s = 0.f;
     for (int c = lane; c < D; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / D;
+    const float mean = wave_sum_x(s) / D;
     float q = 0.f;
     for (int c = lane; c < D; c += 64) { const float d = xr[c] - mean; q = fmaf(d, d, q); }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_x(q) / D + eps);
     float a = 0.f, b = 0.f;
     for (int c = lane; c < D; c += 64) {
         const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
         a += g; b = fmaf(g, xh, b);
     }
-    a = wave_sum(a) / D; b = wave_sum(b) / D;
+    a = wave_sum_x(a) / D; b = wave_sum_x(b) / D;
     for (int c = lane; c < D; c += 64) {
         const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
         dx[(int64_t)row * D + c] = rstd * (g - a - xh * b);
         dyxhat[(int64_t)row * D + c] = dr[c] * xh;
+    }
+}
+
+// NE = D / 64 elements per lane held in registers (one burst of loads; the generic form below re-reads the row four times);
+// same element -> lane assignment, same order of every sum: same bits.
+template <int NE>
+__global__ __launch_bounds__(256) void layernorm_bwd_regs_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ gamma, float eps, float* __restrict__ dx,
+                                                                 float* __restrict__ dyxhat, int R, int D) {
+    const int lane = threadIdx.x & 63;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = row < R;
+    row = live ? row : R - 1;                                // (no early exit in front of the cross-lane reductions; stores are guarded)
+    const float* xr = x + (int64_t)row * D;
+    const float* dr = dy + (int64_t)row * D;
+    float xv[NE], dv[NE], gv[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { xv[i] = xr[lane + 64 * i]; dv[i] = dr[lane + 64 * i]; gv[i] = gamma[lane + 64 * i]; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) s += xv[i];
+    const float mean = wave_sum_x(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { const float d = xv[i] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum_x(q) / D + eps);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const float xh = (xv[i] - mean) * rstd, g = dv[i] * gv[i];
+        a += g; b = fmaf(g, xh, b);
+    }
+    a = wave_sum_x(a) / D; b = wave_sum_x(b) / D;
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const float xh = (xv[i] - mean) * rstd, g = dv[i] * gv[i];
+        dx[(int64_t)row * D + lane + 64 * i] = rstd * (g - a - xh * b);
+        dyxhat[(int64_t)row * D + lane + 64 * i] = dv[i] * xh;
     }
 }
 
@@ -163,10 +202,10 @@ __global__ __launch_bounds__(64) void attention_train_fwd_kernel(AttnT a, float*
         prow[j] = s;
         mx = fmaxf(mx, s);
     }
-    mx = wave_max(mx);
+    mx = wave_max_x(mx);
     float sum = 0.f;
     for (int j = lane; j < a.Tk; j += 64) { const float e = __expf(prow[j] - mx); prow[j] = e; sum += e; }
-    sum = wave_sum(sum);
+    sum = wave_sum_x(sum);
     const float inv = 1.0f / sum;
     for (int j = lane; j < a.Tk; j += 64) prow[j] *= inv;
     __syncthreads();                                      // one wave: orders the row's global writes before the re-reads below
@@ -201,7 +240,7 @@ __global__ __launch_bounds__(64) void attention_train_bwd_q_kernel(AttnT a, cons
         dsrow[j] = dp;
         delta = fmaf(prow[j], dp, delta);
     }
-    delta = wave_sum(delta);
+    delta = wave_sum_x(delta);
     for (int j = lane; j < a.Tk; j += 64) dsrow[j] = prow[j] * (dsrow[j] - delta);
     __syncthreads();
     float acc = 0.f;
@@ -349,10 +388,10 @@ __global__ __launch_bounds__(256) void attn_softmax_rows_kernel(float* __restric
     float* pr = P + row * Tk;
     float mx = -3.0e38f;
     for (int j = lane; j < Tk; j += 64) mx = fmaxf(mx, pr[j]);
-    mx = wave_max(mx);
+    mx = wave_max_x(mx);
     float sum = 0.f;
     for (int j = lane; j < Tk; j += 64) { const float e = __expf(pr[j] - mx); pr[j] = e; sum += e; }
-    sum = wave_sum(sum);
+    sum = wave_sum_x(sum);
     const float inv = 1.0f / sum;
     for (int j = lane; j < Tk; j += 64) pr[j] *= inv;
 }
@@ -366,7 +405,7 @@ __global__ __launch_bounds__(256) void attn_ds_rows_kernel(const float* __restri
     float* dr = dS + row * Tk;
     float delta = 0.f;
     for (int j = lane; j < Tk; j += 64) delta = fmaf(pr[j], dr[j], delta);
-    delta = wave_sum(delta);
+    delta = wave_sum_x(delta);
     for (int j = lane; j < Tk; j += 64) dr[j] = pr[j] * (dr[j] - delta);
 }
 
@@ -473,7 +512,7 @@ __global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict_
     const float* dr = dtn + (int64_t)b * E;
     float q = 0.f, d = 0.f;
     for (int e = lane; e < E; e += 64) { q = fmaf(tr[e], tr[e], q); d = fmaf(tr[e], dr[e], d); }
-    q = wave_sum(q); d = wave_sum(d);
+    q = wave_sum_x(q); d = wave_sum_x(d);
     const float inv = 1.0f / sqrtf(q);
     for (int e = lane; e < E; e += 64) dt[(int64_t)b * E + e] = (dr[e] - tr[e] * inv * (d * inv)) * inv;
 }
@@ -503,10 +542,10 @@ __global__ __launch_bounds__(64) void ce_masked_kernel(const float* __restrict__
     const float NEG = -3.4028234663852886e38f;
     float mx = NEG;
     for (int t = lane; t < T; t += 64) mx = fmaxf(mx, mr[t] ? lr[t] : NEG);
-    mx = wave_max(mx);
+    mx = wave_max_x(mx);
     float sum = 0.f;
     for (int t = lane; t < T; t += 64) sum += __expf((mr[t] ? lr[t] : NEG) - mx);
-    sum = wave_sum(sum);
+    sum = wave_sum_x(sum);
     const float lse = mx + __logf(sum);
     const int tg = target[b];
     for (int t = lane; t < T; t += 64) {
@@ -569,7 +608,12 @@ extern "C" int hirest_dropout_add_f32(const float* x, const float* resid, float*
 extern "C" int hirest_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dyxhat,
                                         int32_t R, int32_t D, void* stream) {
     if (!x || !dy || !gamma || !dx || !dyxhat || R <= 0 || D <= 0) return HIREST_E_BADARG;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, S_(stream), x, dy, gamma, eps, dx, dyxhat, R, D);
+    const dim3 grid((R + 3) / 4), blk(256);
+    if (D == 768) hipLaunchKernelGGL(layernorm_bwd_regs_kernel<12>, grid, blk, 0, S_(stream), x, dy, gamma, eps, dx, dyxhat, R, D);
+    else if (D == 512) hipLaunchKernelGGL(layernorm_bwd_regs_kernel<8>, grid, blk, 0, S_(stream), x, dy, gamma, eps, dx, dyxhat, R, D);
+    else if (D == 384) hipLaunchKernelGGL(layernorm_bwd_regs_kernel<6>, grid, blk, 0, S_(stream), x, dy, gamma, eps, dx, dyxhat, R, D);
+    else if (D == 1024) hipLaunchKernelGGL(layernorm_bwd_regs_kernel<16>, grid, blk, 0, S_(stream), x, dy, gamma, eps, dx, dyxhat, R, D);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel, grid, blk, 0, S_(stream), x, dy, gamma, eps, dx, dyxhat, R, D);
     return hirest_launch_status();
 }
 

@@ -20,4 +20,7 @@ bash tools/caption_round.sh > $out/caption_round.log 2>&1; cp gpurun_out/capt/wo
 CAPTION_REPS=1 bash tools/pmc_sq.sh $out/pmccap "m16|attention_f32_decode|tail_" -- python $GRAFT_REPO_ROOT/tools/caption_profile.py 5 > $out/pmc_caption_kernels.txt 2>&1; rm -rf $out/pmccap
 for pr in fma_order_probe wave_sum_probe lane_path_probe; do hipcc --offload-arch=gfx950 -O2 -w -o /tmp/$pr tools/probes/$pr.hip && timeout 60 /tmp/$pr > $out/$pr.txt 2>&1; done
 timeout 120 python tools/lm_head_probe.py > $out/lm_head_probe.txt 2>&1
+# training step: timings (reference optimizer call and fused=True), kernel stats of the retrieval step
+bash tools/train_round.sh > $out/train_round.log 2>&1; cp gpurun_out/train/train_bench.txt $out/train_bench.txt
+bash tools/train_prof.sh > $out/train_prof.log 2>&1; cp gpurun_out/train/train_kernel_stats.csv $out/rocprofv3_kernel_stats_train_step.csv
 date +%s > $out/collected_at

@@ -148,6 +148,12 @@ def measure(dev=None, cpu=True, log=lambda m: None):
            "includes": "train_step + backward + clip_grad_norm_ + AdamW over the 63 M trainable parameters",
            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_step": flops}}
+    try:      # the same loop with torch.optim.AdamW(fused=True) (the caller's option; trainer_base.py:56 uses the class' defaults)
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, fused=True)
+        dtf, _ = _timeit(step, 10, sync)
+        ent["ms_per_step_with_fused_adamw"] = dtf * 1e3
+    except Exception as e:      # noqa: BLE001 (an optimizer option this torch build may not have)
+        ent["ms_per_step_with_fused_adamw"] = None
     if cpu:
         psd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
         t0 = time.perf_counter()

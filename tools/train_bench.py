@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--frames", type=int, nargs="*", default=[120, 300, 571])
     ap.add_argument("--batch", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--fused", action="store_true", help="also time the loop with torch.optim.AdamW(fused=True)")
+    ap.add_argument("--tasks", nargs="*", default=None, help="subset of moment_retrieval moment_segmentation step_captioning")
     a = ap.parse_args()
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", "joint_schema.json"))).items()}
     sd = synth.joint_state_dict(shapes, 31)
@@ -30,7 +32,12 @@ def main():
     model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
     model.load_state_dict(sd, strict=False)
     model = model.to(dev).train()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    # trainer_base.py:56 builds torch.optim.AdamW with its defaults (the for-each implementation: ~6 passes over the 63 M parameters);
+    # --fused adds a second line with the same class' fused=True option, which is the caller's choice, not a kernel of this repo
+    params = [p for p in model.parameters() if p.requires_grad]
+    opts = {"AdamW": torch.optim.AdamW(params, lr=1e-5)}
+    if a.fused:
+        opts["AdamW(fused=True)"] = torch.optim.AdamW(params, lr=1e-5, fused=True)
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     B = a.batch
     for T in a.frames:
@@ -48,23 +55,26 @@ def main():
             "step_captioning": dict(common, tasks=["step_captioning"], moment_mask=cap_mask,
                                     target_text=caption_targets(f"tb.{T}", B, 48, 61)),
         }
-        line = f"T={T:4d} B={B}:"
-        for task, batch in batches.items():
-            def step():
-                opt.zero_grad(set_to_none=True)
-                loss = model.train_step(batch)["loss"]
-                loss.backward()
-                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-                opt.step()
-                return loss
-            step(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(a.reps):
-                step()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / a.reps
-            line += f"  {task} {dt * 1e3:6.1f} ms/step ({B / dt:6.0f} videos/s)"
-        print(line, flush=True)
+        if a.tasks:
+            batches = {k: v for k, v in batches.items() if k in a.tasks}
+        for oname, opt in opts.items():
+            line = f"T={T:4d} B={B} {oname}:"
+            for task, batch in batches.items():
+                def step():
+                    opt.zero_grad(set_to_none=True)
+                    loss = model.train_step(batch)["loss"]
+                    loss.backward()
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                    opt.step()
+                    return loss
+                step(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.reps):
+                    step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / a.reps
+                line += f"  {task} {dt * 1e3:6.1f} ms/step ({B / dt:6.0f} videos/s)"
+            print(line, flush=True)
         if T <= 300:   # CPU oracle under autograd, retrieval loss only (the other two scale alike)
             psd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
             t0 = time.perf_counter()
