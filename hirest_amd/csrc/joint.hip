@@ -25,6 +25,7 @@ struct GemmF {
     const float* periodic; int period;
     float* out; int64_t ldo;
     int M, N, K, act;   // act: 0 none, 1 gelu (erf), 2 tanh, 3 quick-gelu
+    float* ws;          // gemm_f32_kernel only: not NULL = blockIdx.z is a K quarter whose partial sum goes to ws[z][M][N] (split form)
 };
 
 constexpr int FK = 32, FLD = FK + 1;      // K is staged 32 deep; K itself only has to be a multiple of 16 (zero fill)
@@ -98,10 +99,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     f32x4 av[2], wv[2];
-    fetch(0, av, wv);
     const int quarter = (nslab + 3) >> 2;
+    // split form (few tiles for the CUs: a 768-wide layer over 1500 rows is 288): one block per (tile, quarter), the partial sums
+    // meet in gemm_f32_quarters_kernel in the same order ((p0 + p1) + p2) + p3 — same bits
+    const int ub = p.ws ? (int)blockIdx.z : 0, ue = p.ws ? ub + 1 : 4;
+    const int s_last = p.ws ? ((ub + 1) * quarter < nslab ? (ub + 1) * quarter : nslab) : nslab;   // no slab of another block's quarter is fetched
+    if (ub * quarter < nslab) fetch(ub * quarter * FK, av, wv);
 #pragma unroll 1
-    for (int u = 0; u < 4; ++u) {                             // partial sum u: slabs u * quarter .. (u + 1) * quarter - 1
+    for (int u = ub; u < ue; ++u) {                           // partial sum u: slabs u * quarter .. (u + 1) * quarter - 1
         f32x16 part;
 #pragma unroll
         for (int e = 0; e < 16; ++e) part[e] = 0.f;
@@ -114,16 +119,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { As[srow * FLD + spos + 2 * (4 * h + e)] = av[h][e]; Ws[srow * FLD + spos + 2 * (4 * h + e)] = wv[h][e]; }
             __syncthreads();
-            if (sl + 1 < nslab) fetch((sl + 1) * FK, av, wv);
+            if (sl + 1 < s_last) fetch((sl + 1) * FK, av, wv);
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 part = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + 2 * j], As[arow + 2 * j], part, 0, 0, 0);
         }
-        if (u == 0) acc = part;
+        if (u == ub) acc = part;
         else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] += part[e];
         }
+    }
+    if (p.ws) {                                              // split form: the raw partial sum of quarter ub
+        const int m = M0 + wm * 32 + (lane & 31);
+        if (m >= p.M) return;
+        float* wrow_out = p.ws + ((int64_t)ub * p.M + m) * p.N;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = N0 + wn * 32 + 8 * g + 4 * (lane >> 5);
+            if (n < p.N) *reinterpret_cast<f32x4*>(wrow_out + n) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        }
+        return;
     }
     const int m = M0 + wm * 32 + (lane & 31);
     Epi4 ep[4];                                              // the four column groups' operands in one burst
@@ -136,6 +152,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
         if (n >= p.N) continue;
         epilogue_apply4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, ep[g], m, n);
     }
+}
+
+// second half of the split form: out = epilogue(((p0 + p1) + p2) + p3), four columns per thread
+__global__ __launch_bounds__(256) void gemm_f32_quarters_kernel(GemmF p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = p.N >> 2;
+    if (i >= (int64_t)p.M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+    const Epi4 ep = epilogue_fetch4(p, m, n);
+    const int64_t q = (int64_t)p.M * p.N, o = (int64_t)m * p.N + n;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(p.ws + o), p1 = *reinterpret_cast<const f32x4*>(p.ws + q + o);
+    const f32x4 p2 = *reinterpret_cast<const f32x4*>(p.ws + 2 * q + o), p3 = *reinterpret_cast<const f32x4*>(p.ws + 3 * q + o);
+    epilogue_apply4(p, ((p0 + p1) + p2) + p3, ep, m, n);
 }
 
 // Few rows (M <= 256: beam-search decoding, 5-25 rows per step): the 64x64 kernel above runs as a handful of blocks whose K loop
@@ -1153,7 +1182,7 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
                                float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
-    GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act};
+    GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act, nullptr};
     static const bool log_shapes = getenv("HIREST_GEMM_LOG") != nullptr;   // which problems a workload issues (stderr)
     if (log_shapes) fprintf(stderr, "gemm_f32 M %d N %d K %d\n", M, N, K);
     // 33 .. 256 rows (the sentence encoder's batches, the captioning task's training rows): the same kernel, 32-row tiles across
@@ -1186,13 +1215,41 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     return hirest_launch_status();
 }
 
+// Split form of the 64x64 kernel for problems with few tiles (see gemm_f32_kernel): taken for 256 < M, at most 512 tiles, K >= 1024
+// (same box, B = 5, T = 300: segmentation 330 -> 371 videos/s, retrieval 5400 -> 5800, training step 5.85 -> 5.55 ms; thresholds of
+// 512 .. 2048 for K and 400 .. 1200 tiles measure the same: the gain is the K = 3072 layer)
+static bool splits(int M, int N, int K) {
+    static const int mink = getenv("HIREST_SPLIT_MINK") ? atoi(getenv("HIREST_SPLIT_MINK")) : 1024;          // tuning experiments
+    static const int maxt = getenv("HIREST_SPLIT_MAXTILES") ? atoi(getenv("HIREST_SPLIT_MAXTILES")) : 512;
+    const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+    return g_f32_kernel == 0 && M > 256 && tiles <= maxt && K >= mink;
+}
+extern "C" size_t hirest_gemm_f32_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    return (M > 0 && N > 0 && K > 0 && splits(M, N, K)) ? (size_t)4 * M * N * 4 : 0;
+}
+extern "C" int hirest_gemm_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* resid,
+                                  int64_t ldr, const float* periodic, int32_t period, float* out, int64_t ldo, int32_t M, int32_t N,
+                                  int32_t K, int32_t act, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
+    if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
+    const size_t need = hirest_gemm_f32_workspace_bytes(M, N, K);
+    if (need == 0 || !workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+        return hirest_gemm_f32(A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act, stream);
+    GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act, static_cast<float*>(workspace)};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, 4), dim3(256), 0, s, p);
+    const int64_t n = (int64_t)M * (N / 4);
+    hipLaunchKernelGGL(gemm_f32_quarters_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    return hirest_launch_status();
+}
+
 extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* ids, const float* table, const float* pos_row,
                                   const float* gamma, const float* beta, float eps, float* ln_out, int64_t ldl, const float* W,
                                   int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M,
                                   int32_t N, int32_t K, int32_t act, void* stream) {
     if ((!X && !(ids && table && pos_row)) || !gamma || !beta || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     if (M > 32 || K % 256 != 0 || K > 1024 || N % 4 != 0 || ldw % 4 != 0 || (X && ldx % 4 != 0) || (ln_out && ldl % 4 != 0)) return HIREST_E_SHAPE;
-    GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act}, X, ldx, ids, table, pos_row, gamma, beta, eps,
+    GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act, nullptr}, X, ldx, ids, table, pos_row, gamma, beta, eps,
              ln_out, ldl};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const int v_ln = getenv("HIREST_M16_LN") ? atoi(getenv("HIREST_M16_LN")) : 0;     // tuning experiments

@@ -210,3 +210,19 @@ def topk(scores: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
     _lib.check(lib.hirest_topk_f32(_dev(scores, torch.float32, "topk.scores"), _opt(tie_rank, torch.int32, "topk.tie_rank"),
                                    Q, V, k, idx.data_ptr(), val.data_ptr(), stream_ptr()), "hirest_topk_f32")
     return val, idx
+
+
+_F32_GEMM_WS = {}
+
+
+def f32_gemm_workspace(device, nbytes: int):
+    """Scratch for hirest_gemm_f32_ws (the split form of few-tile fp32 GEMMs), one buffer per device, grown on demand; every user is
+    on the current stream, in order, so sharing it is safe.  Returns (pointer, bytes) — (None, 0) when the problem wants none."""
+    if nbytes <= 0:
+        return None, 0
+    key = (device.type, device.index)
+    buf = _F32_GEMM_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 32 << 20), dtype=torch.uint8, device=device)
+        _F32_GEMM_WS[key] = buf
+    return buf.data_ptr(), buf.numel()

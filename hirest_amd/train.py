@@ -47,10 +47,11 @@ class _K:
         M, K = a.shape
         N = w.shape[0]
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-        _chk(lib.hirest_gemm_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
-                                 resid.data_ptr() if resid is not None else None, N,
-                                 periodic.data_ptr() if periodic is not None else None, period,
-                                 out.data_ptr(), N, M, N, K, act, ops.stream_ptr()), "hirest_gemm_f32")
+        ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_workspace_bytes(M, N, K))
+        _chk(lib.hirest_gemm_f32_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
+                                    resid.data_ptr() if resid is not None else None, N,
+                                    periodic.data_ptr() if periodic is not None else None, period,
+                                    out.data_ptr(), N, M, N, K, act, ws, wsb, ops.stream_ptr()), "hirest_gemm_f32_ws")
         return out
 
     @staticmethod

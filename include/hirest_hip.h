@@ -345,6 +345,14 @@ int hirest_text_forward_f32(const hirest_text_tower_f32* t, const int64_t* token
 int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                     const float* resid, int64_t ldr, const float* periodic, int32_t period,
                     float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+/* hirest_gemm_f32 with scratch memory: problems of few 64x64 tiles (256 < M, at most 512 tiles, K >= 1024 — a 768-wide layer over
+ * 1500 rows is 288 tiles for 256 CUs) run one block per (tile, K quarter) into the workspace and a second kernel adds the four
+ * partial sums in the kernel's own order, so the result has the same bits.  hirest_gemm_f32_workspace_bytes returns what the
+ * problem wants (0: the plain form is taken); a missing / short workspace falls back to hirest_gemm_f32. */
+size_t hirest_gemm_f32_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int hirest_gemm_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                       const float* periodic, int32_t period, float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* 0 = automatic (M <= 256 rows and K % 32 == 0 [and N < 8192 above 32 rows]: 16-column tiles of v_mfma_f32_16x16x4_f32, four waves
  * share K, operands by LDS-DMA; other M <= 256: the split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the
  * 64x64 kernel, 2 = automatic without the 16-column kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */

@@ -66,6 +66,9 @@ def test_argument_errors_without_gpu(lib):
     assert lib.hirest_gemm_f32_ln(None, 768, None, None, None, None, None, 1e-12, None, 0, None, 768, None, None, 0, None, 768, 25, 768, 768, 0,
                                   None) == -1
     assert lib.hirest_attention_f32_decode(None, 768, None, None, 768, None, 0, None, None, 0, None, None, None, 25, 12, 0.125, 0.0, 0.0, None) == -1
+    assert lib.hirest_gemm_f32_workspace_bytes(1500, 768, 3072) == 4 * 1500 * 768 * 4       # 288 tiles: split over the four K quarters
+    assert lib.hirest_gemm_f32_workspace_bytes(1500, 3072, 768) == 0 and lib.hirest_gemm_f32_workspace_bytes(25, 768, 3072) == 0
+    assert lib.hirest_gemm_f32_ws(None, 768, None, 768, None, None, 0, None, 0, None, 768, 1500, 768, 3072, 0, None, 0, None) == -1
 
 
 def test_workspace_size_formula(lib):

@@ -58,7 +58,7 @@ def test_gemm_f32_kernels_share_their_summation_order(dev):
     from hirest_amd.moment_model import MomentModel
     lib = _lib.load()
     for M, N, K in ((200, 768, 768), (25, 30528, 768), (256, 132, 3072), (77, 512, 1040), (25, 768, 3072), (15, 2304, 768), (9, 36, 64),
-                    (32, 3072, 768), (16, 768, 96)):
+                    (32, 3072, 768), (16, 768, 96), (1500, 768, 768), (1500, 768, 3072), (300, 512, 1040), (1500, 100, 528)):   # the last four: split form
         a = synth.tensor("jo.a", (M, K), 1.0, 2).to(dev)
         w = synth.tensor("jo.w", (N, K), 0.05, 2).to(dev)
         b = synth.tensor("jo.b", (N,), 0.3, 2).to(dev)
