@@ -42,12 +42,17 @@ def fusion_flops_per_token():
 
 
 def _timeit(fn, reps, sync):
+    """best of two groups of `reps` calls after one warm-up call (a one-off allocator growth is not the operation)"""
     fn(); sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        out = fn()
-    sync()
-    return (time.perf_counter() - t0) / reps, out
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        sync()
+        dt = (time.perf_counter() - t0) / reps
+        best = dt if best is None else min(best, dt)
+    return best, out
 
 
 def measure(dev=None, cpu=True, log=lambda m: None):
