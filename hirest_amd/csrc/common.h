@@ -127,7 +127,9 @@ __device__ __forceinline__ float wave_max_x(float v) {
 
 // LayerNorm of one row held by one wave (lane owns float4 number lane + 64 i of the row, zeros past the row's nv = D / 4 vectors):
 // two-pass statistics in fp32 like nn.LayerNorm's definition.  Shared by layernorm_rows and the GEMMs that normalise their
-// operand rows themselves, so that both give the same bits.
+// operand rows themselves, so that both give the same bits — which takes the fused multiply-adds written out: left to
+// -ffp-contract, `q += d * d` became v_pk_fma_f32 for some unrolled elements and v_pk_mul_f32 + add for others, differently in
+// each kernel the function was inlined into (one row in five off by an ulp between the two: tools/f32_stress.py).
 template <int NV>
 __device__ __forceinline__ void ln_wave_stats(const f32x4 (&v)[NV], int nv, int D, float eps, int lane, float& mean, float& rstd) {
     float s = 0.f;
@@ -140,14 +142,14 @@ __device__ __forceinline__ void ln_wave_stats(const f32x4 (&v)[NV], int nv, int 
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < nv) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = __builtin_fmaf(d, d, q); }
         }
     rstd = 1.0f / sqrtf(wave_sum_x(q) / (float)D + eps);
 }
 __device__ __forceinline__ f32x4 ln_apply(const f32x4& v, float mean, float rstd, const f32x4& g, const f32x4& b) {
     f32x4 y;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * g[e] + b[e];
+    for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((v[e] - mean) * rstd, g[e], b[e]);
     return y;
 }
 

@@ -739,13 +739,13 @@ int launch_m16ln_stream(const GemmLN& q, hipStream_t s, int lds_max) {
 //   O^T = V^T.P^T  P is reused in place as the B operand: k-step r pairs key kap(r,0) (lanes < 32) with
 //                  kap(r,1) = kap(r,0)+4 (lanes >= 32), which is exactly what each half-wave holds in reg r.
 // ---------------------------------------------------------------------------------------------
-// (shared by the two attention kernels so that both contract the same way)
+// (shared by the two attention kernels, the fused multiply-adds written out so that no kernel contracts differently from the
+// other: the scale and the additive masks in one rounding, as this kernel has always computed them)
 __device__ __forceinline__ float attn_score(float st, float scale, float addc, bool valid) {
-    float sv = st * scale;
-    sv = sv + addc;                                           // additive masks, exactly as the reference adds them
+    const float sv = __builtin_fmaf(st, scale, addc);
     return valid ? sv : -3.0e38f;
 }
-__device__ __forceinline__ float attn_lsum(float lrun, float alpha, float psum) { return lrun * alpha + psum; }
+__device__ __forceinline__ float attn_lsum(float lrun, float alpha, float psum) { return __builtin_fmaf(lrun, alpha, psum); }
 
 // DHP = head dim padded to a multiple of 32 (64, or 96 for EVA-CLIP's 88-wide heads: the fp32 reference-precision tower);
 // dh = the real head dim (the packed layouts are addressed with it; padded dims are zeros and their outputs are not stored).

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     a = wave_sum_x(a) / D; b = wave_sum_x(b) / D;
     for (int c = lane; c < D; c += 64) {
         const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
-        dx[(int64_t)row * D + c] = rstd * (g - a - xh * b);
+        dx[(int64_t)row * D + c] = rstd * __builtin_fmaf(-xh, b, g - a);
         dyxhat[(int64_t)row * D + c] = dr[c] * xh;
     }
 }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_regs_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const float xh = (xv[i] - mean) * rstd, g = dv[i] * gv[i];
-        dx[(int64_t)row * D + lane + 64 * i] = rstd * (g - a - xh * b);
+        dx[(int64_t)row * D + lane + 64 * i] = rstd * __builtin_fmaf(-xh, b, g - a);
         dyxhat[(int64_t)row * D + lane + 64 * i] = dv[i] * xh;
     }
 }

@@ -197,6 +197,18 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
         assert model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"] == ref, nb
 
 
+def test_round3_fp32_kernels_randomised_bit_equality(dev):
+    """tools/f32_stress.py: random shapes / options — hirest_gemm_f32's automatic dispatch (16-column LDS-DMA kernel, split form) vs the
+    forced 64x64 kernel, hirest_gemm_f32_ln vs hirest_layernorm + hirest_gemm_f32, hirest_attention_f32_decode vs gather +
+    hirest_attention_f32_qkv.  (This is the test that caught -ffp-contract contracting a shared inline function differently in two
+    kernels: the fused multiply-adds of the shared arithmetic are written out since.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "f32_stress.py"), "90"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "gemm_f32: 90 random problems, 0 mismatches" in r.stdout
+
+
 @pytest.mark.parametrize("t_hist,newkey,addc", [(0, True, 0.0), (5, True, 0.0), (31, True, 0.0), (32, True, 0.0), (47, True, 0.0), (70, True, 0.0),
                                                  (20, False, -10000.0), (64, False, -10000.0)])
 def test_attention_f32_decode_equals_gather_then_attention(dev, t_hist, newkey, addc):
