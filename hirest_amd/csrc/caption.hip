@@ -206,16 +206,19 @@ __global__ __launch_bounds__(256) void tail_select_kernel(const float* __restric
     const int per_row = nsel * beam, ncand = beam * per_row;  // <= 16 * 8 * 16 = 2048 = 8 per thread; 16 slots
     float val[16];
     int idx[16];
+    int civ[16];                                             // (loads unconditional on a clamped index and all issued before the first use)
+    float cxv[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int v = tid + 256 * u;
-        int iv = -1; float sv = 0.f;
-        if (v < ncand) {
-            iv = ci[(int64_t)b * ncand + v];
-            const int rr = v / per_row;
-            sv = ((cx[(int64_t)b * ncand + v] - row_mx[rr]) - row_lse[rr]) + row_ad[rr];
-        }
-        val[u] = sv; idx[u] = iv;
+        const int v = tid + 256 * u, vc = v < ncand ? v : ncand - 1;
+        civ[u] = ci[(int64_t)b * ncand + vc];
+        cxv[u] = cx[(int64_t)b * ncand + vc];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int v = tid + 256 * u, rr = (v < ncand ? v : ncand - 1) / per_row;
+        val[u] = ((cxv[u] - row_mx[rr]) - row_lse[rr]) + row_ad[rr];
+        idx[u] = v < ncand ? civ[u] : -1;
     }
     block_topk16(val, idx, beam, [&](int j, float sv, int iv) { top_s[j] = sv; top_i[j] = iv; });
     if (tid < beam) {                                        // beam_advance_kernel, thread k = beam k
