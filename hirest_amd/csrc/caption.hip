@@ -9,7 +9,6 @@
 // on later tokens and the rows kept here are bit for bit the rows a recomputation would produce (every kernel involved is
 // batch-invariant).  Beams are re-ordered every step, so each row's history is gathered from its PARENT row of the previous step.
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -327,15 +326,9 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
         const hirest_caption_layer& Z = d->layer[d->layers - 1];
         CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, Z.ff_ln_g, Z.ff_ln_b, eps, nullptr, 0, d->tr_w, D, d->tr_b, nullptr, 0, x, D, R, D,
                               D, 1, stream));
-        static const bool split_lm = getenv("HIREST_CAPTION_SPLIT_LM") != nullptr;       // tuning experiment: LayerNorm + LM head as two kernels
-        if (!split_lm) {
-            // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU)
-            CK(hirest_gemm_f32_ln(x, D, nullptr, nullptr, nullptr, d->tr_ln_g, d->tr_ln_b, eps, nullptr, 0, d->lm_w, D, d->lm_b, nullptr, 0,
-                                  logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
-        } else {
-            CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
-            CK(hirest_gemm_f32(b, D, d->lm_w, D, d->lm_b, nullptr, 0, nullptr, 0, logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
-        }
+        // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU)
+        CK(hirest_gemm_f32_ln(x, D, nullptr, nullptr, nullptr, d->tr_ln_g, d->tr_ln_b, eps, nullptr, 0, d->lm_w, D, d->lm_b, nullptr, 0, logits,
+                              d->vocab_padded, R, d->vocab_padded, D, 0, stream));
         if (logp) CK(hirest_log_softmax_f32(logits, d->vocab_padded, row_add, logp, d->vocab_padded, R, d->vocab_padded, stream));
         return hirest_launch_status();
     } else {

@@ -7,8 +7,6 @@
 // (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, 1/16 of the bf16 rate) — at 10-90 GFLOP per video the
 // whole model is still a few hundred microseconds.
 #include "common.h"
-#include <cstdlib>
-#include <cstdio>
 
 namespace {
 
@@ -1183,29 +1181,18 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     if (K % 16 != 0 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (periodic && period <= 0)) return HIREST_E_SHAPE;
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act, nullptr};
-    static const bool log_shapes = getenv("HIREST_GEMM_LOG") != nullptr;   // which problems a workload issues (stderr)
-    if (log_shapes) fprintf(stderr, "gemm_f32 M %d N %d K %d\n", M, N, K);
     // 33 .. 256 rows (the sentence encoder's batches, the captioning task's training rows): the same kernel, 32-row tiles across
     // blockIdx.y — whole-line operand traffic beats the split-K kernel's lane = row loads (ASR encoder 108 -> 117 k sentences/s)
     if (M > 32 && M <= 256 && K % FK == 0 && g_f32_kernel == 0 && N < 8192)
         return launch_m16<2, 1, 6>(p, reinterpret_cast<hipStream_t>(stream));
     if (M <= 32 && K % FK == 0 && g_f32_kernel == 0) {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        // few column tiles (the decoder's 768- / 3072-wide layers): one row tile per block, so 2 x N / 16 blocks share the
-        // operand traffic; LM head: both row tiles and two column tiles per wave halve the re-reads of A
-        static const int v_mid = getenv("HIREST_M16_MID") ? atoi(getenv("HIREST_M16_MID")) : 0;     // tuning experiments
-        static const int v_lm = getenv("HIREST_M16_LM") ? atoi(getenv("HIREST_M16_LM")) : 0;
+        // one row tile per block for the decoder's layers (2 x N / 16 blocks share the operand traffic; 8 slabs in flight per wave,
+        // 3 for the 2304- / 3072-wide ones so that two blocks fit a CU: +3 % per word); the LM head without a LayerNorm prologue
+        // (hirest_gemm_f32_ln has its own): both row tiles and two column tiles per wave, two slabs in flight (best of 2 / 3 / 4)
         if (N < 2048) return launch_m16<1, 1, 8>(p, s);
-        if (N < 8192) {
-            if (v_mid == 1) return launch_m16<1, 1, 8>(p, s);
-            if (v_mid == 2) return launch_m16<1, 2, 6>(p, s);
-            if (v_mid == 3) return launch_m16<1, 2, 3>(p, s);
-            return launch_m16<1, 1, 3>(p, s);
-        }
-        if (M <= 16) return launch_m16<1, 2, 6>(p, s);
-        if (v_lm == 1) return launch_m16<2, 2, 4>(p, s);
-        if (v_lm == 2) return launch_m16<2, 1, 3>(p, s);
-        return launch_m16<2, 2, 2>(p, s);
+        if (N < 8192) return launch_m16<1, 1, 3>(p, s);
+        return M <= 16 ? launch_m16<1, 2, 6>(p, s) : launch_m16<2, 2, 2>(p, s);
     }
     if (M <= 256 && g_f32_kernel != 1) {
         hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
@@ -1219,10 +1206,8 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
 // (same box, B = 5, T = 300: segmentation 330 -> 371 videos/s, retrieval 5400 -> 5800, training step 5.85 -> 5.55 ms; thresholds of
 // 512 .. 2048 for K and 400 .. 1200 tiles measure the same: the gain is the K = 3072 layer)
 static bool splits(int M, int N, int K) {
-    static const int mink = getenv("HIREST_SPLIT_MINK") ? atoi(getenv("HIREST_SPLIT_MINK")) : 1024;          // tuning experiments
-    static const int maxt = getenv("HIREST_SPLIT_MAXTILES") ? atoi(getenv("HIREST_SPLIT_MAXTILES")) : 512;
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
-    return g_f32_kernel == 0 && M > 256 && tiles <= maxt && K >= mink;
+    return g_f32_kernel == 0 && M > 256 && tiles <= 512 && K >= 1024;
 }
 extern "C" size_t hirest_gemm_f32_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     return (M > 0 && N > 0 && K > 0 && splits(M, N, K)) ? (size_t)4 * M * N * 4 : 0;
@@ -1252,9 +1237,7 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
     GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act, nullptr}, X, ldx, ids, table, pos_row, gamma, beta, eps,
              ln_out, ldl};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int v_ln = getenv("HIREST_M16_LN") ? atoi(getenv("HIREST_M16_LN")) : 0;     // tuning experiments
-    if (N >= 8192 && K == 768 && !ids && !ln_out && v_ln != 3)          // the LM head: persistent blocks, rows normalised once per CU
-    {
+    if (N >= 8192 && K == 768 && !ids && !ln_out) {          // the LM head: persistent blocks, rows normalised once per CU
         // ring depth: D0 slabs per wave in the fixed region + D1 in the space of the A image (M rows x 3200 B shared by 4 MT waves)
         constexpr int MAXLDS = 160 * 1024;
         if (M <= 2) return launch_m16ln_stream<3, 1, 8, 0>(q, s, MAXLDS);
@@ -1271,11 +1254,8 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
     switch (K / 256) {
         case 1: return launch_m16ln<1, 1, 2>(q, s);
         case 2: return launch_m16ln<2, 1, 2>(q, s);
-        case 3:
-            // two W slabs in flight per wave (66 KB of LDS, two blocks per CU: measured best of 2 / 3 / 6; two column tiles per wave
-            // for the wide layers: no better)
-            if (v_ln == 2) return launch_m16ln<3, 2, 2>(q, s);
-            return launch_m16ln<3, 1, 2>(q, s);
+        case 3: return launch_m16ln<3, 1, 2>(q, s);   // two W slabs in flight per wave (66 KB of LDS, two blocks per CU: best of 2 / 3 / 6;
+                                                      // two column tiles per wave for the wide layers measured no better)
         default: return launch_m16ln<4, 1, 2>(q, s);
     }
 }
