@@ -544,7 +544,7 @@ class MomentModel(nn.Module):
         val = torch.empty((B, num_beams), dtype=torch.float32, device=dev)
         idx = torch.empty((B, num_beams), dtype=torch.int32, device=dev)
         st = ops.stream_ptr()
-        fused_tail = bool(getattr(self, "caption_fused_tail", True)) and num_beams <= 16
+        fused_tail = bool(getattr(self, "caption_fused_tail", True)) and num_beams <= 16 and Vp <= 32768    # (the tail kernels' limits)
         if fused_tail:
             tail_ws = torch.empty(max(int(lib.hirest_caption_beam_tail_workspace_bytes(B, num_beams, Vp)), 16), dtype=torch.uint8,
                                   device=dev)
