@@ -59,6 +59,11 @@ __device__ __forceinline__ void epilogue_apply4(const GemmF& p, f32x4 v, const E
     *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
 }
 
+// AK / WK: the operand is stored k-major — A(m, k) at A[k * lda + m], W(n, k) at W[k * ldw + n] — as the backward pass of a linear
+// layer has them (dX = dY W: W(n, k) = W[k][n];  dW = dY^T X: both).  Such an operand is read along its contiguous dimension
+// (4 consecutive rows of one k per thread) and transposed on its way into the same LDS image, so the products, their order and
+// the bits are those of the GEMM on transposed copies, without the copies (the training step made 37 of them per iteration).
+template <bool AK, bool WK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     __shared__ float As[64 * FLD];
     __shared__ float Ws[64 * FLD];
@@ -71,8 +76,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     const int srow = tid >> 2, sk = (tid & 3) * 8;
     int gm = M0 + srow; gm = gm < p.M ? gm : p.M - 1;
     int gn = N0 + srow; gn = gn < p.N ? gn : p.N - 1;
-    const float* ap = p.A + (int64_t)gm * p.lda + sk;
-    const float* wp = p.W + (int64_t)gn * p.ldw + sk;
+    // k-major operand: thread -> (k = tid / 16 (+ 16 h), rows 4 (tid % 16) .. + 3 of the tile); rows past the end re-read the last four
+    const int tk = tid >> 4, tc = (tid & 15) * 4;
+    int cm = M0 + tc; cm = cm + 4 <= p.M ? cm : p.M - 4;
+    int cn = N0 + tc; cn = cn + 4 <= p.N ? cn : p.N - 4;
+    const float* ap = AK ? p.A + cm : p.A + (int64_t)gm * p.lda + sk;
+    const float* wp = WK ? p.W + cn : p.W + (int64_t)gn * p.ldw + sk;
     // Summation order (shared with gemm_f32_skinny_kernel below, so that a row's result does not depend on how many rows the call
     // has): K is cut into four contiguous quarters of ceil(nslab / 4) 32-deep slabs, quarter u gives partial sum p_u (slabs in
     // ascending order; inside a slab MFMA step j pairs k0 + j (lanes < 32) with k0 + 16 + j (lanes >= 32)), and the result is
@@ -88,8 +97,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const bool in = k0 + sk + 4 * h < p.K;            // K % 4 == 0: a 4-vector is inside or outside as a whole
-            av[h] = in ? *reinterpret_cast<const f32x4*>(ap + k0 + 4 * h) : zero;
-            wv[h] = in ? *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h) : zero;
+            const bool ink = k0 + tk + 16 * h < p.K;          // k-major: one k per thread
+            if (AK) av[h] = ink ? *reinterpret_cast<const f32x4*>(ap + (int64_t)(k0 + tk + 16 * h) * p.lda) : zero;
+            else av[h] = in ? *reinterpret_cast<const f32x4*>(ap + k0 + 4 * h) : zero;
+            if (WK) wv[h] = ink ? *reinterpret_cast<const f32x4*>(wp + (int64_t)(k0 + tk + 16 * h) * p.ldw) : zero;
+            else wv[h] = in ? *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h) : zero;
         }
     };
     const int nslab = (p.K + FK - 1) / FK;
@@ -115,7 +127,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { As[srow * FLD + spos + 2 * (4 * h + e)] = av[h][e]; Ws[srow * FLD + spos + 2 * (4 * h + e)] = wv[h][e]; }
+                for (int e = 0; e < 4; ++e) {                 // (k = tk + 16 h sits at position 2 tk + h)
+                    if (AK) As[(tc + e) * FLD + 2 * tk + h] = av[h][e]; else As[srow * FLD + spos + 2 * (4 * h + e)] = av[h][e];
+                    if (WK) Ws[(tc + e) * FLD + 2 * tk + h] = wv[h][e]; else Ws[srow * FLD + spos + 2 * (4 * h + e)] = wv[h][e];
+                }
             __syncthreads();
             if (sl + 1 < s_last) fetch((sl + 1) * FK, av, wv);
 #pragma unroll
@@ -1198,7 +1213,7 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
         hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
         return hirest_launch_status();
     }
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     return hirest_launch_status();
 }
 
@@ -1222,7 +1237,7 @@ extern "C" int hirest_gemm_f32_ws(const float* A, int64_t lda, const float* W, i
         return hirest_gemm_f32(A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act, stream);
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act, static_cast<float*>(workspace)};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3((N + 63) / 64, (M + 63) / 64, 4), dim3(256), 0, s, p);
     const int64_t n = (int64_t)M * (N / 4);
     hipLaunchKernelGGL(gemm_f32_quarters_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
     return hirest_launch_status();
@@ -1258,6 +1273,34 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
                                                       // two column tiles per wave for the wide layers measured no better)
         default: return launch_m16ln<4, 1, 2>(q, s);
     }
+}
+
+extern "C" int hirest_gemm_f32_layouts(const float* A, int64_t lda, int32_t a_kmajor, const float* W, int64_t ldw, int32_t w_kmajor,
+                                       const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M, int32_t N,
+                                       int32_t K, int32_t act, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
+    if (N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || (a_kmajor ? (M % 4 != 0 || M < 4) : K % 4 != 0) || (w_kmajor ? N < 4 : K % 4 != 0)) return HIREST_E_SHAPE;
+    GemmF p{A, lda, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act, nullptr};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // the 64x64 kernel for every size (the few-row kernels read row-major operands only); split form as in hirest_gemm_f32_ws
+    const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+    const bool split = tiles <= 512 && K >= 1024 && workspace && workspace_bytes >= (size_t)4 * M * N * 4 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    if (split) p.ws = static_cast<float*>(workspace);
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, split ? 4 : 1), blk(256);
+    if (a_kmajor && w_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, blk, 0, s, p);
+    else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, blk, 0, s, p);
+    else if (w_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, blk, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, blk, 0, s, p);
+    if (split) {
+        const int64_t n = (int64_t)M * (N / 4);
+        hipLaunchKernelGGL(gemm_f32_quarters_kernel, dim3((unsigned)((n + 255) / 256)), blk, 0, s, p);
+    }
+    return hirest_launch_status();
+}
+extern "C" size_t hirest_gemm_f32_layouts_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+    return (tiles <= 512 && K >= 1024) ? (size_t)4 * M * N * 4 : 0;
 }
 
 extern "C" int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,

@@ -32,6 +32,9 @@ _V = "clip4cap_model.visual."
 # at T = 300, captioning 8.4 -> 9.0: the strided kernel's element-wise staging loses what the 53 saved copies gain, so it is off.
 STRIDED_GEMM = False
 STRIDED_MAX_FLOP = 1.5e9   # when on: only products up to this size (above it hirest_gemm_f32's register-prefetching kernel wins)
+# Since late round 3 the 64x64 kernel itself reads k-major operands (hirest_gemm_f32_layouts: vector loads along the contiguous
+# dimension, transposed on the way into LDS): dX / dW without the 37 transposed copies per step, same bits as with them.
+LAYOUT_GEMM = True
 
 
 def _chk(code, what):
@@ -71,6 +74,15 @@ class _K:
         return out
 
     @staticmethod
+    def layouts(a, lda, a_kmajor, w, ldw, w_kmajor, M, N, K):
+        lib = _lib.load()
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_layouts_workspace_bytes(M, N, K))
+        _chk(lib.hirest_gemm_f32_layouts(a.data_ptr(), lda, int(a_kmajor), w.data_ptr(), ldw, int(w_kmajor), None, None, 0, out.data_ptr(), N,
+                                         M, N, K, 0, ws, wsb, ops.stream_ptr()), "hirest_gemm_f32_layouts")
+        return out
+
+    @staticmethod
     def grad_input(dy, w):
         """dX = dY @ W for y = x W^T:  dY [R, N], W [N, K] -> [R, K].  The strided GEMM reads W column-wise in place (its
         B[n][k] = W[k][n]); STRIDED_GEMM = False: through a zero-padded transposed copy and hirest_gemm_f32 (round 2)."""
@@ -78,6 +90,10 @@ class _K:
             return _K.strided(dy, dy.stride(0), 1, w, 1, w.stride(0), dy.shape[0], w.shape[1], dy.shape[1])
         if w.shape[0] % 16 != 0:
             raise RuntimeError(f"grad_input: out_features {w.shape[0]} must be a multiple of 16")
+        R, O = dy.shape
+        I = w.shape[1]
+        if LAYOUT_GEMM and I % 4 == 0 and dy.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and dy.stride(1) == 1 and w.stride(1) == 1:
+            return _K.layouts(dy, dy.stride(0), False, w, w.stride(0), True, R, I, O)      # B(n = i, k = o) = W[o][i]: k-major
         return _K.gemm(dy, _K.transpose_pad(w))
 
     @staticmethod
@@ -86,6 +102,11 @@ class _K:
         B[n][k] = X[k][n]); STRIDED_GEMM = False: two zero-padded transposed copies."""
         if STRIDED_GEMM and 2.0 * dy.shape[1] * x.shape[1] * dy.shape[0] <= STRIDED_MAX_FLOP:
             return _K.strided(dy, 1, dy.stride(0), x, 1, x.stride(0), dy.shape[1], x.shape[1], dy.shape[0])
+        R, O = dy.shape
+        I = x.shape[1]
+        if (LAYOUT_GEMM and O % 4 == 0 and I % 4 == 0 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.stride(1) == 1
+                and x.stride(1) == 1):
+            return _K.layouts(dy, dy.stride(0), True, x, x.stride(0), True, O, I, R)        # A(m = o, k = r) = dY[r][o], B(n = i, k = r) = X[r][i]
         return _K.gemm(_K.transpose_pad(dy), _K.transpose_pad(x))
 
     @staticmethod

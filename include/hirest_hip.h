@@ -353,6 +353,14 @@ size_t hirest_gemm_f32_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int hirest_gemm_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
                        const float* periodic, int32_t period, float* out, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* out = act(A B^T + bias) (+ resid) with either operand optionally stored k-major (a_kmajor: A(m, k) at A[k * lda + m], M % 4 == 0;
+ * w_kmajor: W(n, k) at W[k * ldw + n]) — the products of a linear layer's backward pass (dX = dY W: w_kmajor; dW = dY^T X: both)
+ * without transposed copies.  Same kernel, same summation order and bits as hirest_gemm_f32 on the transposed, zero-padded copies;
+ * K is free for a k-major operand (K % 4 == 0 otherwise).  The workspace (optional) enables the split form for few-tile problems. */
+size_t hirest_gemm_f32_layouts_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int hirest_gemm_f32_layouts(const float* A, int64_t lda, int32_t a_kmajor, const float* W, int64_t ldw, int32_t w_kmajor,
+                            const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M, int32_t N,
+                            int32_t K, int32_t act, void* workspace, size_t workspace_bytes, void* stream);
 /* 0 = automatic (M <= 256 rows and K % 32 == 0 [and N < 8192 above 32 rows]: 16-column tiles of v_mfma_f32_16x16x4_f32, four waves
  * share K, operands by LDS-DMA; other M <= 256: the split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the
  * 64x64 kernel, 2 = automatic without the 16-column kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */

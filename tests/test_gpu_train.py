@@ -190,3 +190,24 @@ def test_tiled_training_attention_equals_the_row_kernels_with_dropout_on(dev, go
         for n in g0:
             d = (g0[n] - g1[n]).norm().item()
             assert d <= 1e-4 * g0[n].norm().item() + 1e-7, (n, d, g0[n].norm().item())
+
+
+@pytest.mark.gpu
+def test_backward_products_in_place_equal_the_transposed_copies():
+    """hirest_gemm_f32_layouts (k-major operands read in place by the 64x64 kernel) against the zero-padded transposed copies +
+    hirest_gemm_f32: dX and dW bit for bit, including a row count that is no multiple of 16 and the split form"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from hirest_amd import train, synth
+    dev = torch.device("cuda:0")
+    for R, O, I in ((1500, 768, 768), (1500, 768, 3072), (1500, 3072, 768), (1498, 512, 384), (100, 2304, 768), (37, 64, 36), (240, 768, 30528)):
+        dy = synth.tensor(f"lay.dy.{R}.{O}", (R, O), 1.0, 3).to(dev)
+        x = synth.tensor(f"lay.x.{R}.{I}", (R, I), 1.0, 3).to(dev)
+        w = synth.tensor(f"lay.w.{O}.{I}", (O, I), 0.05, 3).to(dev)
+        outs = []
+        for flag in (True, False):
+            train.LAYOUT_GEMM = flag
+            outs.append((train._K.grad_input(dy, w), train._K.grad_weight(dy, x)))
+        train.LAYOUT_GEMM = True
+        assert torch.equal(outs[0][0], outs[1][0]), ("dX", R, O, I)
+        assert torch.equal(outs[0][1], outs[1][1]), ("dW", R, O, I)
