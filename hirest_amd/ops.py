@@ -20,8 +20,15 @@ __all__ = ["gemm", "layernorm", "attention", "patchify", "write_cls_rows", "embe
            "pool_l2norm", "similarity", "topk", "stream_ptr", "on_tensor_device"]
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
-    """Raw hipStream_t of torch's current stream on the CURRENT device (wrappers switch to their tensors' device first)."""
+    """Raw hipStream_t of torch's current stream on the CURRENT device (wrappers switch to their tensors' device first).  Called
+    once per kernel launch — the training step issues ~300 per iteration from Python — so it takes torch's raw accessor when the
+    build has it (no Stream object per call)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
