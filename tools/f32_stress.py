@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised bit-equality stress of the round-3 fp32 kernels against the kernels they replace (GPU):
    hirest_gemm_f32 automatic dispatch (16-column LDS-DMA kernel, split form via hirest_gemm_f32_ws) vs the forced 64x64 kernel;
-   hirest_gemm_f32_ln vs hirest_layernorm + hirest_gemm_f32;  hirest_attention_f32_decode vs gather + hirest_attention_f32_qkv.
+   hirest_gemm_f32_ln vs hirest_layernorm + hirest_gemm_f32;  hirest_attention_f32_decode vs gather + hirest_attention_f32_qkv;
+   hirest_gemm_f32_layouts (k-major operands in place) vs transposed copies + hirest_gemm_f32.
    python tools/f32_stress.py [cases]"""
 import os, random, sys
 import torch
@@ -73,4 +74,19 @@ for case in range(n // 3):
     if not (torch.equal(out, ref) and torch.equal(ko, kc) and torch.equal(vo, vc)):
         bad_at += 1; print("ATTENTION MISMATCH", R, H, t_hist, newkey, addc)
 print(f"attention_f32_decode: {n // 3} random problems, {bad_at} mismatches")
-sys.exit(1 if bad + bad_ln + bad_at else 0)
+# backward products with k-major operands read in place vs zero-padded transposed copies
+from hirest_amd import train
+bad_lay = 0
+for case in range(n // 3):
+    R = rng.choice([37, 100, 240, 1498, 1500, rng.randint(5, 2000)]); O = 16 * rng.randint(1, 200); I = 4 * rng.randint(1, 800)
+    if O * I > 3e6: I = 768
+    dy, x, w = rand(R, O), rand(R, I), rand(O, I, scale=0.05)
+    outs = []
+    for flag in (True, False):
+        train.LAYOUT_GEMM = flag
+        outs.append((train._K.grad_input(dy, w), train._K.grad_weight(dy, x)))
+    train.LAYOUT_GEMM = True
+    if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
+        bad_lay += 1; print("LAYOUTS MISMATCH", R, O, I)
+print(f"gemm_f32_layouts (dX, dW): {n // 3} random problems, {bad_lay} mismatches")
+sys.exit(1 if bad + bad_ln + bad_at + bad_lay else 0)
