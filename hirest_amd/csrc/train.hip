@@ -495,11 +495,23 @@ __global__ __launch_bounds__(256) void joint_base_bwd_kernel(const float* __rest
     if (e >= E) return;
     const float t = tn[(int64_t)b * E + e];
     float acc = 0.f;
-    for (int tt = 0; tt < T; ++tt) {
-        const int64_t i = ((int64_t)b * T + tt) * E + e;
-        const float d = dbase[i];
-        dv[i] = d * t;
-        acc = fmaf(d, v[i], acc);
+    // the sum over t stays one fma chain in t order (same bits), but its loads go out sixteen rows at a time: one row per
+    // iteration was 300 dependent memory round trips in ten blocks (119 us, 3 % of the training step)
+    constexpr int U = 16;
+    for (int t0 = 0; t0 < T; t0 += U) {
+        float d[U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tt = t0 + u < T ? t0 + u : T - 1;
+            const int64_t i = ((int64_t)b * T + tt) * E + e;
+            d[u] = dbase[i]; x[u] = v[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (t0 + u < T) {
+                dv[((int64_t)b * T + t0 + u) * E + e] = d[u] * t;
+                acc = fmaf(d[u], x[u], acc);
+            }
     }
     dtn[(int64_t)b * E + e] = acc;
 }
