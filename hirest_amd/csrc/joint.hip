@@ -804,19 +804,36 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
     float mrun = -3.0e38f, lrun = 0.f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < T; k0 += 32) {
-        __syncthreads();
-        for (int i = tid; i < 32 * (DHP / 4); i += 256) {   // 32 keys x DHP/4 float4
+    // K / V tile staging through registers, one tile ahead (the next tile's rows travel while this one is multiplied: a synchronous
+    // load per 32-key tile was a memory round trip in front of every tile, 10 of them at T = 300)
+    constexpr int NLD = (32 * (DHP / 4) + 255) / 256;         // float4 per thread and operand: 2 (dh 64) or 3 (96)
+    f32x4 kreg[NLD], vreg[NLD];
+    auto fetch_kv = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            int i = tid + 256 * u; i = i < 32 * (DHP / 4) ? i : 32 * (DHP / 4) - 1;
             const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
             const int key = k0 + kr < T ? k0 + kr : T - 1;
             const int cc = c < dh ? c : dh - 4;                  // (dh % 4 == 0: a 4-vector is inside or outside the head as a whole)
-            f32x4 kv = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + cc);
-            f32x4 vv = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + cc);
-            if (c >= dh) { kv = zero4; vv = zero4; }
+            kreg[u] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + cc);
+            vreg[u] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + cc);
+        }
+    };
+    fetch_kv(0);
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { Ks[kr * ALD + c + e] = kv[e]; Vs[kr * ALD + c + e] = vv[e]; }
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + 256 * u;
+            if (i < 32 * (DHP / 4)) {
+                const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
+                const f32x4 kv = c >= dh ? zero4 : kreg[u], vv = c >= dh ? zero4 : vreg[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Ks[kr * ALD + c + e] = kv[e]; Vs[kr * ALD + c + e] = vv[e]; }
+            }
         }
         __syncthreads();
+        if (k0 + 32 < T) fetch_kv(k0 + 32);
         f32x16 st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
