@@ -1,10 +1,12 @@
+"""Host time spent inside the two C calls of a step-captioning word (are the ~20 launches per word host- or GPU-bound?)."""
 import json, os, sys, time
 import torch
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import hirest_amd
 from hirest_amd import synth, _lib
 from hirest_amd.synth import joint_inputs
-shapes = {k: tuple(v) for k, v in json.load(open("/root/repo/tests/golden/joint_schema.json")).items()}
+shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", "joint_schema.json"))).items()}
 sd = synth.joint_state_dict(shapes, 31)
 dev = torch.device("cuda:0")
 model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
