@@ -159,6 +159,12 @@ _SIGNATURES = {
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hirest_caption_select": (C.c_int, [C.c_int32]),
+    "hirest_gemm_f32_ln_colmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_caption_beam_step": (C.c_int, [C.POINTER(CaptionDecoder), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hirest_caption_beam_tail_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "hirest_caption_beam_tail": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

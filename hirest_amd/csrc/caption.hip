@@ -123,7 +123,8 @@ __device__ __forceinline__ void block_topk16(const float (&val)[16], const int (
 }
 
 __global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict__ x, int64_t ldx, int V, int beam, int nsel,
-                                                       float* __restrict__ cx, int32_t* __restrict__ ci, float* __restrict__ stat) {
+                                                       float* __restrict__ cx, int32_t* __restrict__ ci, float* __restrict__ stat,
+                                                       const float* __restrict__ tile_max, int ntile) {
     const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xr = x + (int64_t)r * ldx;
     const int V4 = V >> 2;
@@ -155,13 +156,21 @@ __global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict_
         const int i = tid + 256 * g + 1024 * j;
         mine[j] = *reinterpret_cast<const f32x4*>(xr + 4 * (i < V4 ? i : V4 - 1));
     }
+    if (tile_max) {                                          // (uniform) the LM head reported the maximum of every 16-column tile of the row:
+        float tm[8];                                         // ntile floats instead of the whole row (7.6 KB instead of 122)
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-        const int i = tid + 256 * m;
-        all[m] = *reinterpret_cast<const f32x4*>(xr + 4 * (i < V4 ? i : V4 - 1));
+        for (int m = 0; m < 8; ++m) { const int i = tid + 256 * m; tm[m] = tile_max[(int64_t)r * ntile + (i < ntile ? i : ntile - 1)]; }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mx = fmaxf(mx, tm[m]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int i = tid + 256 * m;
+            all[m] = *reinterpret_cast<const f32x4*>(xr + 4 * (i < V4 ? i : V4 - 1));
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) mx = fmaxf(fmaxf(mx, fmaxf(all[m][0], all[m][1])), fmaxf(all[m][2], all[m][3]));   // (a repeated element changes no max)
     }
-#pragma unroll
-    for (int m = 0; m < NM; ++m) mx = fmaxf(fmaxf(mx, fmaxf(all[m][0], all[m][1])), fmaxf(all[m][2], all[m][3]));   // (a repeated element changes no max)
     mx = wave_max_x(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void tail_select_kernel(const float* __restric
 
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Ws { size_t x, qkv, ctx, a, b, mid, logits, pos, total; };
+struct Ws { size_t x, qkv, ctx, a, b, mid, logits, pos, tm, total; };
 Ws plan(const hirest_caption_decoder* d, int R) {
     Ws w; size_t off = 0;
     const size_t D = d->hidden;
@@ -252,6 +261,7 @@ Ws plan(const hirest_caption_decoder* d, int R) {
     w.mid = off; off += al((size_t)R * d->inter * 4);
     w.logits = off; off += al((size_t)R * d->vocab_padded * 4);
     w.pos = off; off += al((size_t)R * 4);
+    w.tm = off; off += al((size_t)R * ((d->vocab_padded + 15) / 16) * 4);       // the LM head's tile maxima (hirest_caption_beam_step)
     w.total = off;
     return w;
 }
@@ -276,7 +286,7 @@ extern "C" int hirest_caption_select(int32_t mode) {
 // logp != NULL: log_softmax + row_add into logp; logits_out != NULL: the raw LM-head logits there instead (hirest_caption_beam_tail)
 static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
                        const int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
-                       const float* const* enc_kv, int32_t F, const float* row_add, float* logp, float* logits_out,
+                       const float* const* enc_kv, int32_t F, const float* row_add, float* logp, float* logits_out, float** tile_max_out,
                        void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !d->layer || !last_ids || !kv_out || !enc_kv || (!logp && !logits_out) || !workspace || R <= 0 || F <= 0) return HIREST_E_BADARG;
     if (position < 0 || position >= d->max_pos || (position > 0 && (!kv_in || !parent_rows))) return HIREST_E_BADARG;
@@ -326,9 +336,17 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
         const hirest_caption_layer& Z = d->layer[d->layers - 1];
         CK(hirest_gemm_f32_ln(a, D, nullptr, nullptr, nullptr, Z.ff_ln_g, Z.ff_ln_b, eps, nullptr, 0, d->tr_w, D, d->tr_b, nullptr, 0, x, D, R, D,
                               D, 1, stream));
-        // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU)
-        CK(hirest_gemm_f32_ln(x, D, nullptr, nullptr, nullptr, d->tr_ln_g, d->tr_ln_b, eps, nullptr, 0, d->lm_w, D, d->lm_b, nullptr, 0, logits,
-                              d->vocab_padded, R, d->vocab_padded, D, 0, stream));
+        // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU); for the
+        // one-call beam step it also leaves the maxima of its 16-column tiles for the tail
+        if (tile_max_out && d->vocab_padded >= 8192 && D == 768) {
+            float* tm = reinterpret_cast<float*>(base + w.tm);
+            CK(hirest_gemm_f32_ln_colmax(x, D, d->tr_ln_g, d->tr_ln_b, eps, d->lm_w, D, d->lm_b, logits, d->vocab_padded, tm, R, d->vocab_padded, D,
+                                         stream));
+            *tile_max_out = tm;
+        } else {
+            CK(hirest_gemm_f32_ln(x, D, nullptr, nullptr, nullptr, d->tr_ln_g, d->tr_ln_b, eps, nullptr, 0, d->lm_w, D, d->lm_b, nullptr, 0,
+                                  logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
+        }
         if (logp) CK(hirest_log_softmax_f32(logits, d->vocab_padded, row_add, logp, d->vocab_padded, R, d->vocab_padded, stream));
         return hirest_launch_status();
     } else {
@@ -370,8 +388,8 @@ extern "C" int hirest_caption_decode_step(const hirest_caption_decoder* d, int32
                                           const float* const* enc_kv, int32_t F, const float* row_add, float* logp,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (!logp) return HIREST_E_BADARG;
-    return decode_step(d, R, position, last_ids, parent_rows, kv_in, kv_out, enc_kv, F, row_add, logp, nullptr, workspace, workspace_bytes,
-                       stream);
+    return decode_step(d, R, position, last_ids, parent_rows, kv_in, kv_out, enc_kv, F, row_add, logp, nullptr, nullptr, workspace,
+                       workspace_bytes, stream);
 }
 
 extern "C" int hirest_caption_decode_logits(const hirest_caption_decoder* d, int32_t R, int32_t position, const int32_t* last_ids,
@@ -379,7 +397,7 @@ extern "C" int hirest_caption_decode_logits(const hirest_caption_decoder* d, int
                                             const float* const* enc_kv, int32_t F, float* logits, void* workspace, size_t workspace_bytes,
                                             void* stream) {
     if (!logits) return HIREST_E_BADARG;
-    return decode_step(d, R, position, last_ids, parent_rows, kv_in, kv_out, enc_kv, F, nullptr, nullptr, logits, workspace,
+    return decode_step(d, R, position, last_ids, parent_rows, kv_in, kv_out, enc_kv, F, nullptr, nullptr, logits, nullptr, workspace,
                        workspace_bytes, stream);
 }
 
@@ -389,10 +407,10 @@ extern "C" size_t hirest_caption_beam_tail_workspace_bytes(int32_t B, int32_t be
     return R * nsel * beam * 8 + R * TAIL_STAT * 4;
 }
 
-extern "C" int hirest_caption_beam_tail(const float* logits, int64_t ldx, const float* row_add, int32_t B, int32_t beam, int32_t vocab,
-                                        int32_t step, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens,
-                                        int32_t* backptr, int32_t* n_steps, int32_t* done, int32_t* next_ids, int32_t* next_parents,
-                                        float* next_add, int32_t* done_host, void* workspace, size_t workspace_bytes, void* stream) {
+static int beam_tail(const float* logits, int64_t ldx, const float* row_add, const float* tile_max, int32_t B, int32_t beam, int32_t vocab,
+                     int32_t step, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens,
+                     int32_t* backptr, int32_t* n_steps, int32_t* done, int32_t* next_ids, int32_t* next_parents,
+                     float* next_add, int32_t* done_host, void* workspace, size_t workspace_bytes, void* stream) {
     if (!logits || !row_add || !scores || !tokens || !backptr || !n_steps || !done || !next_ids || !next_parents || !next_add || !workspace)
         return HIREST_E_BADARG;
     if (B <= 0 || beam <= 0 || beam > 16 || vocab <= 0 || step < 0 || step >= max_steps) return HIREST_E_BADARG;
@@ -404,11 +422,39 @@ extern "C" int hirest_caption_beam_tail(const float* logits, int64_t ldx, const 
     int32_t* ci = reinterpret_cast<int32_t*>(cx + n);
     float* stat = reinterpret_cast<float*>(ci + n);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(tail_scan_kernel, dim3(nsel + 4, B * beam), dim3(256), 0, s, logits, ldx, vocab, beam, nsel, cx, ci, stat);
+    const int ntile = (vocab + 15) / 16;
+    hipLaunchKernelGGL(tail_scan_kernel, dim3(nsel + 4, B * beam), dim3(256), 0, s, logits, ldx, vocab, beam, nsel, cx, ci, stat,
+                       ntile <= 2048 ? tile_max : nullptr, ntile);
     hipLaunchKernelGGL(tail_select_kernel, dim3(B), dim3(256), 0, s, cx, ci, stat, row_add, nsel, beam, vocab, step, max_steps, eos_id,
                        scores, tokens, backptr, n_steps, done, next_ids, next_parents, next_add, done_host);
     return hirest_launch_status();
 }
+extern "C" int hirest_caption_beam_tail(const float* logits, int64_t ldx, const float* row_add, int32_t B, int32_t beam, int32_t vocab,
+                                        int32_t step, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens,
+                                        int32_t* backptr, int32_t* n_steps, int32_t* done, int32_t* next_ids, int32_t* next_parents,
+                                        float* next_add, int32_t* done_host, void* workspace, size_t workspace_bytes, void* stream) {
+    return beam_tail(logits, ldx, row_add, nullptr, B, beam, vocab, step, max_steps, eos_id, scores, tokens, backptr, n_steps, done, next_ids,
+                     next_parents, next_add, done_host, workspace, workspace_bytes, stream);
+}
+
+// One word of the beam search in one call: hirest_caption_decode_logits, then the tail on its logits — with the LM head's per-tile
+// maxima (kept in the decode workspace) in place of the tail's row scan when the step ran the fused kernels.
+extern "C" int hirest_caption_beam_step(const hirest_caption_decoder* d, int32_t B, int32_t beam, int32_t position, int32_t* ids,
+                                        int32_t* parent_rows, const float* const* kv_in, float* const* kv_out,
+                                        const float* const* enc_kv, int32_t F, float* row_add, float* logits, int32_t max_steps,
+                                        int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr, int32_t* n_steps, int32_t* done,
+                                        int32_t* done_host, void* workspace, size_t workspace_bytes, void* tail_workspace,
+                                        size_t tail_workspace_bytes, void* stream) {
+    if (!d || B <= 0 || beam <= 0 || !logits) return HIREST_E_BADARG;
+    const int R = B * beam;
+    float* tm = nullptr;
+    if (int e = decode_step(d, R, position, ids, position > 0 ? parent_rows : nullptr, kv_in, kv_out, enc_kv, F, nullptr, nullptr, logits, &tm,
+                            workspace, workspace_bytes, stream))
+        return e;
+    return beam_tail(logits, d->vocab_padded, row_add, tm, B, beam, d->vocab_padded, position, max_steps, eos_id, scores, tokens, backptr,
+                     n_steps, done, ids, parent_rows, row_add, done_host, tail_workspace, tail_workspace_bytes, stream);
+}
+
 extern "C" int hirest_beam_advance(const float* val, const int32_t* idx, int32_t B, int32_t beam, int32_t vocab, int32_t step,
                                    int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr, int32_t* n_steps,
                                    int32_t* done, int32_t* next_ids, int32_t* next_parents, float* next_add, void* stream) {

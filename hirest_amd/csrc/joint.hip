@@ -42,7 +42,7 @@ __device__ __forceinline__ Epi4 epilogue_fetch4(const GemmF& p, int m, int n) { 
     e.periodic = p.periodic ? *reinterpret_cast<const f32x4*>(p.periodic + (int64_t)(mc % p.period) * p.N + nc) : zero;
     return e;
 }
-__device__ __forceinline__ void epilogue_apply4(const GemmF& p, f32x4 v, const Epi4& e, int m, int n) {
+__device__ __forceinline__ f32x4 epilogue_apply4(const GemmF& p, f32x4 v, const Epi4& e, int m, int n, bool store = true) {
     if (p.bias) v += e.bias;
     if (p.act == 1) {
 #pragma unroll
@@ -56,7 +56,8 @@ __device__ __forceinline__ void epilogue_apply4(const GemmF& p, f32x4 v, const E
     }
     if (p.resid) v += e.resid;
     if (p.periodic) v += e.periodic;
-    *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+    if (store) *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+    return v;
 }
 
 // AK / WK: the operand is stored k-major — A(m, k) at A[k * lda + m], W(n, k) at W[k * ldw + n] — as the backward pass of a linear
@@ -394,6 +395,7 @@ struct GemmLN {
     const int32_t* ids; const float* table; const float* pos_row;   // X[r] = table[ids[r]] + pos_row
     const float* gamma; const float* beta; float eps;
     float* ln_out; int64_t ldl;
+    float* colmax;                                           // stream kernel only: [M, ceil(N / 16)] maxima of the stored 16-column tiles
 };
 
 template <int NV, int NT, int DEPTH>
@@ -718,12 +720,16 @@ __global__ __launch_bounds__(256 * MT) void gemm_f32_m16ln_stream_kernel(GemmLN 
         }
         __syncthreads();
         if (have && kq == 0) {
-            const int n = (tile0 + i * tstep) * 16 + 4 * slot;
-            if (n < p.N) {
+            const int tile = tile0 + i * tstep, n = tile * 16 + 4 * slot;
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const int m = 16 * t + idx;
-                    if (m < p.M) epilogue_apply4(p, ((acc[t] + red[0][t][lane]) + red[1][t][lane]) + red[2][t][lane], ep[t], m, n);
+            for (int t = 0; t < MT; ++t) {
+                const int m = 16 * t + idx;
+                const bool in = n < p.N && m < p.M;
+                const f32x4 v = epilogue_apply4(p, ((acc[t] + red[0][t][lane]) + red[1][t][lane]) + red[2][t][lane], ep[t], m, n, in);
+                if (q.colmax) {                              // (wave-uniform) the tile's maximum per row: the beam tail's row max without a row scan
+                    float mx = in ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
+                    { float pa = mx, pb = mx; lane_swap16(pa, pb); mx = fmaxf(pa, pb); pa = mx; pb = mx; lane_swap32(pa, pb); mx = fmaxf(pa, pb); }
+                    if (slot == 0 && m < p.M) q.colmax[(int64_t)m * ntile + tile] = mx;
                 }
             }
         }
@@ -1260,6 +1266,7 @@ extern "C" int hirest_gemm_f32_ws(const float* A, int64_t lda, const float* W, i
     return hirest_launch_status();
 }
 
+static thread_local float* g_ln_colmax = nullptr;       // set by hirest_gemm_f32_ln_colmax around its call of hirest_gemm_f32_ln
 extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* ids, const float* table, const float* pos_row,
                                   const float* gamma, const float* beta, float eps, float* ln_out, int64_t ldl, const float* W,
                                   int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M,
@@ -1267,7 +1274,7 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
     if ((!X && !(ids && table && pos_row)) || !gamma || !beta || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     if (M > 32 || K % 256 != 0 || K > 1024 || N % 4 != 0 || ldw % 4 != 0 || (X && ldx % 4 != 0) || (ln_out && ldl % 4 != 0)) return HIREST_E_SHAPE;
     GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act, nullptr}, X, ldx, ids, table, pos_row, gamma, beta, eps,
-             ln_out, ldl};
+             ln_out, ldl, g_ln_colmax};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (N >= 8192 && K == 768 && !ids && !ln_out) {          // the LM head: persistent blocks, rows normalised once per CU
         // ring depth: D0 slabs per wave in the fixed region + D1 in the space of the A image (M rows x 3200 B shared by 4 MT waves)
@@ -1290,6 +1297,19 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
                                                       // two column tiles per wave for the wide layers measured no better)
         default: return launch_m16ln<4, 1, 2>(q, s);
     }
+}
+
+// The LM-head form of hirest_gemm_f32_ln (N >= 8192, K = 768, no ids, no ln_out) that also reports, per row, the maximum of every
+// 16-column tile it stores: colmax [M, ceil(N / 16)].
+extern "C" int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const float* gamma, const float* beta, float eps, const float* W,
+                                         int64_t ldw, const float* bias, float* out, int64_t ldo, float* colmax, int32_t M, int32_t N,
+                                         int32_t K, void* stream) {
+    if (!colmax) return HIREST_E_BADARG;
+    if (N < 8192 || K != 768) return HIREST_E_SHAPE;
+    g_ln_colmax = colmax;
+    const int e = hirest_gemm_f32_ln(X, ldx, nullptr, nullptr, nullptr, gamma, beta, eps, nullptr, 0, W, ldw, bias, nullptr, 0, out, ldo, M, N, K, 0, stream);
+    g_ln_colmax = nullptr;
+    return e;
 }
 
 extern "C" int hirest_gemm_f32_layouts(const float* A, int64_t lda, int32_t a_kmajor, const float* W, int64_t ldw, int32_t w_kmajor,

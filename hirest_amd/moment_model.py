@@ -550,15 +550,13 @@ class MomentModel(nn.Module):
                                   device=dev)
         for t in range(1, max_words + 1):
             if fused_tail:
-                # LM-head logits, then log-softmax + beam score + top-k + bookkeeping + the done flags to pinned memory: 2 kernels
-                _lib.check(lib.hirest_caption_decode_logits(
-                    C.byref(desc), R, t - 1, ids.data_ptr(), parents.data_ptr() if t > 1 else None,
-                    ptrs[t & 1] if t > 1 else None, ptrs[(t + 1) & 1], enc_ptrs, F, logp.data_ptr(),
-                    ws.data_ptr(), ws.numel(), st), "hirest_caption_decode_logits")
-                _lib.check(lib.hirest_caption_beam_tail(
-                    logp.data_ptr(), Vp, add.data_ptr(), B, num_beams, Vp, t - 1, max_words, EOS_ID, scores.data_ptr(),
-                    tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(), done.data_ptr(), ids.data_ptr(), parents.data_ptr(),
-                    add.data_ptr(), done_host[t - 1].data_ptr(), tail_ws.data_ptr(), tail_ws.numel(), st), "hirest_caption_beam_tail")
+                # one C call per word: the decoder step up to the LM-head logits (20 kernels), then log-softmax + beam score + top-k +
+                # bookkeeping + the done flags to pinned memory (2 kernels, fed the LM head's tile maxima)
+                _lib.check(lib.hirest_caption_beam_step(
+                    C.byref(desc), B, num_beams, t - 1, ids.data_ptr(), parents.data_ptr(), ptrs[t & 1] if t > 1 else None,
+                    ptrs[(t + 1) & 1], enc_ptrs, F, add.data_ptr(), logp.data_ptr(), max_words, EOS_ID, scores.data_ptr(),
+                    tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(), done.data_ptr(), done_host[t - 1].data_ptr(),
+                    ws.data_ptr(), ws.numel(), tail_ws.data_ptr(), tail_ws.numel(), st), "hirest_caption_beam_step")
             else:
                 _lib.check(lib.hirest_caption_decode_step(
                     C.byref(desc), R, t - 1, ids.data_ptr(), parents.data_ptr() if t > 1 else None,

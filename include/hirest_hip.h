@@ -374,6 +374,11 @@ int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* ids, const fl
                        const float* gamma, const float* beta, float eps, float* ln_out, int64_t ldl, const float* W, int64_t ldw,
                        const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M, int32_t N, int32_t K,
                        int32_t act, void* stream);
+/* The LM-head form of hirest_gemm_f32_ln (N >= 8192, K = 768, rows given directly, no ln_out, no activation / residual) that also
+ * writes colmax[M, ceil(N / 16)]: per row, the maximum of each 16-column tile of `out` (what hirest_caption_beam_step's tail uses
+ * instead of scanning the rows for their maximum). */
+int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const float* gamma, const float* beta, float eps, const float* W, int64_t ldw,
+                              const float* bias, float* out, int64_t ldo, float* colmax, int32_t M, int32_t N, int32_t K, void* stream);
 /* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*64]; no key masking (the
  * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3). */
 int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,
@@ -465,6 +470,16 @@ int hirest_caption_beam_tail(const float* logits, int64_t ldx, const float* row_
                              int32_t step, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr,
                              int32_t* n_steps, int32_t* done, int32_t* next_ids, int32_t* next_parents, float* next_add,
                              int32_t* done_host, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One word of the beam search in one call = hirest_caption_decode_logits + hirest_caption_beam_tail on R = B * beam rows at
+ * `position` (= the tail's step).  ids / parent_rows / row_add ([R]) are the step's inputs and receive the next step's (as
+ * hirest_beam_advance's next_ids / next_parents / next_add); logits: [R, vocab_padded] scratch.  workspace:
+ * hirest_caption_step_workspace_bytes; tail_workspace: hirest_caption_beam_tail_workspace_bytes. */
+int hirest_caption_beam_step(const hirest_caption_decoder* d, int32_t B, int32_t beam, int32_t position, int32_t* ids, int32_t* parent_rows,
+                             const float* const* kv_in, float* const* kv_out, const float* const* enc_kv, int32_t F, float* row_add,
+                             float* logits, int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr,
+                             int32_t* n_steps, int32_t* done, int32_t* done_host, void* workspace, size_t workspace_bytes,
+                             void* tail_workspace, size_t tail_workspace_bytes, void* stream);
 
 /* Beam bookkeeping of one decoding step on the device (clip4caption/modules/beam.py:70-92): val / idx = the sorted top-`beam` of
  * every sample's beam x vocab scores ([B, beam]; idx = source_beam * vocab + word).  Per sample b that is not done: scores <- val,

@@ -48,7 +48,7 @@ def test_argument_errors_without_gpu(lib):
     d = _lib.CaptionDecoder(2, 12, 768, 3072, 30528, 512)
     al = lambda v: (v + 255) // 256 * 256
     assert lib.hirest_caption_step_workspace_bytes(ctypes.byref(d), 25) == \
-        5 * al(25 * 768 * 4) + al(25 * 3 * 768 * 4) - al(25 * 768 * 4) + al(25 * 3072 * 4) + al(25 * 30528 * 4) + al(25 * 4)
+        5 * al(25 * 768 * 4) + al(25 * 3 * 768 * 4) - al(25 * 768 * 4) + al(25 * 3072 * 4) + al(25 * 30528 * 4) + al(25 * 4) + al(25 * 1908 * 4)
     assert lib.hirest_caption_step_workspace_bytes(None, 25) == 0
     assert lib.hirest_caption_decode_step(ctypes.byref(d), 25, 0, None, None, None, None, None, 20, None, None, None, 0, None) == -1
     assert lib.hirest_beam_advance(None, None, 5, 5, 30528, 0, 48, 102, None, None, None, None, None, None, None, None, None) == -1
@@ -66,6 +66,9 @@ def test_argument_errors_without_gpu(lib):
     assert lib.hirest_gemm_f32_ln(None, 768, None, None, None, None, None, 1e-12, None, 0, None, 768, None, None, 0, None, 768, 25, 768, 768, 0,
                                   None) == -1
     assert lib.hirest_attention_f32_decode(None, 768, None, None, 768, None, 0, None, None, 0, None, None, None, 25, 12, 0.125, 0.0, 0.0, None) == -1
+    assert lib.hirest_caption_beam_step(ctypes.byref(d), 5, 5, 0, None, None, None, None, None, 20, None, None, 48, 102, None, None, None, None,
+                                        None, None, None, 0, None, 0, None) == -1
+    assert lib.hirest_gemm_f32_ln_colmax(None, 768, None, None, 1e-12, None, 768, None, None, 30528, None, 25, 30528, 768, None) == -1
     assert lib.hirest_gemm_f32_workspace_bytes(1500, 768, 3072) == 4 * 1500 * 768 * 4       # 288 tiles: split over the four K quarters
     assert lib.hirest_gemm_f32_workspace_bytes(1500, 3072, 768) == 0 and lib.hirest_gemm_f32_workspace_bytes(25, 768, 3072) == 0
     assert lib.hirest_gemm_f32_ws(None, 768, None, 768, None, None, 0, None, 0, None, 768, 1500, 768, 3072, 0, None, 0, None) == -1

@@ -197,6 +197,26 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
         assert model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"] == ref, nb
 
 
+@pytest.mark.parametrize("M", [25, 15, 32, 3])
+def test_lm_head_tile_maxima(dev, M):
+    """hirest_gemm_f32_ln_colmax: same output as hirest_gemm_f32_ln, and colmax[m][t] = max of out[m][16 t .. 16 t + 15]"""
+    from hirest_amd import _lib, ops
+    lib, st = _lib.load(), ops.stream_ptr()
+    N, K = 30528, 768
+    x = synth.tensor("tm.x", (M, K), 2.0, 3).to(dev)
+    w = synth.tensor("tm.w", (N, K), 0.05, 3).to(dev)
+    b = synth.tensor("tm.b", (N,), 0.3, 3).to(dev)
+    g = (1.0 + synth.tensor("tm.g", (K,), 0.2, 3)).to(dev)
+    be = synth.tensor("tm.be", (K,), 0.2, 3).to(dev)
+    ref = torch.empty((M, N), device=dev); out = torch.empty((M, N), device=dev); cm = torch.full((M, N // 16), 7.0, device=dev)
+    _lib.check(lib.hirest_gemm_f32_ln(x.data_ptr(), K, None, None, None, g.data_ptr(), be.data_ptr(), 1e-12, None, 0, w.data_ptr(), K, b.data_ptr(),
+                                      None, 0, ref.data_ptr(), N, M, N, K, 0, st), "gemm_ln")
+    _lib.check(lib.hirest_gemm_f32_ln_colmax(x.data_ptr(), K, g.data_ptr(), be.data_ptr(), 1e-12, w.data_ptr(), K, b.data_ptr(), out.data_ptr(), N,
+                                             cm.data_ptr(), M, N, K, st), "gemm_ln_colmax")
+    assert torch.equal(out, ref)
+    assert torch.equal(cm, ref.reshape(M, N // 16, 16).max(-1).values)
+
+
 def test_round3_fp32_kernels_randomised_bit_equality(dev):
     """tools/f32_stress.py: random shapes / options — hirest_gemm_f32's automatic dispatch (16-column LDS-DMA kernel, split form) vs the
     forced 64x64 kernel, hirest_gemm_f32_ln vs hirest_layernorm + hirest_gemm_f32, hirest_attention_f32_decode vs gather +
