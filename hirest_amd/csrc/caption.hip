@@ -84,41 +84,52 @@ constexpr int TAIL_CHUNK = 4096, TAIL_STAT = 17;            // floats of statist
 __device__ __forceinline__ bool tail_better(float sa, int ta, float sb, int tb) { return sa > sb || (sa == sb && ta > tb); }
 
 // top k of (val, idx) pairs held 16 per thread by a 256-thread block; thread 0 reports pick j through put(j, val, idx).
-// One barrier per pick: the four wave winners go through a two-deep LDS buffer and every thread reduces them itself.
+// The pairs are packed into one 64-bit key each — the float's bits made monotone in the high word (-0 taken as +0), the index in the
+// low word — so that topk_kernel's strict order (higher score, then higher index) is the unsigned order of the keys and a pick is a
+// branch-free max: written with tail_better's && / || the compiler turned the 16-element scan into a cascade of ~50 exec-mask
+// branches per pick (12 us for five picks).  One barrier per pick: the four wave winners go through a two-deep LDS buffer and
+// every thread reduces them itself.
+__device__ __forceinline__ unsigned long long tail_key(float v, int idx) {
+    unsigned u = __builtin_bit_cast(unsigned, v + 0.0f);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+    return idx >= 0 ? ((unsigned long long)u << 32) | (unsigned)idx : 0ull;          // 0 = no element (a real key has a non-zero high word
+}                                                                                      // unless the score is the most negative NaN pattern)
+__device__ __forceinline__ float tail_key_value(unsigned long long k) {
+    unsigned u = (unsigned)(k >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+    return __builtin_bit_cast(float, u);
+}
 template <class Put>
 __device__ __forceinline__ void block_topk16(const float (&val)[16], const int (&idx)[16], int k, Put put) {
-    __shared__ float rs[2][4];
-    __shared__ int ri[2][4];
+    __shared__ unsigned long long rk[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto pick = [](float& s1, int& i1, float s2, int i2) {
-        const bool second = i2 >= 0 && (i1 < 0 || tail_better(s2, i2, s1, i1));
-        s1 = second ? s2 : s1; i1 = second ? i2 : i1;
-    };
-    float prev_s = INFINITY; int prev_i = 0x7fffffff;
+    unsigned long long key[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) key[e] = tail_key(val[e], idx[e]);
+    auto umax = [](unsigned long long a, unsigned long long b) { return a > b ? a : b; };
+    unsigned long long prev = ~0ull;
     for (int j = 0; j < k; ++j) {
-        float bs = -INFINITY; int bi = -1;
+        unsigned long long best = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const bool take = idx[e] >= 0 && tail_better(prev_s, prev_i, val[e], idx[e]) && (bi < 0 || tail_better(val[e], idx[e], bs, bi));
-            bs = take ? val[e] : bs; bi = take ? idx[e] : bi;
+        for (int e = 0; e < 16; ++e) best = umax(best, key[e] < prev ? key[e] : 0ull);
+        {   // best of the wave on the cross-lane data paths (common.h: wave_max_x), the two words moving together
+            int lo = (int)(unsigned)best, hi = (int)(unsigned)(best >> 32);
+            auto join = [](int l, int h) { return ((unsigned long long)(unsigned)h << 32) | (unsigned)l; };
+            int l2 = lo, h2 = hi;
+            lane_swap32(lo, l2); lane_swap32(hi, h2); best = umax(join(lo, hi), join(l2, h2));
+            lo = l2 = (int)(unsigned)best; hi = h2 = (int)(unsigned)(best >> 32);
+            lane_swap16(lo, l2); lane_swap16(hi, h2); best = umax(join(lo, hi), join(l2, h2));
+            lo = (int)(unsigned)best; hi = (int)(unsigned)(best >> 32);
+            best = umax(best, join(lane_dpp<0x128>(lo), lane_dpp<0x128>(hi))); lo = (int)(unsigned)best; hi = (int)(unsigned)(best >> 32);
+            best = umax(best, join(lane_dpp<0x124>(lo), lane_dpp<0x124>(hi))); lo = (int)(unsigned)best; hi = (int)(unsigned)(best >> 32);
+            best = umax(best, join(lane_dpp<0x4E>(lo), lane_dpp<0x4E>(hi))); lo = (int)(unsigned)best; hi = (int)(unsigned)(best >> 32);
+            best = umax(best, join(lane_dpp<0xB1>(lo), lane_dpp<0xB1>(hi)));
         }
-        {   // best of the wave on the cross-lane data paths (common.h: wave_max_x), the pair (score, index) moving together
-            float s2 = bs; int i2 = bi;
-            lane_swap32(bs, s2); lane_swap32(bi, i2); pick(bs, bi, s2, i2);
-            s2 = bs; i2 = bi;
-            lane_swap16(bs, s2); lane_swap16(bi, i2); pick(bs, bi, s2, i2);
-            pick(bs, bi, lane_dpp<0x128>(bs), lane_dpp<0x128>(bi));
-            pick(bs, bi, lane_dpp<0x124>(bs), lane_dpp<0x124>(bi));
-            pick(bs, bi, lane_dpp<0x4E>(bs), lane_dpp<0x4E>(bi));
-            pick(bs, bi, lane_dpp<0xB1>(bs), lane_dpp<0xB1>(bi));
-        }
-        if (lane == 0) { rs[j & 1][wave] = bs; ri[j & 1][wave] = bi; }
+        if (lane == 0) rk[j & 1][wave] = best;
         __syncthreads();
-        float sb = rs[j & 1][0]; int ib = ri[j & 1][0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) pick(sb, ib, rs[j & 1][w], ri[j & 1][w]);
-        if (tid == 0) put(j, sb, ib);                        // ib < 0: fewer than j + 1 elements
-        prev_s = sb; prev_i = ib;
+        best = umax(umax(rk[j & 1][0], rk[j & 1][1]), umax(rk[j & 1][2], rk[j & 1][3]));
+        if (tid == 0) put(j, tail_key_value(best), best ? (int)(unsigned)best : -1);     // -1: fewer than j + 1 elements
+        prev = best ? best : 0ull;                           // (nothing left: every later pick is empty too)
     }
 }
 
