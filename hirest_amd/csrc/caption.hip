@@ -210,22 +210,18 @@ __global__ __launch_bounds__(256) void tail_select_kernel(const float* __restric
     __shared__ int top_i[16];
     __shared__ float row_mx[16], row_lse[16], row_ad[16];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (done[b] != 0) {                                      // (block-uniform: written only by this block, in an earlier launch)
-        if (tid < beam) { const int row = b * beam + tid; next_ids[row] = eos; next_parents[row] = row; next_add[row] = 0.f; }
-        if (tid == 0 && done_host) done_host[b] = ((step + 1) << 1) | 1;
-        return;
-    }
-    if (tid < beam) {
-        const float* st = stat + (int64_t)(b * beam + tid) * TAIL_STAT;
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += st[w];            // log_softmax_kernel's fixed order
-        row_lse[tid] = logf(t); row_mx[tid] = st[16]; row_ad[tid] = row_add[b * beam + tid];
-    }
-    __syncthreads();
+    // every load of the kernel is issued here, unconditionally and on clamped indices, before the first use: three dependent round
+    // trips (done, the row statistics, the candidates) become one
     const int per_row = nsel * beam, ncand = beam * per_row;  // <= 16 * 8 * 16 = 2048 = 8 per thread; 16 slots
+    const int was_done = done[b];                            // (block-uniform: written only by this block, in an earlier launch)
+    const int rb = b * beam + (tid < beam ? tid : beam - 1);
+    float stv[TAIL_STAT];
+#pragma unroll
+    for (int w = 0; w < TAIL_STAT; ++w) stv[w] = stat[(int64_t)rb * TAIL_STAT + w];
+    const float radd = row_add[rb];
     float val[16];
     int idx[16];
-    int civ[16];                                             // (loads unconditional on a clamped index and all issued before the first use)
+    int civ[16];
     float cxv[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -233,6 +229,18 @@ __global__ __launch_bounds__(256) void tail_select_kernel(const float* __restric
         civ[u] = ci[(int64_t)b * ncand + vc];
         cxv[u] = cx[(int64_t)b * ncand + vc];
     }
+    if (was_done != 0) {
+        if (tid < beam) { const int row = b * beam + tid; next_ids[row] = eos; next_parents[row] = row; next_add[row] = 0.f; }
+        if (tid == 0 && done_host) done_host[b] = ((step + 1) << 1) | 1;
+        return;
+    }
+    if (tid < beam) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += stv[w];           // log_softmax_kernel's fixed order
+        row_lse[tid] = logf(t); row_mx[tid] = stv[16]; row_ad[tid] = radd;
+    }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int v = tid + 256 * u, rr = (v < ncand ? v : ncand - 1) / per_row;
