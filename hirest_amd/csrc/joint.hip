@@ -1032,6 +1032,23 @@ __global__ __launch_bounds__(256) void joint_base_kernel(const float* __restrict
     }
 }
 
+__device__ __forceinline__ float time_grid_value(int t, int n) {
+    if (t >= n) return 0.f;
+    // torch.linspace(0, 1, n): step = 1/(n-1); values i*step for the first half, 1-(n-1-i)*step for the second
+    float lin;
+    if (n == 1) lin = 0.f;
+    else {
+        const float step = 1.0f / (float)(n - 1);
+        lin = t < n / 2 ? (float)t * step : 1.0f - (float)(n - 1 - t) * step;
+    }
+    return (lin - 0.5f) * 2.0f;
+}
+// the grid itself, [B, T]: the weight of temporal_embed.0.weight's gradient column sum (the training step must not fetch n_valid
+// to the host to build it: that is a device synchronisation in the middle of the backward)
+__global__ __launch_bounds__(256) void joint_time_grid_kernel(const int32_t* __restrict__ n_valid, float* __restrict__ grid, int B, int T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * T) grid[i] = time_grid_value(i % T, n_valid[i / T]);
+}
 // temporal input: tin[b,t,:] = tanh(time(b,t) * w1 + b1), time = (linspace(0,1,n_b)[t]-0.5)*2 for t < n_b else 0
 // (modeling.py:176-195; linspace(0,1,1) = [0]).  One thread per 4 channels.
 __global__ __launch_bounds__(256) void joint_time_kernel(const int32_t* __restrict__ n_valid, const float* __restrict__ w1,
@@ -1042,18 +1059,7 @@ __global__ __launch_bounds__(256) void joint_time_kernel(const int32_t* __restri
         const int c = (int)(idx % nv) * 4;
         const int64_t row = idx / nv;
         const int t = (int)(row % T), b = (int)(row / T);
-        const int n = n_valid[b];
-        float tm = 0.f;
-        if (t < n) {
-            // torch.linspace(0, 1, n): step = 1/(n-1); values i*step for the first half, 1-(n-1-i)*step for the second
-            float lin;
-            if (n == 1) lin = 0.f;
-            else {
-                const float step = 1.0f / (float)(n - 1);
-                lin = t < n / 2 ? (float)t * step : 1.0f - (float)(n - 1 - t) * step;
-            }
-            tm = (lin - 0.5f) * 2.0f;
-        }
+        const float tm = time_grid_value(t, n_valid[b]);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = tanhf(tm * w1[c + e] + b1[c + e]);
@@ -1445,6 +1451,13 @@ extern "C" int hirest_joint_time_features(const int32_t* n_valid, const float* w
     if (!n_valid || !w1 || !b1 || !tin || B <= 0 || T <= 0 || E % 4 != 0) return HIREST_E_BADARG;
     hipLaunchKernelGGL(joint_time_kernel, dim3(grid1d((int64_t)B * T * (E / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        n_valid, w1, b1, tin, B, T, E);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_joint_time_grid_f32(const int32_t* n_valid, int32_t B, int32_t T, float* grid, void* stream) {
+    if (!n_valid || !grid || B <= 0 || T <= 0 || (int64_t)B * T > INT32_MAX) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(joint_time_grid_kernel, dim3((B * T + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n_valid, grid,
+                       B, T);
     return hirest_launch_status();
 }
 

@@ -338,7 +338,8 @@ def _encoder_backward(model, P, S, dx, G):
     G["temporal_embed.2.weight"] = _K.grad_weight(df, S["tin"])
     G["temporal_embed.2.bias"] = _K.colsum(df)
     dpre = _K.act_bwd(S["tin"], _K.grad_input(df, P["temporal_embed.2.weight"]), 3)
-    time = time_grid(S["n_valid"], T).reshape(R).contiguous()
+    time = torch.empty((R,), dtype=torch.float32, device=dev)      # on the device: reading n_valid back would stall the step's enqueue
+    _chk(lib.hirest_joint_time_grid_f32(S["n_valid"].data_ptr(), B, T, time.data_ptr(), ops.stream_ptr()), "time_grid")
     G["temporal_embed.0.weight"] = _K.colsum(dpre, weight=time).reshape(E, 1)
     G["temporal_embed.0.bias"] = _K.colsum(dpre)
     if model.use_asr:

@@ -399,6 +399,9 @@ int hirest_log_softmax_f32(const float* x, int64_t ldx, const float* row_add, fl
 /* tin[b,t,:] = tanh(time(b,t)*w1 + b1), time = (linspace(0,1,n_valid[b])[t]-0.5)*2, 0 past n_valid (modeling.py:176-195) */
 int hirest_joint_time_features(const int32_t* n_valid, const float* w1, const float* b1, float* tin,
                                int32_t B, int32_t T, int32_t E, void* stream);
+/* grid[b][t] = that time(b,t) itself, [B, T] fp32: the per-row weight of temporal_embed.0.weight's gradient (a column sum of
+ * d pre-activation * time), built on the device so that the training step never reads n_valid back (modeling.py:176-193) */
+int hirest_joint_time_grid_f32(const int32_t* n_valid, int32_t B, int32_t T, float* grid, void* stream);
 /* base = v * (text_proj/||text_proj||)[:,None,:] + asr + temporal   (modeling.py:163-195, loop invariant) */
 int hirest_joint_base(const float* v, const float* text_proj, const float* asr, const float* temporal, float* base,
                       int32_t B, int32_t T, int32_t E, void* stream);

@@ -74,6 +74,7 @@ def test_argument_errors_without_gpu(lib):
     assert lib.hirest_gemm_f32_ws(None, 768, None, 768, None, None, 0, None, 0, None, 768, 1500, 768, 3072, 0, None, 0, None) == -1
     assert lib.hirest_gemm_f32_layouts(None, 768, 1, None, 768, 1, None, None, 0, None, 768, 768, 768, 1500, 0, None, 0, None) == -1
     assert lib.hirest_gemm_f32_layouts_workspace_bytes(768, 768, 1500) == 4 * 768 * 768 * 4 and lib.hirest_gemm_f32_layouts_workspace_bytes(3072, 3072, 1500) == 0
+    assert lib.hirest_joint_time_grid_f32(None, 5, 300, None, None) == -1
 
 
 def test_workspace_size_formula(lib):

@@ -211,3 +211,20 @@ def test_backward_products_in_place_equal_the_transposed_copies():
         train.LAYOUT_GEMM = True
         assert torch.equal(outs[0][0], outs[1][0]), ("dX", R, O, I)
         assert torch.equal(outs[0][1], outs[1][1]), ("dW", R, O, I)
+
+
+@pytest.mark.gpu
+def test_time_grid_on_device_equals_the_host_linspace_table():
+    """hirest_joint_time_grid_f32 (the backward's weight for temporal_embed.0.weight, built without reading n_valid back) against
+    train.time_grid, the torch.linspace restatement of modeling.py:176-193 — bit for bit, incl. n = 1 and n = T."""
+    import ctypes as C
+    from hirest_amd import _lib, ops, train
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    T = 97
+    n = torch.tensor([1, 2, 3, 50, 96, 97, 31], dtype=torch.int32)
+    want = train.time_grid(n, T)
+    nd = n.to(dev)
+    got = torch.full((n.numel(), T), 7.0, dtype=torch.float32, device=dev)
+    assert lib.hirest_joint_time_grid_f32(nd.data_ptr(), n.numel(), T, got.data_ptr(), ops.stream_ptr()) == 0
+    assert torch.equal(got.cpu(), want)
