@@ -86,6 +86,15 @@ class CaptionDecoder(C.Structure):
                [(n, C.c_void_p) for n in ("tr_w", "tr_b", "tr_ln_g", "tr_ln_b", "lm_w", "lm_b")]
 
 
+class ColsumItem(C.Structure):
+    """hirest_colsum_item (include/hirest_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("row_weight", C.c_void_p), ("row_select", C.c_void_p), ("out", C.c_void_p), ("ldx", C.c_int64),
+                ("R", C.c_int32), ("C", C.c_int32), ("select_value", C.c_int32), ("reserved", C.c_int32)]
+
+
+COLSUM_GROUP_MAX = 40
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("kind", C.c_int32), ("tag", C.c_int32), ("d0", C.c_int64), ("d1", C.c_int64), ("d2", C.c_int64),
                 ("ms", C.c_float)]
@@ -180,6 +189,7 @@ _SIGNATURES = {
     "hirest_joint_mask_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int32, C.c_void_p]),
     "hirest_transpose_pad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "hirest_weighted_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "hirest_weighted_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "hirest_scale_by_device_scalar_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hirest_act_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),

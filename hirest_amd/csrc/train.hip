@@ -40,12 +40,12 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 // out[c] = sum_r w(r) x[r][c],  w(r) = (wt ? wt[r] : 1) * (sel ? sel[r] == sel_value : 1).  One block per 32 columns (a row
 // segment = one 128-B line), 32 row lanes of 32 threads, four independent partial sums per thread so that four rows are in
 // flight per lane, then a fixed-order LDS reduction over the row lanes (deterministic: no atomics).
-__global__ __launch_bounds__(1024) void weighted_colsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
-                                                               const int32_t* __restrict__ sel, int sel_value, int R, int C,
-                                                               float* __restrict__ out) {
+__device__ __forceinline__ void weighted_colsum_block(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
+                                                      const int32_t* __restrict__ sel, int sel_value, int R, int C,
+                                                      float* __restrict__ out, int block) {
     __shared__ float red[32][33];
     const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + col;
+    const int c = block * 32 + col;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     auto wgt = [&](int r) -> float {
         float w = wt ? wt[r] : 1.f;
@@ -70,6 +70,23 @@ __global__ __launch_bounds__(1024) void weighted_colsum_kernel(const float* __re
         for (int i = 0; i < 32; ++i) t += red[i][col];
         out[c] = t;
     }
+}
+
+__global__ __launch_bounds__(1024) void weighted_colsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
+                                                               const int32_t* __restrict__ sel, int sel_value, int R, int C,
+                                                               float* __restrict__ out) {
+    weighted_colsum_block(x, ldx, wt, sel, sel_value, R, C, out, blockIdx.x);
+}
+
+// Many column sums in one launch (the ~36 bias / LayerNorm / embedding gradients of a training step, each a 5-7 us kernel of a few
+// blocks): the item table travels in the kernel arguments, a block finds its item by a scan over the first-block numbers (uniform,
+// scalar loads) and then runs exactly the single-matrix block above — the same bits.
+struct ColsumGroup { hirest_colsum_item item[HIREST_COLSUM_GROUP_MAX]; int first[HIREST_COLSUM_GROUP_MAX]; int count; };
+__global__ __launch_bounds__(1024) void weighted_colsum_grouped_kernel(ColsumGroup g) {
+    int i = 0;
+    while (i + 1 < g.count && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    const hirest_colsum_item& it = g.item[i];
+    weighted_colsum_block(it.x, it.ldx, it.row_weight, it.row_select, it.select_value, it.R, it.C, it.out, blockIdx.x - g.first[i]);
 }
 
 __device__ __forceinline__ float gelu_grad(float x) {      // d/dx [x Phi(x)] = Phi(x) + x phi(x)
@@ -585,6 +602,20 @@ extern "C" int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const flo
     if (!x || !out || R <= 0 || C <= 0) return HIREST_E_BADARG;
     hipLaunchKernelGGL(weighted_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, S_(stream), x, ldx, row_weight, row_select,
                        select_value, R, C, out);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_weighted_colsum_grouped_f32(const hirest_colsum_item* items, int32_t count, void* stream) {
+    if (!items || count <= 0) return HIREST_E_BADARG;
+    for (int i = 0; i < count; ++i)
+        if (!items[i].x || !items[i].out || items[i].R <= 0 || items[i].C <= 0) return HIREST_E_BADARG;
+    for (int base = 0; base < count; base += HIREST_COLSUM_GROUP_MAX) {
+        ColsumGroup g;
+        g.count = count - base < HIREST_COLSUM_GROUP_MAX ? count - base : HIREST_COLSUM_GROUP_MAX;
+        int blocks = 0;
+        for (int i = 0; i < g.count; ++i) { g.item[i] = items[base + i]; g.first[i] = blocks; blocks += (items[base + i].C + 31) / 32; }
+        hipLaunchKernelGGL(weighted_colsum_grouped_kernel, dim3(blocks), dim3(1024), 0, S_(stream), g);
+    }
     return hirest_launch_status();
 }
 

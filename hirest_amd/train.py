@@ -109,10 +109,36 @@ class _K:
             return _K.layouts(dy, dy.stride(0), True, x, x.stride(0), True, O, I, R)        # A(m = o, k = r) = dY[r][o], B(n = i, k = r) = X[r][i]
         return _K.gemm(_K.transpose_pad(dy), _K.transpose_pad(x))
 
+    # column sums asked for while a batch is open are recorded and run as ONE launch by flush_colsums(): a step has ~36 of them
+    # (bias, LayerNorm and embedding gradients), each a few blocks.  Their results are only read after the backward returns.
+    _pending = None
+
     @staticmethod
-    def colsum(x, weight=None, select=None, value=0):
+    def open_colsums():
+        _K._pending = []
+
+    @staticmethod
+    def flush_colsums():
+        items, _K._pending = _K._pending, None
+        if not items:
+            return
+        arr = (_lib.ColsumItem * len(items))()
+        for slot, (x, weight, select, value, out) in zip(arr, items):
+            slot.x, slot.ldx, slot.R, slot.C = x.data_ptr(), x.stride(0), x.shape[0], x.shape[1]
+            slot.row_weight = weight.data_ptr() if weight is not None else None
+            slot.row_select = select.data_ptr() if select is not None else None
+            slot.select_value, slot.out = value, out.data_ptr()
+        _chk(_lib.load().hirest_weighted_colsum_grouped_f32(arr, len(items), ops.stream_ptr()), "colsum_grouped")
+        # (`items` kept the operands alive up to here; the caching allocator orders their reuse after this launch on the stream)
+
+    @staticmethod
+    def colsum(x, weight=None, select=None, value=0, out=None):
         R, Cc = x.shape
-        out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        if _K._pending is not None:
+            _K._pending.append((x, weight, select, value, out))
+            return out
         _chk(_lib.load().hirest_weighted_colsum_f32(x.data_ptr(), x.stride(0), weight.data_ptr() if weight is not None else None,
                                                     select.data_ptr() if select is not None else None, value, R, Cc, out.data_ptr(),
                                                     ops.stream_ptr()), "colsum")
@@ -321,15 +347,19 @@ def _encoder_backward(model, P, S, dx, G):
         _K.layernorm_bwd(S["x0"], dxe, P[_V + "embeddings.LayerNorm.weight"], 1e-12)
     pos = P[_V + "embeddings.position_embeddings.weight"]
     dpos = torch.zeros_like(pos)
-    dpos[:T] = _K.colsum(dx0.reshape(B, T * Hd)).reshape(T, Hd)
+    _K.colsum(dx0.reshape(B, T * Hd), out=dpos[:T].reshape(-1))
     G[_V + "embeddings.position_embeddings.weight"] = dpos
     G[_V + "embeddings.word_embeddings.weight"] = _K.grad_weight(dx0, S["f"])
     G[_V + "embeddings.word_embeddings.bias"] = _K.colsum(dx0)
     df = _K.grad_input(dx0, P[_V + "embeddings.word_embeddings.weight"])
     # ---- fusion
-    G["mask_embed.weight"] = torch.stack([_K.colsum(df, select=mm32.reshape(-1), value=k) for k in (0, 1)])
+    G["mask_embed.weight"] = torch.empty((2, E), dtype=torch.float32, device=dev)
+    for k in (0, 1):
+        _K.colsum(df, select=mm32.reshape(-1), value=k, out=G["mask_embed.weight"][k])
     if S["boundary"]:
-        G["boundary_embed.weight"] = torch.stack([_K.colsum(df, select=S["bm32"].reshape(-1), value=k) for k in (0, 1)])
+        G["boundary_embed.weight"] = torch.empty((2, E), dtype=torch.float32, device=dev)
+        for k in (0, 1):
+            _K.colsum(df, select=S["bm32"].reshape(-1), value=k, out=G["boundary_embed.weight"][k])
     dv = torch.empty_like(df)
     dtn = torch.empty((B, E), dtype=torch.float32, device=dev)
     _chk(lib.hirest_joint_base_bwd_f32(df.data_ptr(), S["v"].data_ptr(), S["tn"].data_ptr(), dv.data_ptr(), dtn.data_ptr(), B, T, E,
@@ -355,6 +385,19 @@ def _encoder_backward(model, P, S, dx, G):
     _chk(lib.hirest_l2norm_bwd_f32(S["t"].data_ptr(), dtn.data_ptr(), dt.data_ptr(), B, E, ops.stream_ptr()), "l2norm_bwd")
     G["clip_g_map_text.weight"] = _K.grad_weight(dt, S["text"])
     G["clip_g_map_text.bias"] = _K.colsum(dt)
+
+
+def _colsum_batched(backward):
+    """Run a backward with _K's column-sum batch open; an exception closes it without launching (nothing may stay recorded)."""
+    def wrapped(ctx, gloss):
+        _K.open_colsums()
+        try:
+            out = backward(ctx, gloss)
+            _K.flush_colsums()
+            return out
+        finally:
+            _K._pending = None
+    return wrapped
 
 
 class MomentLoss(torch.autograd.Function):
@@ -401,6 +444,7 @@ class MomentLoss(torch.autograd.Function):
         return loss.reshape(())
 
     @staticmethod
+    @_colsum_batched
     def backward(ctx, gloss):
         S = ctx.S
         if S is None:
@@ -529,6 +573,7 @@ class CaptionLoss(torch.autograd.Function):
         return loss.reshape(())
 
     @staticmethod
+    @_colsum_batched
     def backward(ctx, gloss):
         S = ctx.S
         if S is None:
@@ -615,7 +660,7 @@ class CaptionLoss(torch.autograd.Function):
             _K.layernorm_bwd(S["e0"], dxe, P[_D + "embeddings.LayerNorm.weight"], 1e-12)
         pos = P[_D + "embeddings.position_embeddings.weight"]
         dpos = torch.zeros_like(pos)
-        dpos[:L] = _K.colsum(de0.reshape(B, L * Hd)).reshape(L, Hd)
+        _K.colsum(de0.reshape(B, L * Hd), out=dpos[:L].reshape(-1))
         G[_D + "embeddings.position_embeddings.weight"] = dpos
         _chk(lib.hirest_embedding_bwd_f32(S["ids32"].data_ptr(), de0.data_ptr(), dWe.data_ptr(), R, Hd, ops.stream_ptr()), "embedding_bwd")
         G[_D + "embeddings.word_embeddings.weight"] = dWe[:V]

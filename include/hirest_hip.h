@@ -510,6 +510,20 @@ int hirest_transpose_pad_f32(const float* in, int64_t ld_in, int32_t R, int32_t 
  * the Linear(1, E) time embedding (weights) */
 int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const float* row_weight, const int32_t* row_select,
                                int32_t select_value, int32_t R, int32_t C, float* out, void* stream);
+/* The same sums for up to any number of matrices in one call (launches of HIREST_COLSUM_GROUP_MAX items): a training step's bias,
+ * LayerNorm and embedding gradients are ~36 such sums of a few blocks each, which cost more in launches than in work.  Each item is
+ * computed exactly as by hirest_weighted_colsum_f32 (same bits).  `items` is a HOST array, copied into the kernel arguments; the
+ * matrices it points to must stay alive and unchanged until the call has been enqueued AND executed on `stream`. */
+#define HIREST_COLSUM_GROUP_MAX 40
+typedef struct hirest_colsum_item {
+    const float*   x;            /* [R, C] fp32, row stride ldx */
+    const float*   row_weight;   /* [R] or NULL */
+    const int32_t* row_select;   /* [R] or NULL: only rows with row_select[r] == select_value count */
+    float*         out;          /* [C] */
+    int64_t        ldx;
+    int32_t        R, C, select_value, reserved;
+} hirest_colsum_item;
+int hirest_weighted_colsum_grouped_f32(const hirest_colsum_item* items, int32_t count, void* stream);
 /* y = act(pre) and dx = dy * act'(pre);  act: 0 identity, 1 gelu (erf form), 2 tanh; backward only: 3 = tanh given its OUTPUT
  * in `pre` (1 - y^2) */
 int hirest_act_f32(const float* pre, float* y, int64_t n, int32_t act, void* stream);

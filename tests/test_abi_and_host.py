@@ -75,6 +75,10 @@ def test_argument_errors_without_gpu(lib):
     assert lib.hirest_gemm_f32_layouts(None, 768, 1, None, 768, 1, None, None, 0, None, 768, 768, 768, 1500, 0, None, 0, None) == -1
     assert lib.hirest_gemm_f32_layouts_workspace_bytes(768, 768, 1500) == 4 * 768 * 768 * 4 and lib.hirest_gemm_f32_layouts_workspace_bytes(3072, 3072, 1500) == 0
     assert lib.hirest_joint_time_grid_f32(None, 5, 300, None, None) == -1
+    from hirest_amd._lib import ColsumItem, COLSUM_GROUP_MAX
+    assert ctypes.sizeof(ColsumItem) == 56 and COLSUM_GROUP_MAX == 40       # hirest_colsum_item / HIREST_COLSUM_GROUP_MAX
+    assert lib.hirest_weighted_colsum_grouped_f32(None, 3, None) == -1
+    assert lib.hirest_weighted_colsum_grouped_f32((ColsumItem * 2)(), 2, None) == -1     # NULL matrices: refused before any launch
 
 
 def test_workspace_size_formula(lib):

@@ -228,3 +228,39 @@ def test_time_grid_on_device_equals_the_host_linspace_table():
     got = torch.full((n.numel(), T), 7.0, dtype=torch.float32, device=dev)
     assert lib.hirest_joint_time_grid_f32(nd.data_ptr(), n.numel(), T, got.data_ptr(), ops.stream_ptr()) == 0
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.gpu
+def test_grouped_column_sums_equal_the_single_calls():
+    """hirest_weighted_colsum_grouped_f32 (one launch for a step's bias / LayerNorm / embedding gradients) against
+    hirest_weighted_colsum_f32 item by item, bit for bit: plain, weighted, selected, strided, a single column, and more items than
+    one launch takes (HIREST_COLSUM_GROUP_MAX)."""
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for i in range(_lib.COLSUM_GROUP_MAX + 7):
+        R, Cc = [(1500, 768), (25, 3072), (1500, 1), (5, 300 * 768), (240, 513), (1, 64), (97, 31)][i % 7]
+        big = torch.randn((R, Cc + 3 * (i % 2)), generator=g).to(dev)
+        x = big[:, :Cc]                                                        # (odd cases: row stride > C)
+        wt = torch.randn((R,), generator=g).to(dev) if i % 3 == 1 else None
+        sel = torch.randint(0, 2, (R,), generator=g, dtype=torch.int32).to(dev) if i % 3 == 2 else None
+        cases.append((x, wt, sel, i % 2))
+    want, got = [], []
+    arr = (_lib.ColsumItem * len(cases))()
+    for slot, (x, wt, sel, val) in zip(arr, cases):
+        w = torch.empty((x.shape[1],), dtype=torch.float32, device=dev)
+        assert lib.hirest_weighted_colsum_f32(x.data_ptr(), x.stride(0), wt.data_ptr() if wt is not None else None,
+                                              sel.data_ptr() if sel is not None else None, val, x.shape[0], x.shape[1], w.data_ptr(),
+                                              ops.stream_ptr()) == 0
+        want.append(w)
+        o = torch.full((x.shape[1],), 3.0, dtype=torch.float32, device=dev)
+        got.append(o)
+        slot.x, slot.ldx, slot.R, slot.C, slot.out = x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], o.data_ptr()
+        slot.row_weight = wt.data_ptr() if wt is not None else None
+        slot.row_select = sel.data_ptr() if sel is not None else None
+        slot.select_value = val
+    assert lib.hirest_weighted_colsum_grouped_f32(arr, len(cases), ops.stream_ptr()) == 0
+    for i, (w, o) in enumerate(zip(want, got)):
+        assert torch.equal(w, o), i
