@@ -74,27 +74,31 @@ class _K:
         return out
 
     @staticmethod
-    def layouts(a, lda, a_kmajor, w, ldw, w_kmajor, M, N, K):
+    def layouts(a, lda, a_kmajor, w, ldw, w_kmajor, M, N, K, resid=None):
         lib = _lib.load()
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_layouts_workspace_bytes(M, N, K))
-        _chk(lib.hirest_gemm_f32_layouts(a.data_ptr(), lda, int(a_kmajor), w.data_ptr(), ldw, int(w_kmajor), None, None, 0, out.data_ptr(), N,
-                                         M, N, K, 0, ws, wsb, ops.stream_ptr()), "hirest_gemm_f32_layouts")
+        _chk(lib.hirest_gemm_f32_layouts(a.data_ptr(), lda, int(a_kmajor), w.data_ptr(), ldw, int(w_kmajor), None,
+                                         resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
+                                         out.data_ptr(), N, M, N, K, 0, ws, wsb, ops.stream_ptr()), "hirest_gemm_f32_layouts")
         return out
 
     @staticmethod
-    def grad_input(dy, w):
-        """dX = dY @ W for y = x W^T:  dY [R, N], W [N, K] -> [R, K].  The strided GEMM reads W column-wise in place (its
+    def grad_input(dy, w, resid=None):
+        """dX = dY @ W (+ resid: the gradient arriving over a residual connection, added in the GEMM's epilogue — the same bits as a
+        separate add) for y = x W^T:  dY [R, N], W [N, K] -> [R, K].  The strided GEMM reads W column-wise in place (its
         B[n][k] = W[k][n]); STRIDED_GEMM = False: through a zero-padded transposed copy and hirest_gemm_f32 (round 2)."""
-        if STRIDED_GEMM and 2.0 * dy.shape[0] * w.shape[1] * dy.shape[1] <= STRIDED_MAX_FLOP:
-            return _K.strided(dy, dy.stride(0), 1, w, 1, w.stride(0), dy.shape[0], w.shape[1], dy.shape[1])
-        if w.shape[0] % 16 != 0:
-            raise RuntimeError(f"grad_input: out_features {w.shape[0]} must be a multiple of 16")
         R, O = dy.shape
         I = w.shape[1]
-        if LAYOUT_GEMM and I % 4 == 0 and dy.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and dy.stride(1) == 1 and w.stride(1) == 1:
-            return _K.layouts(dy, dy.stride(0), False, w, w.stride(0), True, R, I, O)      # B(n = i, k = o) = W[o][i]: k-major
-        return _K.gemm(dy, _K.transpose_pad(w))
+        if STRIDED_GEMM and 2.0 * R * I * O <= STRIDED_MAX_FLOP:
+            dx = _K.strided(dy, dy.stride(0), 1, w, 1, w.stride(0), R, I, O)
+        elif w.shape[0] % 16 != 0:
+            raise RuntimeError(f"grad_input: out_features {w.shape[0]} must be a multiple of 16")
+        elif LAYOUT_GEMM and I % 4 == 0 and dy.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and dy.stride(1) == 1 and w.stride(1) == 1:
+            return _K.layouts(dy, dy.stride(0), False, w, w.stride(0), True, R, I, O, resid=resid)   # B(n = i, k = o) = W[o][i]: k-major
+        else:
+            dx = _K.gemm(dy, _K.transpose_pad(w))
+        return dx if resid is None else _K.dropout_add(dx, resid, 0.0, 0)
 
     @staticmethod
     def grad_weight(dy, x):
@@ -180,7 +184,8 @@ class _K:
 
 
 def _f32(t):
-    return t.detach().float().contiguous()
+    t = t.detach()
+    return t if t.dtype is torch.float32 and t.is_contiguous() else t.float().contiguous()
 
 
 def _scale_by_upstream(dl: torch.Tensor, gloss) -> None:
@@ -323,7 +328,7 @@ def _encoder_backward(model, P, S, dx, G):
         dhp = _K.act_bwd(Ly["hpre"], dh, 1)
         G[p + "intermediate.dense.weight"] = _K.grad_weight(dhp, Ly["aa"])
         G[p + "intermediate.dense.bias"] = _K.colsum(dhp)
-        da = _K.dropout_add(_K.grad_input(dhp, P[p + "intermediate.dense.weight"]), dxp, 0.0, 0)      # + residual path
+        da = _K.grad_input(dhp, P[p + "intermediate.dense.weight"], resid=dxp)                        # + residual path
         dap, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
             _K.layernorm_bwd(Ly["a_pre"], da, P[p + "attention.output.LayerNorm.weight"], 1e-12)
         do = _K.dropout_add(dap, None, drop, seed + 11 + 4 * i)
@@ -340,7 +345,7 @@ def _encoder_backward(model, P, S, dx, G):
         for k, nm in enumerate(("query", "key", "value")):
             G[p + f"attention.self.{nm}.weight"] = dwqkv[k * Hd:(k + 1) * Hd]
             G[p + f"attention.self.{nm}.bias"] = dbqkv[k * Hd:(k + 1) * Hd]
-        dx = _K.dropout_add(_K.grad_input(dqkv, Ly["wqkv"]), dap, 0.0, 0)                               # + residual path
+        dx = _K.grad_input(dqkv, Ly["wqkv"], resid=dap)                                                # + residual path
     # ---- embeddings
     dxe = _K.dropout_add(dx, None, drop, seed + 1)
     dx0, G[_V + "embeddings.LayerNorm.weight"], G[_V + "embeddings.LayerNorm.bias"] = \
@@ -613,7 +618,7 @@ class CaptionLoss(torch.autograd.Function):
             dhp = _K.act_bwd(Ly["hpre"], _K.grad_input(dy, P[p + "output.dense.weight"]), 1)
             G[p + "intermediate.dense.weight"] = _K.grad_weight(dhp, Ly["d"])
             G[p + "intermediate.dense.bias"] = _K.colsum(dhp)
-            dd = _K.dropout_add(_K.grad_input(dhp, P[p + "intermediate.dense.weight"]), dxp, 0.0, 0)
+            dd = _K.grad_input(dhp, P[p + "intermediate.dense.weight"], resid=dxp)
             # cross-attention block
             ddp, G[ea + "output.LayerNorm.weight"], G[ea + "output.LayerNorm.bias"] = _K.layernorm_bwd(Ly["d_pre"], dd, P[ea + "output.LayerNorm.weight"], 1e-12)
             do2 = _K.dropout_add(ddp, None, drop, seed + 113 + 8 * i)
@@ -633,9 +638,8 @@ class CaptionLoss(torch.autograd.Function):
             dwkv, dbkv = _K.grad_weight(dkv, S["enc"]), _K.colsum(dkv)
             G[ea + "att.key.weight"], G[ea + "att.value.weight"] = dwkv[:Hd], dwkv[Hd:]
             G[ea + "att.key.bias"], G[ea + "att.value.bias"] = dbkv[:Hd], dbkv[Hd:]
-            de = _K.grad_input(dkv, Ly["wkv"])
-            denc = de if denc is None else _K.dropout_add(de, denc, 0.0, 0)
-            ds = _K.dropout_add(_K.grad_input(dq2, P[ea + "att.query.weight"]), ddp, 0.0, 0)
+            denc = _K.grad_input(dkv, Ly["wkv"], resid=denc)
+            ds = _K.grad_input(dq2, P[ea + "att.query.weight"], resid=ddp)
             # self-attention block
             dsp, G[sa + "output.LayerNorm.weight"], G[sa + "output.LayerNorm.bias"] = _K.layernorm_bwd(Ly["s_pre"], ds, P[sa + "output.LayerNorm.weight"], 1e-12)
             do1 = _K.dropout_add(dsp, None, drop, seed + 111 + 8 * i)
@@ -653,7 +657,7 @@ class CaptionLoss(torch.autograd.Function):
             for k, nm in enumerate(("query", "key", "value")):
                 G[sa + f"att.{nm}.weight"] = dwqkv[k * Hd:(k + 1) * Hd]
                 G[sa + f"att.{nm}.bias"] = dbqkv[k * Hd:(k + 1) * Hd]
-            dx = _K.dropout_add(_K.grad_input(dqkv, Ly["wqkv"]), dsp, 0.0, 0)
+            dx = _K.grad_input(dqkv, Ly["wqkv"], resid=dsp)
         # decoder embeddings: LayerNorm, position table, and the input-embedding share of the tied matrix
         dxe = _K.dropout_add(dx, None, drop, seed + 101)
         de0, G[_D + "embeddings.LayerNorm.weight"], G[_D + "embeddings.LayerNorm.bias"] = \
@@ -686,6 +690,22 @@ def _dropout_seed() -> int:
     if dist.is_available() and dist.is_initialized():
         s = (s + 0x9E3779B1 * (dist.get_rank() + 1)) % (2 ** 31 - 1024)
     return s
+
+
+def _parameters_by_name(model, names: List[str]):
+    """The Parameters behind `names`, through (submodule, attribute) pairs resolved once per model: dict(model.named_parameters())
+    walks the whole module tree (0.65 ms of host time per step, more with the CLIP towers attached).  Read through getattr every
+    step, so a Parameter object swapped after the first step is still found; after replacing a whole SUBMODULE of a model that
+    has already trained, drop the table (``model.__dict__.pop("_train_param_sites", None)``)."""
+    cache = model.__dict__.setdefault("_train_param_sites", {})
+    out = []
+    for n in names:
+        site = cache.get(n)
+        if site is None:
+            prefix, _, leaf = n.rpartition(".")
+            site = cache[n] = (model.get_submodule(prefix) if prefix else model, leaf)
+        out.append(getattr(site[0], site[1]))
+    return out
 
 
 def _train(model, batch, task) -> Dict[str, torch.Tensor]:
@@ -722,8 +742,7 @@ def _train(model, batch, task) -> Dict[str, torch.Tensor]:
         inp["output_ids"] = torch.tensor([list(t[7]) for t in tt], dtype=torch.long)
         fn = CaptionLoss
     names = task_param_names(model, task)
-    named = dict(model.named_parameters())
-    return {"loss": fn.apply(model, inp, names, *[named[n] for n in names])}
+    return {"loss": fn.apply(model, inp, names, *_parameters_by_name(model, names))}
 
 
 def train_moment_retrieval(model, batch) -> Dict[str, torch.Tensor]:

@@ -1,3 +1,5 @@
+"""Host side of the joint-model training step: enqueue time per phase with the GPU idle at the start (is the step host- or GPU-bound?),
+wall time per step, and cProfile tables of the main thread and of MomentLoss.backward (which runs on autograd's thread)."""
 import json, os, sys, time, torch
 ROOT='/root/repo'; sys.path.insert(0, ROOT)
 import hirest_amd
@@ -42,4 +44,19 @@ torch.cuda.synchronize(); print("wall per step %.2f ms" % ((time.perf_counter() 
 pr = cProfile.Profile(); pr.enable()
 for _ in range(n): step()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+print("---- main thread (forward, clip, optimizer; the backward runs on autograd's thread)")
+pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
+from hirest_amd import train
+inner = train.MomentLoss.backward
+prb = cProfile.Profile()
+def profiled(ctx, gloss):
+    prb.enable()
+    try:
+        return inner(ctx, gloss)
+    finally:
+        prb.disable()
+train.MomentLoss.backward = staticmethod(profiled)
+for _ in range(n): step()
+torch.cuda.synchronize()
+print("---- MomentLoss.backward")
+pstats.Stats(prb).sort_stats("tottime").print_stats(22)
