@@ -66,8 +66,9 @@ __device__ __forceinline__ f32x4 epilogue_apply4(const GemmF& p, f32x4 v, const 
 // the bits are those of the GEMM on transposed copies, without the copies (the training step made 37 of them per iteration).
 template <bool AK, bool WK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
-    __shared__ float As[64 * FLD];
-    __shared__ float Ws[64 * FLD];
+    constexpr int TLD = 36;                                  // tile row stride in floats: rows 16-B aligned, 8 consecutive rows on distinct banks
+    __shared__ __attribute__((aligned(16))) float As[64 * TLD];
+    __shared__ __attribute__((aligned(16))) float Ws[64 * TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int M0 = blockIdx.y * 64, N0 = blockIdx.x * 64;
@@ -88,11 +89,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     // ascending order; inside a slab MFMA step j pairs k0 + j (lanes < 32) with k0 + 16 + j (lanes >= 32)), and the result is
     // ((p0 + p1) + p2) + p3.  Here the quarters are walked one after the other, so memory is read front to back and only one
     // accumulator block is live (four live ones cost 13 % on moment retrieval / segmentation: occupancy).
-    // LDS slab image: k is stored at position 2 (k & 15) + (k >> 4), so the step that pairs k0 + j with k0 + 16 + j reads positions
-    // 2 j (lanes < 32) and 2 j + 1 (lanes >= 32): with the 33-float row stride both halves hit distinct banks.
-    const int arow = (wm * 32 + (lane & 31)) * FLD + (lane >> 5);
-    const int wrow = (wn * 32 + (lane & 31)) * FLD + (lane >> 5);
-    const int spos = 2 * (sk & 15) + (sk >> 4);          // position of this thread's first k; its 8 k's are 2 apart
+    // LDS slab image: row r holds its 32 k's in natural order as eight 16-B chunks, chunk c at position c ^ ((r >> 4) & 3).  The step
+    // that pairs k0 + j with k0 + 16 + j reads float j of chunks 0..3 (lanes < 32) / 4..7 (lanes >= 32): four ds_read_b128 per operand
+    // and slab instead of sixteen ds_read_b32 (the scalar image at a 33-float stride spent 25 % of its LDS cycles on bank conflicts),
+    // a row-major operand is stored with two ds_write_b128 per thread, and the XOR keeps the k-major operand's scalar stores (16 lanes
+    // = 16 row quadruples at one k) on distinct banks.
+    const int frow_a = wm * 32 + (lane & 31), frow_w = wn * 32 + (lane & 31);
+    const int fsw_a = (frow_a >> 4) & 3, fsw_w = (frow_w >> 4) & 3, fhalf = 4 * (lane >> 5);
+    const int ssw = (srow >> 4) & 3;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int k0, f32x4 (&av)[2], f32x4 (&wv)[2]) {
 #pragma unroll
@@ -126,17 +130,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
         for (int sl = u * quarter; sl < s_end; ++sl) {
             __syncthreads();
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+                if (!AK) *reinterpret_cast<f32x4*>(&As[srow * TLD + 4 * (((sk >> 2) + h) ^ ssw)]) = av[h];
+                if (!WK) *reinterpret_cast<f32x4*>(&Ws[srow * TLD + 4 * (((sk >> 2) + h) ^ ssw)]) = wv[h];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {                 // (k = tk + 16 h sits at position 2 tk + h)
-                    if (AK) As[(tc + e) * FLD + 2 * tk + h] = av[h][e]; else As[srow * FLD + spos + 2 * (4 * h + e)] = av[h][e];
-                    if (WK) Ws[(tc + e) * FLD + 2 * tk + h] = wv[h][e]; else Ws[srow * FLD + spos + 2 * (4 * h + e)] = wv[h][e];
+                for (int e = 0; e < 4; ++e) {                 // k-major: k = tk + 16 h of rows tc .. tc + 3
+                    const int kk = tk + 16 * h, r = tc + e;
+                    if (AK) As[r * TLD + 4 * ((kk >> 2) ^ ((r >> 4) & 3)) + (kk & 3)] = av[h][e];
+                    if (WK) Ws[r * TLD + 4 * ((kk >> 2) ^ ((r >> 4) & 3)) + (kk & 3)] = wv[h][e];
                 }
+            }
             __syncthreads();
             if (sl + 1 < s_last) fetch((sl + 1) * FK, av, wv);
+            f32x4 aq[4], wq[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                aq[c] = *reinterpret_cast<const f32x4*>(&As[frow_a * TLD + 4 * ((fhalf + c) ^ fsw_a)]);
+                wq[c] = *reinterpret_cast<const f32x4*>(&Ws[frow_w * TLD + 4 * ((fhalf + c) ^ fsw_w)]);
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                part = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[wrow + 2 * j], As[arow + 2 * j], part, 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j >> 2][j & 3], aq[j >> 2][j & 3], part, 0, 0, 0);
         }
         if (u == ub) acc = part;
         else {

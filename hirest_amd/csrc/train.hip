@@ -40,9 +40,25 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 // out[c] = sum_r w(r) x[r][c],  w(r) = (wt ? wt[r] : 1) * (sel ? sel[r] == sel_value : 1).  One block per 32 columns (a row
 // segment = one 128-B line), 32 row lanes of 32 threads, four independent partial sums per thread so that four rows are in
 // flight per lane, then a fixed-order LDS reduction over the row lanes (deterministic: no atomics).
+constexpr int COLSUM_THIN_ROWS = 32;
+inline int colsum_blocks(int R, int C) { return R <= COLSUM_THIN_ROWS ? (C + 1023) / 1024 : (C + 31) / 32; }
 __device__ __forceinline__ void weighted_colsum_block(const float* __restrict__ x, int64_t ldx, const float* __restrict__ wt,
                                                       const int32_t* __restrict__ sel, int sel_value, int R, int C,
                                                       float* __restrict__ out, int block) {
+    if (R <= COLSUM_THIN_ROWS) {
+        // few rows (the position table's gradient: 5 rows x T * 768 columns): a thread per column, 1024 columns per block.  The wide
+        // form below gives row r to lane row r alone and then adds the 32 lane-row sums in order, i.e. the plain sum over r: same bits.
+        const int c = block * 1024 + threadIdx.x;
+        if (c >= C) return;
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) {
+            float w = wt ? wt[r] : 1.f;
+            if (sel && sel[r] != sel_value) w = 0.f;
+            t += fmaf(w, x[(int64_t)r * ldx + c], 0.f);
+        }
+        out[c] = t;
+        return;
+    }
     __shared__ float red[32][33];
     const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = block * 32 + col;
@@ -83,8 +99,9 @@ __global__ __launch_bounds__(1024) void weighted_colsum_kernel(const float* __re
 // scalar loads) and then runs exactly the single-matrix block above — the same bits.
 struct ColsumGroup { hirest_colsum_item item[HIREST_COLSUM_GROUP_MAX]; int first[HIREST_COLSUM_GROUP_MAX]; int count; };
 __global__ __launch_bounds__(1024) void weighted_colsum_grouped_kernel(ColsumGroup g) {
-    int i = 0;
-    while (i + 1 < g.count && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    int i = 0;                                               // first[] ascends: the item is the number of later items starting at or before
+#pragma unroll                                               // this block (independent scalar loads; a dependent scan cost 3 us per block)
+    for (int j = 1; j < HIREST_COLSUM_GROUP_MAX; ++j) i += (j < g.count && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
     const hirest_colsum_item& it = g.item[i];
     weighted_colsum_block(it.x, it.ldx, it.row_weight, it.row_select, it.select_value, it.R, it.C, it.out, blockIdx.x - g.first[i]);
 }
@@ -600,7 +617,7 @@ extern "C" int hirest_transpose_pad_f32(const float* in, int64_t ld_in, int32_t 
 extern "C" int hirest_weighted_colsum_f32(const float* x, int64_t ldx, const float* row_weight, const int32_t* row_select,
                                           int32_t select_value, int32_t R, int32_t C, float* out, void* stream) {
     if (!x || !out || R <= 0 || C <= 0) return HIREST_E_BADARG;
-    hipLaunchKernelGGL(weighted_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, S_(stream), x, ldx, row_weight, row_select,
+    hipLaunchKernelGGL(weighted_colsum_kernel, dim3(colsum_blocks(R, C)), dim3(1024), 0, S_(stream), x, ldx, row_weight, row_select,
                        select_value, R, C, out);
     return hirest_launch_status();
 }
@@ -613,7 +630,7 @@ extern "C" int hirest_weighted_colsum_grouped_f32(const hirest_colsum_item* item
         ColsumGroup g;
         g.count = count - base < HIREST_COLSUM_GROUP_MAX ? count - base : HIREST_COLSUM_GROUP_MAX;
         int blocks = 0;
-        for (int i = 0; i < g.count; ++i) { g.item[i] = items[base + i]; g.first[i] = blocks; blocks += (items[base + i].C + 31) / 32; }
+        for (int i = 0; i < g.count; ++i) { g.item[i] = items[base + i]; g.first[i] = blocks; blocks += colsum_blocks(items[base + i].R, items[base + i].C); }
         hipLaunchKernelGGL(weighted_colsum_grouped_kernel, dim3(blocks), dim3(1024), 0, S_(stream), g);
     }
     return hirest_launch_status();
