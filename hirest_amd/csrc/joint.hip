@@ -65,10 +65,10 @@ __device__ __forceinline__ f32x4 epilogue_apply4(const GemmF& p, f32x4 v, const 
 // (4 consecutive rows of one k per thread) and transposed on its way into the same LDS image, so the products, their order and
 // the bits are those of the GEMM on transposed copies, without the copies (the training step made 37 of them per iteration).
 template <bool AK, bool WK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmF p) {
     constexpr int TLD = 36;                                  // tile row stride in floats: rows 16-B aligned, 8 consecutive rows on distinct banks
-    __shared__ __attribute__((aligned(16))) float As[64 * TLD];
-    __shared__ __attribute__((aligned(16))) float Ws[64 * TLD];
+    __shared__ __attribute__((aligned(16))) float As[2][64 * TLD];   // two slabs: the next one is stored while this one is multiplied
+    __shared__ __attribute__((aligned(16))) float Ws[2][64 * TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int M0 = blockIdx.y * 64, N0 = blockIdx.x * 64;
@@ -98,15 +98,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     const int fsw_a = (frow_a >> 4) & 3, fsw_w = (frow_w >> 4) & 3, fhalf = 4 * (lane >> 5);
     const int ssw = (srow >> 4) & 3;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // The loads are written as asm so that the WAITS are ours: the compiler's own counter tracking turns the two-slabs-ahead prefetch
+    // into vmcnt(0) at the loop header (it cannot prove which set is older across the back edge).  A set is touched again only through
+    // landed<N>(), whose "+v" operands tie it to the s_waitcnt; every load is unconditional, on a clamped k (what lies past K becomes
+    // zero when the slab is stored to the LDS; K % 4 == 0 for a row-major operand: a 4-vector is inside or outside as a whole).
+    auto gload = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory"); return v; };
     auto fetch = [&](int k0, f32x4 (&av)[2], f32x4 (&wv)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const bool in = k0 + sk + 4 * h < p.K;            // K % 4 == 0: a 4-vector is inside or outside as a whole
-            const bool ink = k0 + tk + 16 * h < p.K;          // k-major: one k per thread
-            if (AK) av[h] = ink ? *reinterpret_cast<const f32x4*>(ap + (int64_t)(k0 + tk + 16 * h) * p.lda) : zero;
-            else av[h] = in ? *reinterpret_cast<const f32x4*>(ap + k0 + 4 * h) : zero;
-            if (WK) wv[h] = ink ? *reinterpret_cast<const f32x4*>(wp + (int64_t)(k0 + tk + 16 * h) * p.ldw) : zero;
-            else wv[h] = in ? *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h) : zero;
+            const int kr = k0 + sk + 4 * h < p.K ? k0 + 4 * h : p.K - 4 - sk;          // (ap / wp already point at column sk)
+            const int kc = k0 + tk + 16 * h < p.K ? k0 + tk + 16 * h : p.K - 1;        // k-major: one k per thread
+            av[h] = gload(AK ? ap + (int64_t)kc * p.lda : ap + kr);
+            wv[h] = gload(WK ? wp + (int64_t)kc * p.ldw : wp + kr);
         }
     };
     const int nslab = (p.K + FK - 1) / FK;
@@ -118,46 +121,96 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
     // split form (few tiles for the CUs: a 768-wide layer over 1500 rows is 288): one block per (tile, quarter), the partial sums
     // meet in gemm_f32_quarters_kernel in the same order ((p0 + p1) + p2) + p3 — same bits
     const int ub = p.ws ? (int)blockIdx.z : 0, ue = p.ws ? ub + 1 : 4;
+    const int s_first = ub * quarter;
     const int s_last = p.ws ? ((ub + 1) * quarter < nslab ? (ub + 1) * quarter : nslab) : nslab;   // no slab of another block's quarter is fetched
-    if (ub * quarter < nslab) fetch(ub * quarter * FK, av, wv);
-#pragma unroll 1
-    for (int u = ub; u < ue; ++u) {                           // partial sum u: slabs u * quarter .. (u + 1) * quarter - 1
-        f32x16 part;
+    // Software pipeline of a wave, one s_barrier per slab:
+    //   global -> registers: slab s + 2 is requested at the top of step s, right after slab s + 1 has left the registers for the LDS,
+    //   and has the whole step to arrive; registers -> LDS one slab ahead (buffers 0 / 1 alternate); LDS -> fragment registers half a
+    //   slab ahead: the chunks of slab s + 1 replace those of slab s as soon as its MFMAs have issued, so the ds_read latency lies
+    //   under the second half of the MFMAs instead of in front of every group of four.  (Two register sets, i.e. two slabs in flight,
+    //   do not fit 128 registers without spills, and a spill reload's vmcnt(0) drains the prefetch.)
+    // Before (LDS single-buffered, two __syncthreads — whose fence also waits for the prefetch — per slab, fragments read in front of
+    // every four MFMAs) the memory skeleton alone took 50 us and the MFMAs alone 68 us of an 85-us launch (M 1500, N 3072, K 768):
+    // they ran one after the other.
+    // Hazards: buffer b is stored for slab s + 1 at the top of step s; its previous content (slab s - 1) was read as fragments during
+    // step s - 2 and those reads were waited for (lgkmcnt(0)) before the barrier of step s - 1, which every wave has passed.  The
+    // barrier of step s publishes the stores (each wave's lgkmcnt(0) precedes it) to the fragment reads that follow it.
+    auto lds_done = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto landed = [](f32x4 (&ar)[2], f32x4 (&wr)[2]) {       // (the "+v" operands tie the registers to the wait)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ar[0]), "+v"(ar[1]), "+v"(wr[0]), "+v"(wr[1]) : : "memory");
+    };
+    auto store = [&](int slab_index, int buf, f32x4 (&ar)[2], f32x4 (&wr)[2]) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) part[e] = 0.f;
-        const int s_end = (u + 1) * quarter < nslab ? (u + 1) * quarter : nslab;
-#pragma unroll 1
-        for (int sl = u * quarter; sl < s_end; ++sl) {
-            __syncthreads();
+        for (int h = 0; h < 2; ++h) {
+            const bool in = slab_index * FK + sk + 4 * h < p.K, ink = slab_index * FK + tk + 16 * h < p.K;
+            if (!(AK ? ink : in)) ar[h] = zero;
+            if (!(WK ? ink : in)) wr[h] = zero;
+            if (!AK) *reinterpret_cast<f32x4*>(&As[buf][srow * TLD + 4 * (((sk >> 2) + h) ^ ssw)]) = ar[h];
+            if (!WK) *reinterpret_cast<f32x4*>(&Ws[buf][srow * TLD + 4 * (((sk >> 2) + h) ^ ssw)]) = wr[h];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (!AK) *reinterpret_cast<f32x4*>(&As[srow * TLD + 4 * (((sk >> 2) + h) ^ ssw)]) = av[h];
-                if (!WK) *reinterpret_cast<f32x4*>(&Ws[srow * TLD + 4 * (((sk >> 2) + h) ^ ssw)]) = wv[h];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {                 // k-major: k = tk + 16 h of rows tc .. tc + 3
-                    const int kk = tk + 16 * h, r = tc + e;
-                    if (AK) As[r * TLD + 4 * ((kk >> 2) ^ ((r >> 4) & 3)) + (kk & 3)] = av[h][e];
-                    if (WK) Ws[r * TLD + 4 * ((kk >> 2) ^ ((r >> 4) & 3)) + (kk & 3)] = wv[h][e];
-                }
+            for (int e = 0; e < 4; ++e) {                     // k-major: k = tk + 16 h of rows tc .. tc + 3
+                const int kk = tk + 16 * h, r = tc + e;
+                if (AK) As[buf][r * TLD + 4 * ((kk >> 2) ^ ((r >> 4) & 3)) + (kk & 3)] = ar[h][e];
+                if (WK) Ws[buf][r * TLD + 4 * ((kk >> 2) ^ ((r >> 4) & 3)) + (kk & 3)] = wr[h][e];
             }
-            __syncthreads();
-            if (sl + 1 < s_last) fetch((sl + 1) * FK, av, wv);
-            f32x4 aq[4], wq[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                aq[c] = *reinterpret_cast<const f32x4*>(&As[frow_a * TLD + 4 * ((fhalf + c) ^ fsw_a)]);
-                wq[c] = *reinterpret_cast<const f32x4*>(&Ws[frow_w * TLD + 4 * ((fhalf + c) ^ fsw_w)]);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                part = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j >> 2][j & 3], aq[j >> 2][j & 3], part, 0, 0, 0);
         }
+    };
+    f32x4 aq[4], wq[4];
+    auto frag = [&](int buf, int c) {
+        aq[c] = *reinterpret_cast<const f32x4*>(&As[buf][frow_a * TLD + 4 * ((fhalf + c) ^ fsw_a)]);
+        wq[c] = *reinterpret_cast<const f32x4*>(&Ws[buf][frow_w * TLD + 4 * ((fhalf + c) ^ fsw_w)]);
+    };
+    f32x16 part;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[e] = 0.f;
+    int u = ub, sl = s_first;
+    auto close_quarter = [&]() {                             // partial sum u is complete: acc = ((p0 + p1) + p2) + p3 as they come
         if (u == ub) acc = part;
         else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] += part[e];
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[e] = 0.f;
+        ++u;
+    };
+    // (the prefetch is issued unconditionally — past the block's last slab it re-reads that slab — so that the registers always belong
+    //  to exactly one outstanding request)
+    auto fetch_slab = [&](int s_) { fetch((s_ < s_last ? s_ : s_last - 1) * FK, av, wv); };
+    if (s_first < s_last) {
+        fetch_slab(s_first);
+        landed(av, wv);
+        store(s_first, 0, av, wv);
+        fetch_slab(s_first + 1);
+        lds_done();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) frag(0, c);
     }
+    auto step = [&](int cur) {                               // buffer `cur` holds slab sl, the registers slab sl + 1 (in flight)
+        const bool more = sl + 1 < s_last;
+        landed(av, wv);
+        if (more) store(sl + 1, cur ^ 1, av, wv);
+        fetch_slab(sl + 2);
+        lds_done();                                          // this slab's fragments (read during the previous step) and the stores above
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j >> 2][j & 3], aq[j >> 2][j & 3], part, 0, 0, 0);
+        __builtin_amdgcn_s_barrier();
+        if (more) { frag(cur ^ 1, 0); frag(cur ^ 1, 1); }
+#pragma unroll
+        for (int j = 8; j < 16; ++j) part = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j >> 2][j & 3], aq[j >> 2][j & 3], part, 0, 0, 0);
+        if (more) { frag(cur ^ 1, 2); frag(cur ^ 1, 3); }
+        ++sl;
+        if (sl == (u + 1) * quarter || sl == nslab) close_quarter();
+    };
+#pragma unroll 1
+    while (sl + 1 < s_last) {                                // slabs in pairs: the buffer numbers are literals
+        step(0);
+        step(1);
+    }
+    if (sl < s_last) step(0);
+    if (s_first < s_last) landed(av, wv);                    // the surplus prefetch owns the registers until it lands
+    while (u < ue) close_quarter();                          // quarters without a slab (K < 4 slabs) still take their place in the sum: + 0
     if (p.ws) {                                              // split form: the raw partial sum of quarter ub
         const int m = M0 + wm * 32 + (lane & 31);
         if (m >= p.M) return;
