@@ -66,6 +66,13 @@ __device__ __forceinline__ f32x4 epilogue_apply4(const GemmF& p, f32x4 v, const 
 // the bits are those of the GEMM on transposed copies, without the copies (the training step made 37 of them per iteration).
 template <bool AK, bool WK>
 __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmF p) {
+    // The four blocks that share a CU start together and would run their memory and MFMA phases in step (the matrix pipe idles while
+    // all of them store / synchronise / read): groups of 32 consecutive blocks start 0 / 512 / 1024 / 1536 cycles late.  Grids that
+    // divide evenly over the CUs gain 10-17 % (1024 x 4096 x 768: 75 -> 62 us, 4096 x 3072 x 768: 189 -> 171), M = 1500 nothing.
+    {
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        for (int i = (bid >> 5) & 3; i > 0; --i) __builtin_amdgcn_s_sleep(8);
+    }
     constexpr int TLD = 36;                                  // tile row stride in floats: rows 16-B aligned, 8 consecutive rows on distinct banks
     __shared__ __attribute__((aligned(16))) float As[2][64 * TLD];   // two slabs: the next one is stored while this one is multiplied
     __shared__ __attribute__((aligned(16))) float Ws[2][64 * TLD];

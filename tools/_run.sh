@@ -1,19 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_joint.py tests/test_gpu_train.py -m gpu -q -x 2>&1 | tail -3
-python - <<'PY'
-import sys, torch
-sys.path.insert(0, '/root/repo')
-from hirest_amd import _lib, ops
-lib = _lib.load(); dev = torch.device("cuda:0")
-def run(M, N, K, reps=50):
-    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); out = torch.empty(M, N, device=dev)
-    f = lambda: lib.hirest_gemm_f32(a.data_ptr(), K, w.data_ptr(), K, None, None, 0, None, 0, out.data_ptr(), N, M, N, K, 0, ops.stream_ptr())
-    for _ in range(5): f()
-    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): f()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
-for (M, N, K) in ((1500, 3072, 768), (1500, 2304, 768), (1500, 768, 768), (1500, 768, 3072), (4096, 3072, 768), (10240, 3072, 768)):
-    t = run(M, N, K); print(M, N, K, f"{t:.1f} us  {2.0*M*N*K/t/1e6:.1f} TF  (ideal at 150 TF: {2.0*M*N*K/150e12*1e6:.1f} us)")
-PY
-bash tools/train_round.sh 2>&1 | grep -E "T= 300|T= 571|colsum|# step|gemm_f32_kernel"
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+python tools/secondary_bench.py > gpurun_out/secondary_now.json 2> gpurun_out/secondary_now.err; tail -c 600 gpurun_out/secondary_now.err
