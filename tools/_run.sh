@@ -1,2 +1,6 @@
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-python tools/secondary_bench.py > gpurun_out/secondary_now.json 2> gpurun_out/secondary_now.err; tail -c 600 gpurun_out/secondary_now.err
+export TMPDIR=/tmp
+for task in moment_retrieval moment_segmentation; do
+  python tools/joint_profile.py $task
+  ( cd /tmp && rm -rf /tmp/prof && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o x -- python $GRAFT_REPO_ROOT/tools/joint_profile.py $task > /dev/null 2>&1 )
+  python tools/busy_span.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) 0.5
+done
