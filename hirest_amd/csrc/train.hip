@@ -529,9 +529,9 @@ __global__ __launch_bounds__(256) void joint_base_bwd_kernel(const float* __rest
     if (e >= E) return;
     const float t = tn[(int64_t)b * E + e];
     float acc = 0.f;
-    // the sum over t stays one fma chain in t order (same bits), but its loads go out sixteen rows at a time: one row per
-    // iteration was 300 dependent memory round trips in ten blocks (119 us, 3 % of the training step)
-    constexpr int U = 16;
+    // the sum over t stays one fma chain in t order (same bits), but its loads go out 48 rows at a time: one row per
+    // iteration was 300 dependent memory round trips in ten blocks (119 us, 3 % of the training step; 16 rows: 44 us)
+    constexpr int U = 48;
     for (int t0 = 0; t0 < T; t0 += U) {
         float d[U], x[U];
 #pragma unroll

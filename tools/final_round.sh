@@ -21,6 +21,10 @@ CAPTION_REPS=1 bash tools/pmc_sq.sh $out/pmccap "m16|attention_f32_decode|tail_"
 for pr in fma_order_probe wave_sum_probe lane_path_probe; do hipcc --offload-arch=gfx950 -O2 -w -o /tmp/$pr tools/probes/$pr.hip && timeout 60 /tmp/$pr > $out/$pr.txt 2>&1; done
 timeout 120 python tools/lm_head_probe.py > $out/lm_head_probe.txt 2>&1
 # training step: timings (reference optimizer call and fused=True), kernel stats of the retrieval step
-bash tools/train_round.sh > $out/train_round.log 2>&1; cp gpurun_out/train/train_bench.txt $out/train_bench.txt
+bash tools/train_round.sh > $out/train_round.log 2>&1; cp gpurun_out/train/train_bench.txt $out/train_bench.txt; cp gpurun_out/train/step_timeline.txt $out/train_step_timeline.txt
+timeout 300 python tools/train_host_probe.py 2>&1 | grep -v amdgpu.ids | head -60 > $out/train_host_probe.txt
+timeout 300 python tools/gemm_f32_sweep.py 2>&1 | grep -v amdgpu.ids > $out/gemm_f32_sweep.txt
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_f32_peak_probe tools/probes/mfma_f32_peak_probe.hip && timeout 120 /tmp/mfma_f32_peak_probe > $out/mfma_f32_peak_probe.txt 2>&1
+for b in 5 3; do timeout 300 python tools/caption_batch_breakdown.py $b 2>&1 | tail -1; done > $out/caption_batch_breakdown.txt
 bash tools/train_prof.sh > $out/train_prof.log 2>&1; cp gpurun_out/train/train_kernel_stats.csv $out/rocprofv3_kernel_stats_train_step.csv
 date +%s > $out/collected_at
