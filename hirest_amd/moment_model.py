@@ -458,12 +458,30 @@ class MomentModel(nn.Module):
             idx += [sel[j]] * (((j + 1) * max_frames) // N - (j * max_frames) // N)
         return idx + [-1] * (max_frames - len(idx))
 
-    def _trim(self, feats: torch.Tensor, moment_mask: torch.Tensor, max_frames: int) -> torch.Tensor:
-        B = feats.shape[0]
-        rows = [self._trim_index(moment_mask[b].tolist(), max_frames) for b in range(B)]
-        idx = torch.tensor(rows, dtype=torch.long, device=feats.device)
-        out = torch.gather(feats, 1, idx.clamp(min=0).unsqueeze(-1).expand(-1, -1, feats.shape[-1]))   # pure data movement
-        return (out * (idx >= 0).unsqueeze(-1)).contiguous()
+    def _trim_rows(self, moment_mask: torch.Tensor, max_frames: int, device):
+        """The row-index table of trim_feats for a batch, on `device`: flat row numbers b * T + t into the [B * T, D] feature matrix,
+        [B * max_frames] long, and — only when some sample selects fewer than max_frames rows — a [B * max_frames, 1] 0 / 1 column
+        that zeroes the missing ones (else None).  Host index arithmetic on the mask as the collate function delivers it (a CPU
+        tensor: no device round trip; a device tensor costs one copy back, not one per sample), uploaded once and shared by the
+        visual and the ASR features."""
+        mask = moment_mask.cpu()
+        T = mask.shape[1]
+        rows = [self._trim_index(r, max_frames) for r in mask.tolist()]
+        flat = [b * T + max(i, 0) for b, r in enumerate(rows) for i in r]
+        keep = None
+        if any(i < 0 for r in rows for i in r):
+            keep = torch.tensor([[1.0 if i >= 0 else 0.0] for r in rows for i in r], dtype=torch.float32).to(device)
+        return torch.tensor(flat, dtype=torch.long).to(device), keep
+
+    def _trim(self, feats: torch.Tensor, moment_mask, max_frames: int, idx=None) -> torch.Tensor:
+        if idx is None:
+            idx = self._trim_rows(moment_mask, max_frames, feats.device)
+        flat, keep = idx
+        B, T, D = feats.shape
+        out = feats.reshape(B * T, D).index_select(0, flat)                    # pure data movement
+        if keep is not None:
+            out = out * keep
+        return out.reshape(B, max_frames, D)
 
     def _decoder_last_logprob(self, ids: torch.Tensor, enc_kv: List[torch.Tensor], row_add: torch.Tensor) -> torch.Tensor:
         """DecoderModel.forward on the whole prefix (no KV cache, like the reference), then log_softmax of the LAST
@@ -527,24 +545,36 @@ class MomentModel(nn.Module):
         cache = [torch.empty((2 * nl, R, max_words, Dm), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
         ptrs = [(C.c_void_p * (2 * nl))(*[cb[i].data_ptr() for i in range(2 * nl)]) for cb in cache]
         logp = torch.empty((R, Vp), dtype=torch.float32, device=dev)
-        # device-side beam state (beam.py: scores, next_ys, prev_ks) and the inputs of the next step
-        ids = torch.full((R,), BOS_ID, dtype=torch.int32, device=dev)
-        parents = torch.arange(R, dtype=torch.int32, device=dev)
-        add = torch.full((B, num_beams), -3.0e38, dtype=torch.float32, device=dev)            # first step: only beam 0 competes
-        add[:, 0] = 0.0                                                                       # (beam.py:78)
-        scores = torch.zeros((R,), dtype=torch.float32, device=dev)
-        tokens = torch.zeros((B, max_words, num_beams), dtype=torch.int32, device=dev)
-        backptr = torch.zeros((B, max_words, num_beams), dtype=torch.int32, device=dev)
-        n_steps = torch.zeros((B,), dtype=torch.int32, device=dev)
-        done = torch.zeros((B,), dtype=torch.int32, device=dev)
-        done_host = [torch.zeros((B,), dtype=torch.int32).pin_memory() for _ in range(max_words)]
-        copied = [torch.cuda.Event() for _ in range(max_words)]
+        # device-side beam state (beam.py: scores, next_ys, prev_ks) and the inputs of the next step, in two packed buffers (one fill,
+        # two small copies and one read-back per batch instead of a dozen): int32 = tokens | backptr | n_steps | done | ids | parents
+        nt = B * max_words * num_beams
+        ibuf = torch.zeros((2 * nt + 2 * B + 2 * R,), dtype=torch.int32, device=dev)
+        tokens, backptr = ibuf[:nt].view(B, max_words, num_beams), ibuf[nt:2 * nt].view(B, max_words, num_beams)
+        n_steps, done = ibuf[2 * nt:2 * nt + B], ibuf[2 * nt + B:2 * nt + 2 * B]
+        ids, parents = ibuf[2 * nt + 2 * B:2 * nt + 2 * B + R], ibuf[2 * nt + 2 * B + R:]
+        key = (B, num_beams, max_words, str(dev))
+        init = self.__dict__.setdefault("_beam_init", {}).get(key)
+        if init is None:                                  # constants of the search, built once per shape
+            add0 = torch.full((B, num_beams), -3.0e38, dtype=torch.float32)    # first step: only beam 0 competes
+            add0[:, 0] = 0.0                                                   # (beam.py:78)
+            init = self._beam_init[key] = (
+                torch.cat([torch.full((R,), BOS_ID, dtype=torch.int32), torch.arange(R, dtype=torch.int32)]).to(dev),
+                torch.cat([add0.reshape(-1), torch.zeros(R)]).to(dev),
+                torch.zeros((max_words, B), dtype=torch.int32).pin_memory())
+        ibuf[2 * nt + 2 * B:].copy_(init[0])
+        fbuf = init[1].clone()                             # float32 = add | scores
+        add, scores = fbuf[:R].view(B, num_beams), fbuf[R:]
+        # the stamped done flags of every step, pinned (the previous batch ended with a device synchronisation: nothing still writes here)
+        done_rows = init[2]
+        done_rows.zero_()
+        done_host = [done_rows[t] for t in range(max_words)]
+        fused_tail = bool(getattr(self, "caption_fused_tail", True)) and num_beams <= 16 and Vp <= 32768    # (the tail kernels' limits)
+        copied = None if fused_tail else [torch.cuda.Event() for _ in range(max_words)]
         need = lib.hirest_topk_workspace_bytes(B, num_beams * Vp, num_beams)
         tk_ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
         val = torch.empty((B, num_beams), dtype=torch.float32, device=dev)
         idx = torch.empty((B, num_beams), dtype=torch.int32, device=dev)
         st = ops.stream_ptr()
-        fused_tail = bool(getattr(self, "caption_fused_tail", True)) and num_beams <= 16 and Vp <= 32768    # (the tail kernels' limits)
         if fused_tail:
             tail_ws = torch.empty(max(int(lib.hirest_caption_beam_tail_workspace_bytes(B, num_beams, Vp)), 16), dtype=torch.uint8,
                                   device=dev)
@@ -579,7 +609,9 @@ class MomentModel(nn.Module):
                 copied[t - 3].synchronize()
                 if int(done_host[t - 3].min()) == 1:
                     break
-        tok_h, bp_h, n_h, sc_h = tokens.cpu().tolist(), backptr.cpu().tolist(), n_steps.cpu().tolist(), scores.view(B, -1).cpu().tolist()
+        ih = ibuf[:2 * nt + B].cpu()                       # tokens | backptr | n_steps in one copy (this is the batch's synchronisation)
+        tok_h, bp_h = ih[:nt].view(B, max_words, num_beams).tolist(), ih[nt:2 * nt].view(B, max_words, num_beams).tolist()
+        n_h, sc_h = ih[2 * nt:].tolist(), scores.view(B, -1).cpu().tolist()
         for b in range(B):                               # hand the recorded search to the host-side BeamState for the read-out
             beams[b].scores = sc_h[b]
             beams[b].backptr = [bp_h[b][j] for j in range(n_h[b])]
@@ -598,8 +630,9 @@ class MomentModel(nn.Module):
         vis = batch["vis_feats"].to(dev).float()
         mmask = batch["moment_mask"]
         B = vis.shape[0]
-        v = self._trim(vis, mmask.to(dev), max_frames)
-        a = self._trim(batch["asr_feats"].to(dev).float(), mmask.to(dev), max_frames) if self.use_asr else None
+        rows = self._trim_rows(mmask, max_frames, dev)
+        v = self._trim(vis, None, max_frames, idx=rows)
+        a = self._trim(batch["asr_feats"].to(dev).float(), None, max_frames, idx=rows) if self.use_asr else None
         text = self._text_feat(batch, dev)
         ones = torch.ones((B, max_frames), dtype=torch.long, device=dev)
         base = self._fusion_base(v, text, a, ones)

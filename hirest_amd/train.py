@@ -730,10 +730,10 @@ def _train(model, batch, task) -> Dict[str, torch.Tensor]:
         args = model.args
         max_frames = int(getattr(args, "max_frames_step_captioning", 20)) if args is not None else 20
         B = inp["vis"].shape[0]
-        mm = inp["moment_mask"]
-        inp["vis"] = model._trim(inp["vis"].float(), mm, max_frames)
+        rows = model._trim_rows(batch["moment_mask"], max_frames, dev)      # from the batch's own (CPU) mask: no device round trip
+        inp["vis"] = model._trim(inp["vis"].float(), None, max_frames, idx=rows)
         if model.use_asr:
-            inp["asr"] = model._trim(inp["asr"].float(), mm, max_frames)
+            inp["asr"] = model._trim(inp["asr"].float(), None, max_frames, idx=rows)
         ones = torch.ones((B, max_frames), dtype=torch.long, device=dev)
         inp["vis_mask"], inp["moment_mask"] = ones, ones
         tt = batch["target_text"]
