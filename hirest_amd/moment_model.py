@@ -318,8 +318,11 @@ class MomentModel(nn.Module):
         rows, D = feats.shape
         names = {"start": ("start_predictor.0.weight", 0), "end": ("end_predictor.0.weight", 1), "segment": ("segment_predictor.0.weight", 2)}
         ws = [c[names[w][0]] for w in which]
-        bias3 = torch.stack([c["head_bias"][names[w][1]] for w in which]).contiguous()
-        bias3 = torch.cat([bias3, torch.zeros(3 - len(which), device=bias3.device)]).contiguous()
+        bkey = "head_bias3." + ".".join(which)             # (lives in the weight cache: rebuilt with it when a parameter changes)
+        bias3 = c.get(bkey)
+        if bias3 is None:
+            bias3 = torch.stack([c["head_bias"][names[w][1]] for w in which]).contiguous()
+            bias3 = c[bkey] = torch.cat([bias3, torch.zeros(3 - len(which), device=bias3.device)]).contiguous()
         logits = torch.empty((len(which), rows), dtype=torch.float32, device=feats.device)
         _lib.check(lib.hirest_linear_heads(feats.data_ptr(), rows, D, len(which), ws[0].data_ptr(),
                                            ws[1].data_ptr() if len(ws) > 1 else None, ws[2].data_ptr() if len(ws) > 2 else None,
