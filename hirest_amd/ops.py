@@ -222,12 +222,13 @@ def topk(scores: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
 _F32_GEMM_WS = {}
 
 
-def f32_gemm_workspace(device, nbytes: int):
-    """Scratch for hirest_gemm_f32_ws (the split form of few-tile fp32 GEMMs), one buffer per device, grown on demand; every user is
-    on the current stream, in order, so sharing it is safe.  Returns (pointer, bytes) — (None, 0) when the problem wants none."""
+def f32_gemm_workspace(device, nbytes: int, tag: int = 0):
+    """Scratch for hirest_gemm_f32_ws (the split form of few-tile fp32 GEMMs), one buffer per device and `tag`, grown on demand; every
+    user of a tag is on one stream, in order, so sharing it is safe (tag 1: the training step's side stream).  Returns
+    (pointer, bytes) — (None, 0) when the problem wants none."""
     if nbytes <= 0:
         return None, 0
-    key = (device.type, device.index)
+    key = (device.type, device.index, tag)
     buf = _F32_GEMM_WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 32 << 20), dtype=torch.uint8, device=device)

@@ -41,6 +41,10 @@ def _chk(code, what):
     _lib.check(code, what)
 
 
+SIDE_STREAM_DW = True      # weight-gradient GEMMs of a backward on a second stream (_K.side_open)
+_SIDE = {}
+
+
 class _K:
     """Thin tensor-level wrappers over the training entry points (device fp32 contiguous in, fresh tensors out)."""
 
@@ -74,14 +78,39 @@ class _K:
         return out
 
     @staticmethod
-    def layouts(a, lda, a_kmajor, w, ldw, w_kmajor, M, N, K, resid=None):
+    def layouts(a, lda, a_kmajor, w, ldw, w_kmajor, M, N, K, resid=None, stream=None):
         lib = _lib.load()
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-        ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_layouts_workspace_bytes(M, N, K))
+        ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_layouts_workspace_bytes(M, N, K), 0 if stream is None else 1)
         _chk(lib.hirest_gemm_f32_layouts(a.data_ptr(), lda, int(a_kmajor), w.data_ptr(), ldw, int(w_kmajor), None,
                                          resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
-                                         out.data_ptr(), N, M, N, K, 0, ws, wsb, ops.stream_ptr()), "hirest_gemm_f32_layouts")
+                                         out.data_ptr(), N, M, N, K, 0, ws, wsb, ops.stream_ptr() if stream is None else stream),
+             "hirest_gemm_f32_layouts")
         return out
+
+    # Weight gradients on a second stream.  dW = dY^T X is needed only when the backward returns, while dX = dY W is on the critical
+    # path: inside a backward (side_open() .. side_join()) every dW GEMM is issued on a side stream behind an event that marks "dY is
+    # ready", so it fills the CUs the dX chain leaves idle — the tails of its GEMM launches, its row kernels of a few blocks, the
+    # latency-bound attention products.  The operands stay referenced until the join (the allocator must not hand their memory to the
+    # main stream while the side stream reads it); outputs are read after the join only.
+    _side = None
+
+    @staticmethod
+    def side_open(device):
+        if not SIDE_STREAM_DW:
+            return
+        st = _SIDE.get(device.index)
+        if st is None:
+            st = _SIDE[device.index] = {"stream": torch.cuda.Stream(device=device), "events": [], "keep": [], "used": 0}
+        st["used"] = 0
+        _K._side = st
+
+    @staticmethod
+    def side_join():
+        st, _K._side = _K._side, None
+        if st is not None and st["used"]:
+            torch.cuda.current_stream().wait_stream(st["stream"])
+            st["keep"].clear()
 
     @staticmethod
     def grad_input(dy, w, resid=None):
@@ -101,8 +130,8 @@ class _K:
         return dx if resid is None else _K.dropout_add(dx, resid, 0.0, 0)
 
     @staticmethod
-    def grad_weight(dy, x):
-        """dW = dY^T @ X:  dY [R, N], X [R, K] -> [N, K]: both operands read column-wise in place (A[m][k] = dY[k][m],
+    def grad_weight(dy, x, side=True):
+        """dW = dY^T @ X (side = False: on the main stream even inside a backward — for a result the backward itself goes on using):  dY [R, N], X [R, K] -> [N, K]: both operands read column-wise in place (A[m][k] = dY[k][m],
         B[n][k] = X[k][n]); STRIDED_GEMM = False: two zero-padded transposed copies."""
         if STRIDED_GEMM and 2.0 * dy.shape[1] * x.shape[1] * dy.shape[0] <= STRIDED_MAX_FLOP:
             return _K.strided(dy, 1, dy.stride(0), x, 1, x.stride(0), dy.shape[1], x.shape[1], dy.shape[0])
@@ -110,7 +139,17 @@ class _K:
         I = x.shape[1]
         if (LAYOUT_GEMM and O % 4 == 0 and I % 4 == 0 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.stride(1) == 1
                 and x.stride(1) == 1):
-            return _K.layouts(dy, dy.stride(0), True, x, x.stride(0), True, O, I, R)        # A(m = o, k = r) = dY[r][o], B(n = i, k = r) = X[r][i]
+            st = _K._side if side else None
+            if st is None:
+                return _K.layouts(dy, dy.stride(0), True, x, x.stride(0), True, O, I, R)    # A(m = o, k = r) = dY[r][o], B(n = i, k = r) = X[r][i]
+            if st["used"] == len(st["events"]):
+                st["events"].append(torch.cuda.Event())
+            ev = st["events"][st["used"]]
+            st["used"] += 1
+            ev.record()                                                      # dY (and X) are complete on the main stream here
+            st["stream"].wait_event(ev)
+            st["keep"].append((dy, x))
+            return _K.layouts(dy, dy.stride(0), True, x, x.stride(0), True, O, I, R, stream=st["stream"].cuda_stream)
         return _K.gemm(_K.transpose_pad(dy), _K.transpose_pad(x))
 
     # column sums asked for while a batch is open are recorded and run as ONE launch by flush_colsums(): a step has ~36 of them
@@ -393,15 +432,18 @@ def _encoder_backward(model, P, S, dx, G):
 
 
 def _colsum_batched(backward):
-    """Run a backward with _K's column-sum batch open; an exception closes it without launching (nothing may stay recorded)."""
+    """Run a backward with _K's column-sum batch and its side stream for the weight gradients open; an exception closes the batch
+    without launching (nothing may stay recorded); the side stream is joined either way."""
     def wrapped(ctx, gloss):
         _K.open_colsums()
+        _K.side_open(gloss.device if gloss is not None and gloss.is_cuda else torch.device("cuda", torch.cuda.current_device()))
         try:
             out = backward(ctx, gloss)
             _K.flush_colsums()
             return out
         finally:
             _K._pending = None
+            _K.side_join()
     return wrapped
 
 
@@ -598,7 +640,8 @@ class CaptionLoss(torch.autograd.Function):
         _chk(lib.hirest_ce_rows_f32(logits.data_ptr(), Vp, S["tgt32"].data_ptr(), R, Vp, g, S["n_tok"], scratch.data_ptr(), dlog.data_ptr(),
                                     ops.stream_ptr()), "ce_rows")
         _scale_by_upstream(dlog, gloss)
-        dWe = _K.grad_weight(dlog, S["tnorm"])                          # [Vp, 768]: the LM head's share of the tied matrix
+        dWe = _K.grad_weight(dlog, S["tnorm"], side=False)              # [Vp, 768]: the LM head's share of the tied matrix (the embedding
+                                                                        # scatter below adds into it on this stream)
         G[cp + "bias"] = _K.colsum(dlog)[:V]
         dtn = _K.grad_input(dlog, S["Wp"])
         dtg, G[cp + "transform.LayerNorm.weight"], G[cp + "transform.LayerNorm.bias"] = _K.layernorm_bwd(S["tg"], dtn, P[cp + "transform.LayerNorm.weight"], 1e-12)

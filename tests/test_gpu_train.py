@@ -264,3 +264,34 @@ def test_grouped_column_sums_equal_the_single_calls():
     assert lib.hirest_weighted_colsum_grouped_f32(arr, len(cases), ops.stream_ptr()) == 0
     for i, (w, o) in enumerate(zip(want, got)):
         assert torch.equal(w, o), i
+
+
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_backward(dev, golden_dir):
+    """The dW GEMMs of a backward run on a second stream behind "dY is ready" events (train.SIDE_STREAM_DW): same kernels on the same
+    operands, so every gradient must equal the single-stream backward bit for bit — in train mode (same seed, same dropout masks),
+    for all three tasks, repeatedly (a missing dependency would show as a race)."""
+    from hirest_amd import train
+    model, batch, seg_batch, cap_batch, _ = _setup(golden_dir, "a", dev)
+    model.train()
+    def grads(b, side, seed):
+        train.SIDE_STREAM_DW = side
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(seed)
+        model.train_step(b)["loss"].backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    try:
+        for b in (batch, seg_batch, cap_batch):
+            want = grads(b, False, 11)
+            for rep in range(4):
+                got = grads(b, True, 11)
+                assert got.keys() == want.keys()
+                for n in want:
+                    if n == "clip4cap_model.decoder.embeddings.word_embeddings.weight":
+                        # the tied matrix: its embedding share is an atomic scatter-add (order of the adds is not fixed run to run)
+                        assert torch.allclose(got[n], want[n], rtol=1e-4, atol=1e-8), (b["tasks"][0], n, rep)
+                    else:
+                        assert torch.equal(got[n], want[n]), (b["tasks"][0], n, rep)
+    finally:
+        train.SIDE_STREAM_DW = True
