@@ -332,7 +332,7 @@ class MomentModel(nn.Module):
     # ------------------------------------------------------------------ reference interface
     def _text_feat(self, batch, device):
         if "text_feat" in batch:
-            return batch["text_feat"].to(device).float().contiguous()
+            return ops.to_device(batch["text_feat"], device).float().contiguous()
         if self.clip_model is None:
             raise RuntimeError("MomentModel needs clip_model (encode_text) or batch['text_feat']")
         return self.clip_model.encode_text(batch["clip_text_ids"].to(device)).float().contiguous()

@@ -757,18 +757,18 @@ def _train(model, batch, task) -> Dict[str, torch.Tensor]:
         raise RuntimeError("hirest_amd.MomentModel trains on MI355X only (no CPU fallback); move the model to a GPU")
     with torch.no_grad():
         text = model._text_feat(batch, dev)
-    inp = {"task": task, "vis": batch["vis_feats"].to(dev), "text": text, "vis_mask": batch["vis_mask"].to(dev),
-           "moment_mask": batch["moment_mask"].to(dev),
+    inp = {"task": task, "vis": ops.to_device(batch["vis_feats"], dev), "text": text, "vis_mask": ops.to_device(batch["vis_mask"], dev),
+           "moment_mask": ops.to_device(batch["moment_mask"], dev),
            "dropout": 0.1 if model.training else 0.0, "seed": _dropout_seed()}
     if model.use_asr:
-        inp["asr"] = batch["asr_feats"].to(dev)
+        inp["asr"] = ops.to_device(batch["asr_feats"], dev)
     fn = MomentLoss
     if task == "moment_segmentation":
-        inp["boundary_mask"] = batch["prev_boundary_mask"].to(dev)
-        inp["segment_target"] = batch["moment_segmentation_target"].to(dev)
+        inp["boundary_mask"] = ops.to_device(batch["prev_boundary_mask"], dev)
+        inp["segment_target"] = ops.to_device(batch["moment_segmentation_target"], dev)
     elif task == "moment_retrieval":
-        inp["start_target"] = batch["moment_retrieval_start_target"].to(dev)
-        inp["end_target"] = batch["moment_retrieval_end_target"].to(dev)
+        inp["start_target"] = ops.to_device(batch["moment_retrieval_start_target"], dev)
+        inp["end_target"] = ops.to_device(batch["moment_retrieval_end_target"], dev)
     else:   # step_captioning (modeling.py:476-527): trimmed moment frames, all-ones masks, teacher-forcing triples of target_text
         args = model.args
         max_frames = int(getattr(args, "max_frames_step_captioning", 20)) if args is not None else 20

@@ -137,8 +137,9 @@ def measure(dev=None, cpu=True, log=lambda m: None):
     model.train()
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
     st, et, seg, prev = train_targets(f"tb.{T}", B, T, 61, bounds)
-    btr = {"vis_feats": vis, "vis_mask": vis_mask, "asr_feats": asr, "text_feat": text, "tasks": ["moment_retrieval"],
-           "moment_mask": moment_mask, "moment_retrieval_start_target": st, "moment_retrieval_end_target": et}
+    pin = lambda t: t.pin_memory()                    # the reference's loaders deliver pinned batches (hirest_dataset.py:614,624)
+    btr = {"vis_feats": pin(vis), "vis_mask": pin(vis_mask), "asr_feats": pin(asr), "text_feat": pin(text), "tasks": ["moment_retrieval"],
+           "moment_mask": pin(moment_mask), "moment_retrieval_start_target": pin(st), "moment_retrieval_end_target": pin(et)}
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--fused", action="store_true", help="also time the loop with torch.optim.AdamW(fused=True)")
     ap.add_argument("--tasks", nargs="*", default=None, help="subset of moment_retrieval moment_segmentation step_captioning")
+    ap.add_argument("--pageable", action="store_true", help="leave the batch tensors in pageable memory (default: pinned, as DataLoader(pin_memory=True))")
     a = ap.parse_args()
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", "joint_schema.json"))).items()}
     sd = synth.joint_state_dict(shapes, 31)
@@ -57,6 +58,8 @@ def main():
         }
         if a.tasks:
             batches = {k: v for k, v in batches.items() if k in a.tasks}
+        if not a.pageable:                               # the reference's loaders deliver pinned batches (hirest_dataset.py:614,624)
+            batches = {k: {n: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for n, v in b.items()} for k, b in batches.items()}
         for oname, opt in opts.items():
             line = f"T={T:4d} B={B} {oname}:"
             for task, batch in batches.items():

@@ -15,8 +15,9 @@ opt = torch.optim.AdamW(params, lr=1e-5)
 B, T = 5, 300
 vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"tb.{T}", B, T, 61)
 st, et, seg, prev = train_targets(f"tb.{T}", B, T, 61, bounds)
-batch = dict(vis_feats=vis, vis_mask=vis_mask, asr_feats=asr, text_feat=text, tasks=["moment_retrieval"], moment_mask=moment_mask,
-             moment_retrieval_start_target=st, moment_retrieval_end_target=et)
+pin = lambda t: t.pin_memory()                       # as DataLoader(pin_memory=True) delivers them (hirest_dataset.py:614,624)
+batch = dict(vis_feats=pin(vis), vis_mask=pin(vis_mask), asr_feats=pin(asr), text_feat=pin(text), tasks=["moment_retrieval"],
+             moment_mask=pin(moment_mask), moment_retrieval_start_target=pin(st), moment_retrieval_end_target=pin(et))
 import cProfile, pstats
 def step(parts=None):
     t0 = time.perf_counter()
