@@ -717,8 +717,9 @@ class CaptionLoss(torch.autograd.Function):
 
 
 def time_grid(n_valid: torch.Tensor, T: int) -> torch.Tensor:
-    """modeling.py:176-193 as a [B, T] table: (linspace(0, 1, n) - 0.5) * 2 over the n valid frames, zero padded.  Host index
-    arithmetic (the reference builds it on the host too), uploaded once per step."""
+    """modeling.py:176-193 as a [B, T] table: (linspace(0, 1, n) - 0.5) * 2 over the n valid frames, zero padded — built on the host
+    with torch.linspace, as the reference builds it.  The training step does NOT call this (reading n_valid back would stall its
+    enqueue): it uses hirest_joint_time_grid_f32, which tests/test_gpu_train.py holds to this table bit for bit."""
     rows = []
     for n in n_valid.cpu().tolist():
         rows.append(torch.cat([(torch.linspace(0, 1, int(n)) - 0.5) * 2, torch.zeros(T - int(n))]))
