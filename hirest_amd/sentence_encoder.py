@@ -24,10 +24,12 @@ There is no CPU path: `encode` raises off-GPU.
 """
 from __future__ import annotations
 
+import itertools
 import json
 import os
 from typing import Dict, List, Optional, Sequence, Union
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -187,30 +189,42 @@ class SentenceTransformer(nn.Module):
         return out
 
     @torch.no_grad()
-    def encode_ids(self, rows: Sequence[Sequence[int]], max_tokens_per_pass: int = 1 << 18) -> torch.Tensor:
+    def encode_ids(self, rows: Sequence[Sequence[int]], max_tokens_per_pass: int = 1 << 18, pipeline_tokens: int = 12288) -> torch.Tensor:
         """Ragged token-id rows ([CLS] ... [SEP] each, already truncated) -> [N, hidden] fp32 on the model's device."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("hirest_amd.SentenceTransformer runs on MI355X only (no CPU fallback); move the model to a GPU")
         maxpos, vocab = self.config["max_position_embeddings"], self.config["vocab_size"]
         out = torch.empty((len(rows), self.hidden), dtype=torch.float32, device=dev)
+        if not len(rows):
+            return out
+        # Host side of a pass (flatten the ragged rows, positions, offsets) in numpy, packed into ONE pinned int32 buffer and uploaded
+        # asynchronously, and the batch cut into passes of ~pipeline_tokens so that the host prepares pass k + 1 while the GPU runs
+        # pass k (as one pass, 45 k tokens cost 3 ms of Python list work with the GPU idle: 18 % of the call).  Rows are independent
+        # and every kernel is batch-invariant, so the cut does not change a bit of the result.
+        lens_all = np.fromiter(map(len, rows), dtype=np.int64, count=len(rows))
+        bad = np.nonzero((lens_all < 1) | (lens_all > maxpos))[0]
+        if bad.size:
+            raise ValueError(f"sentence {int(bad[0])}: {int(lens_all[bad[0]])} tokens (1 .. {maxpos})")
+        per_pass = min(int(max_tokens_per_pass), max(int(pipeline_tokens), maxpos))
         with torch.cuda.device(dev):
             s = 0
             while s < len(rows):
-                e, tokens = s, 0
-                while e < len(rows) and (e == s or tokens + len(rows[e]) <= max_tokens_per_pass):
-                    if not 1 <= len(rows[e]) <= maxpos:
-                        raise ValueError(f"sentence {e}: {len(rows[e])} tokens (1 .. {maxpos})")
-                    tokens += len(rows[e]); e += 1
-                lens = torch.tensor([len(r) for r in rows[s:e]], dtype=torch.int64)
-                ids = torch.tensor([t for r in rows[s:e] for t in r], dtype=torch.int32)
-                if int(ids.min()) < 0 or int(ids.max()) >= vocab:
+                cum = np.cumsum(lens_all[s:])
+                e = s + max(1, int(np.searchsorted(cum, per_pass, side="right")))
+                lens = lens_all[s:e]
+                tokens, n = int(cum[e - s - 1]), e - s
+                host = torch.empty((2 * tokens + n + 1,), dtype=torch.int32).pin_memory()     # ids | positions | offsets
+                buf = host.numpy()
+                buf[:tokens] = np.fromiter(itertools.chain.from_iterable(rows[s:e]), dtype=np.int64, count=tokens)
+                if int(buf[:tokens].min()) < 0 or int(buf[:tokens].max()) >= vocab:
                     raise ValueError("token id outside the vocabulary")
-                off = torch.zeros(e - s + 1, dtype=torch.int64)
-                off[1:] = torch.cumsum(lens, 0)
-                pos = torch.arange(tokens, dtype=torch.int64) - torch.repeat_interleave(off[:-1], lens)
-                out[s:e] = self._encode_packed(ids.to(dev), pos.to(torch.int32).to(dev), off.to(torch.int32).to(dev), e - s,
-                                               int(lens.max()))
+                off = buf[2 * tokens:]
+                off[0] = 0
+                off[1:] = np.cumsum(lens)
+                buf[tokens:2 * tokens] = np.arange(tokens, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), lens)
+                d = host.to(dev, non_blocking=True)
+                out[s:e] = self._encode_packed(d[:tokens], d[tokens:2 * tokens], d[2 * tokens:], n, int(lens.max()))
                 s = e
         return out
 
