@@ -60,6 +60,7 @@ class OpenAIVisionTower(_Tower):
             b.mlp.c_fc, b.mlp.c_proj = _linear(4 * D, D), _linear(D, 4 * D)
             blocks.append(b)
         self.transformer.resblocks = nn.ModuleList(blocks)
+        self.pip_head = False          # True: return the CLS embedding like the pip `clip` package (clip.load(..., pip_head=True))
         self.ln_post = _norm(D)
         self.proj = nn.Parameter(torch.zeros(D, output_dim))
         self.max_frames_per_call = 2048
@@ -117,6 +118,10 @@ class OpenAIVisionTower(_Tower):
             _lib.check(lib.hirest_vision_forward(C.byref(prep["desc"]), x[s:s + n].data_ptr(), ops._IN_DTYPES[x.dtype], n,
                                                  out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(), 0, ops.stream_ptr()),
                        "hirest_vision_forward")
+        if self.pip_head:
+            # the pip `clip` package's head (openai/CLIP @ a9b1bf5, model.py VisionTransformer.forward: ln_post(x[:, 0, :]) @ proj):
+            # LayerNorm and projection act per token, so it is row 0 of what the kernel computed for every token
+            return out[:, 0, :]
         return out[:, 1:, :]            # w/o cls token (model.py:269)
 
 
@@ -196,8 +201,14 @@ def build_model(state_dict: Dict[str, torch.Tensor]) -> CLIP:
     return model.eval()
 
 
-def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False, download_root: str = None):
-    """clip.py:94-193 for local checkpoints: a JIT archive or a plain state dict -> (model, preprocess)."""
+def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False, download_root: str = None, pip_head: bool = False):
+    """clip.py:94-193 for local checkpoints: a JIT archive or a plain state dict -> (model, preprocess).
+
+    ``pip_head=True`` gives the model of the *pip* ``clip`` package (openai/CLIP @ a9b1bf5, requirements.txt:25) that the reference's
+    ``'clip'`` retrieval branch imports (inference_video_retrieval.py:11,169; hirest_dataset.py:84): same weights, same tower, but
+    ``encode_image`` returns the CLS embedding ``ln_post(x[:, 0]) @ proj`` -> [B, embed_dim] instead of the vendored copy's projected
+    patch tokens.  That package is not part of the reference tree, so this head is checked against the oracle's restatement of its
+    published forward only (parity unpinned)."""
     if not os.path.isfile(name):
         raise RuntimeError(f"Model {name} not found; available models = {available_models()}")
     try:
@@ -205,4 +216,5 @@ def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False
     except RuntimeError:
         state_dict = torch.load(name, map_location="cpu")
     model = build_model(state_dict).to(device)
+    model.visual.pip_head = bool(pip_head)
     return model, image_transform(model.visual.input_resolution)

@@ -164,7 +164,7 @@ def eva_forward(sd: SD, img, tok, cfg: dict):
 # OpenAI CLIP ViT as vendored by the reference (EVA_clip/model.py) — BASELINE config 1
 # ----------------------------------------------------------------------------------
 
-def openai_encode_image(sd: SD, img: torch.Tensor, c: dict) -> torch.Tensor:
+def openai_encode_image(sd: SD, img: torch.Tensor, c: dict, pip_head: bool = False) -> torch.Tensor:
     """VisionTransformer.forward (model.py:254-273).  NOTE the vendored copy drops the CLS
     token and returns ln_post(patch tokens) @ proj -> [B, grid^2, E] (SURVEY hazard H4)."""
     P, W = c["vision_patch_size"], c["vision_width"]
@@ -177,6 +177,11 @@ def openai_encode_image(sd: SD, img: torch.Tensor, c: dict) -> torch.Tensor:
     heads = W // 64  # model.py:299
     for i in range(c["vision_layers"]):
         x = _mha_block(sd, f"visual.transformer.resblocks.{i}.", x, heads, None, quick_gelu)
+    if pip_head:
+        # NOT the reference tree: the pip `clip` package (openai/CLIP @ a9b1bf5920416aaeaec965c25dd9e8f98c864f16, pinned by
+        # requirements.txt:25) ends VisionTransformer.forward with x = self.ln_post(x[:, 0, :]); x = x @ self.proj.  Parity unpinned:
+        # no golden vector of that package exists here; this line restates its published forward.
+        return layer_norm(x[:, 0], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5) @ sd["visual.proj"]
     x = layer_norm(x[:, 1:], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5)
     return x @ sd["visual.proj"]
 

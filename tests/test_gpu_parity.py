@@ -391,6 +391,24 @@ def test_openai_clip_tiny_vs_reference(dev, golden_dir):
     _check_embed(model.encode_text(torch.from_numpy(g["tokens"]).to(dev)).cpu(), torch.from_numpy(g["text_embed"]), "openai tiny text")
 
 
+def test_openai_clip_pip_head_vs_oracle(dev):
+    """The pip `clip` package's CLS head (`clip.load(..., pip_head=True)`; inference_video_retrieval.py:169's model): PARITY UNPINNED —
+    that package is not in the reference tree, so the yardstick is the oracle's restatement of its published forward
+    (oracle/ref_cpu.py:openai_encode_image(pip_head=True)), whose tower is the one the vendored-head goldens pin."""
+    from hirest_amd import clip
+    from oracle import ref_cpu
+    c, seed = synth.OPENAI_VIT_TINY, 23
+    sd = synth.openai_clip_state_dict(c, seed)
+    model = clip.build_model(sd).to(dev)
+    img = synth.frames("openai_pip.img", (6, 3, 224, 224), seed + 1)
+    model.visual.pip_head = True
+    got = model.encode_image(img.to(dev))
+    assert got.shape == (6, c["embed_dim"])
+    _check_embed(got.cpu(), ref_cpu.openai_encode_image(sd, img, c, pip_head=True), "openai tiny CLS head (pip clip)")
+    model.visual.pip_head = False
+    assert model.encode_image(img.to(dev)).shape == (6, 49, c["embed_dim"])
+
+
 def test_openai_clip_b32_config1_vs_reference(dev, golden_dir):
     """ViT-B/32, 64 frames + 16 real prompts: frame embedding = mean of projected patch tokens, cosine top-5."""
     from hirest_amd import clip
