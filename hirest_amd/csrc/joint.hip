@@ -1063,12 +1063,15 @@ __global__ __launch_bounds__(64) void attention_f32_decode_kernel(AttnDec p) {
     p.out[(int64_t)r * D + h * 64 + lane] = o * inv;
 }
 
-// dh 64 -> the 64-wide instantiation (the joint model, the sentence encoder's padded heads), 64 < dh <= 96 -> the 96-wide one
+// head width (a multiple of 4) -> the narrowest instantiation that holds it: 32 (MiniLM's 32-wide heads: the sentence encoder used to
+// zero-pad them to 64, i.e. twice the attention and qkv / output-projection work), 64 (the joint model), 96 (EVA-CLIP's 88).  Padded
+// dims are zeros that join the sums last or not at all, so a head gives the same bits in every instantiation that holds it.
 template <class... Args>
 int launch_attention_f32(int dh, dim3 grid, hipStream_t s, Args... args) {
-    if (dh == 64) hipLaunchKernelGGL(attention_f32_kernel<64>, grid, dim3(256), 0, s, args...);
-    else if (dh > 64 && dh <= 96 && dh % 4 == 0) hipLaunchKernelGGL(attention_f32_kernel<96>, grid, dim3(256), 0, s, args...);
-    else return HIREST_E_SHAPE;
+    if (dh <= 0 || dh % 4 != 0 || dh > 96) return HIREST_E_SHAPE;
+    if (dh <= 32) hipLaunchKernelGGL(attention_f32_kernel<32>, grid, dim3(256), 0, s, args...);
+    else if (dh <= 64) hipLaunchKernelGGL(attention_f32_kernel<64>, grid, dim3(256), 0, s, args...);
+    else hipLaunchKernelGGL(attention_f32_kernel<96>, grid, dim3(256), 0, s, args...);
     return hirest_launch_status();
 }
 

@@ -36,7 +36,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .wordpiece import WordPieceTokenizer
 
-_AH = 64   # head width of hirest_attention_f32
+_AH_MAX = 96   # widest head of hirest_attention_f32 (any multiple of 4 up to it; other widths are zero-padded to the next multiple of 4)
 
 
 def _load_weights(model_dir: str) -> Dict[str, torch.Tensor]:
@@ -81,8 +81,11 @@ class SentenceTransformer(nn.Module):
         self.heads = int(config["num_attention_heads"])
         self.eps = float(config.get("layer_norm_eps", 1e-12))
         self.dh = self.hidden // self.heads
-        if self.dh > _AH or self.hidden % self.heads or self.hidden % 4:
-            raise NotImplementedError(f"head width {self.dh} > {_AH}")
+        if self.dh > _AH_MAX or self.hidden % self.heads or self.hidden % 4:
+            raise NotImplementedError(f"head width {self.dh} > {_AH_MAX}")
+        self.ah = (self.dh + 3) // 4 * 4               # head width as the kernels see it (MiniLM: 32, no padding) ...
+        while (self.heads * self.ah) % 16:             # ... such that the output projection's reduction length suits the GEMM
+            self.ah += 4
         self.max_seq_length = int(max_seq_length or 256)                      # all-MiniLM-L6-v2's sentence_bert_config.json
         self.max_seq_length = min(self.max_seq_length, int(config["max_position_embeddings"]))
         self.tokenizer = WordPieceTokenizer(vocab) if vocab is not None else None
@@ -128,19 +131,21 @@ class SentenceTransformer(nn.Module):
              "pos": (f("embeddings.position_embeddings.weight") + f("embeddings.token_type_embeddings.weight")[0]).contiguous(),
              "eln_w": f("embeddings.LayerNorm.weight"), "eln_b": f("embeddings.LayerNorm.bias")}
 
-        def pad_rows(w, b):      # [H*dh, D] -> [H*64, D]: head h's rows at 64 h .. 64 h + dh, zeros after
-            wp = torch.zeros((H, _AH, D), device=dev); wp[:, :dh] = w.view(H, dh, D)
-            bp = torch.zeros((H, _AH), device=dev); bp[:, :dh] = b.view(H, dh)
-            return wp.view(H * _AH, D), bp.view(H * _AH)
+        AH = self.ah
+
+        def pad_rows(w, b):      # [H*dh, D] -> [H*AH, D]: head h's rows at AH h .. AH h + dh, zeros after (AH = dh: a copy)
+            wp = torch.zeros((H, AH, D), device=dev); wp[:, :dh] = w.view(H, dh, D)
+            bp = torch.zeros((H, AH), device=dev); bp[:, :dh] = b.view(H, dh)
+            return wp.view(H * AH, D), bp.view(H * AH)
         for i in range(self.layers):
             p = f"encoder.layer.{i}."
             ws, bs = zip(*(pad_rows(f(p + f"attention.self.{n}.weight"), f(p + f"attention.self.{n}.bias"))
                            for n in ("query", "key", "value")))
             c[f"qkv_w.{i}"] = torch.cat(ws, 0).contiguous()
             c[f"qkv_b.{i}"] = torch.cat(bs, 0).contiguous()
-            wo = torch.zeros((D, H, _AH), device=dev)
+            wo = torch.zeros((D, H, AH), device=dev)
             wo[:, :, :dh] = f(p + "attention.output.dense.weight").view(D, H, dh)
-            c[f"o_w.{i}"] = wo.view(D, H * _AH).contiguous()
+            c[f"o_w.{i}"] = wo.view(D, H * AH).contiguous()
             for n in ("attention.output.dense.bias", "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
                       "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight", "output.dense.bias",
                       "output.LayerNorm.weight", "output.LayerNorm.bias"):
@@ -175,8 +180,8 @@ class SentenceTransformer(nn.Module):
         for i in range(self.layers):
             p = f"encoder.layer.{i}."
             qkv = self._gemm(x, c[f"qkv_w.{i}"], c[f"qkv_b.{i}"])
-            ctx = torch.empty((rows, H * _AH), dtype=torch.float32, device=x.device)
-            _lib.check(lib.hirest_attention_f32_varlen(qkv.data_ptr(), ctx.data_ptr(), seq_off.data_ptr(), n, max_len, H, _AH,
+            ctx = torch.empty((rows, H * self.ah), dtype=torch.float32, device=x.device)
+            _lib.check(lib.hirest_attention_f32_varlen(qkv.data_ptr(), ctx.data_ptr(), seq_off.data_ptr(), n, max_len, H, self.ah,
                                                        self.dh ** -0.5, 0.0, ops.stream_ptr()), "hirest_attention_f32_varlen")
             a = self._gemm(ctx, c[f"o_w.{i}"], c[p + "attention.output.dense.bias"], resid=x)
             a = self._ln(a, c[p + "attention.output.LayerNorm.weight"], c[p + "attention.output.LayerNorm.bias"])

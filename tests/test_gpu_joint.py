@@ -107,6 +107,28 @@ def test_attention_f32_with_constant_shift(dev, B, T, H):
     assert (out.cpu().double() - ref).abs().max().item() < 5e-3 * v.abs().max().item()
 
 
+@pytest.mark.parametrize("dh", [32, 20, 48])
+def test_attention_f32_narrow_heads_equal_zero_padded_wide_ones(dev, dh):
+    """Heads narrower than 64 take the narrowest instantiation that holds them (MiniLM's 32-wide heads: the 32-wide one) instead of
+    being zero-padded to 64 by the caller: same products in the same order, so the context equals the padded run bit for bit, and
+    the fp64 softmax within the usual bound."""
+    from hirest_amd import _lib, ops
+    lib, st = _lib.load(), ops.stream_ptr()
+    B, T, H = 3, 45, 12
+    qkv = synth.tensor(f"an.{dh}", (B * T, 3, H, dh), 1.0, 5)
+    out = torch.empty((B * T, H * dh), dtype=torch.float32, device=dev)
+    q_ = qkv.reshape(B * T, 3 * H * dh).to(dev)
+    _lib.check(lib.hirest_attention_f32(q_.data_ptr(), out.data_ptr(), B, T, H, dh, dh ** -0.5, 0.0, st), "attention_f32 narrow")
+    wide = torch.zeros((B * T, 3, H, 64)); wide[..., :dh] = qkv
+    w_ = wide.reshape(B * T, 3 * H * 64).to(dev)
+    outw = torch.empty((B * T, H * 64), dtype=torch.float32, device=dev)
+    _lib.check(lib.hirest_attention_f32(w_.data_ptr(), outw.data_ptr(), B, T, H, 64, dh ** -0.5, 0.0, st), "attention_f32 padded")
+    assert torch.equal(out.view(B * T, H, dh), outw.view(B * T, H, 64)[..., :dh])
+    q, k, v = qkv.reshape(B, T, 3, H, dh).permute(2, 0, 3, 1, 4).double()
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, -1) @ v).transpose(1, 2).reshape(B * T, H * dh)
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-5
+
+
 def _case(golden_dir, case):
     from hirest_amd.synth import joint_inputs
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
