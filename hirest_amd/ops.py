@@ -222,7 +222,8 @@ def topk(scores: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
 def to_device(t: torch.Tensor, device) -> torch.Tensor:
     """t.to(device) that does not stall the host when it need not: a pinned CPU tensor (what DataLoader(pin_memory=True) delivers:
     hirest_dataset.py:614,624) is copied asynchronously on the current stream — the kernels that read it are behind it on the same
-    stream — everything else as t.to(device)."""
+    stream — everything else as t.to(device).  As with any non_blocking copy, the source must not be overwritten before the copy has
+    run (DataLoader hands out fresh pinned tensors per batch; a caller that refills one pinned buffer in place must synchronise first)."""
     if t.device.type == "cpu" and t.is_pinned():
         return t.to(device, non_blocking=True)
     return t.to(device)
