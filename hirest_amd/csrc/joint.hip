@@ -842,8 +842,10 @@ __device__ __forceinline__ float attn_lsum(float lrun, float alpha, float psum) 
 
 // DHP = head dim padded to a multiple of 32 (64, or 96 for EVA-CLIP's 88-wide heads: the fp32 reference-precision tower);
 // dh = the real head dim (the packed layouts are addressed with it; padded dims are zeros and their outputs are not stored).
-template <int DHP>
-__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
+// NW = waves per block (32 queries each): 4, or 1 for short sequences (the sentence encoder's 4 .. 40-token sentences left three of
+// four waves without a query, staging and synchronising for nothing).
+template <int DHP, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attention_f32_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
                                                            const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
                                                            int Tq, int T, int H, int dh, float scale, float add_const,
                                                            float causal_penalty, const int32_t* __restrict__ seq_off) {
@@ -852,7 +854,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     __shared__ float Vs[32 * ALD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int qblocks = (Tq + 127) / 128;
+    constexpr int QB = 32 * NW, NT = 64 * NW;                // queries per block, threads per block
+    const int qblocks = (Tq + QB - 1) / QB;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
     const int b = bh / H, h = bh - b * H;
     const int D = H * dh;
@@ -860,12 +863,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     if (seq_off) {   // packed ragged self-attention: sequence b = rows seq_off[b] .. seq_off[b+1]; Tq was only the longest one
         qrow0 = krow0 = seq_off[b];
         Tq = T = seq_off[b + 1] - seq_off[b];
-        if (qb * 128 >= Tq) return;                       // (block-uniform)
+        if (qb * QB >= Tq) return;                       // (block-uniform)
     }
     const float* qbase = qp + qrow0 * ldq + h * dh;
     const float* kbase = kp + krow0 * ldkv + h * dh;
     const float* vbase = vp + krow0 * ldkv + h * dh;
-    const int q = qb * 128 + wave * 32 + l31;
+    const int q = qb * QB + wave * 32 + l31;
     const bool qvalid = q < Tq;
     // Q^T fragments: B operand [k = d][j = query]: lane holds Q[q][2s + half] for s = 0..DHP/2-1
     // (every load unconditional on a clamped index, the zero chosen afterwards: a guarded load is a memory round trip of its own)
@@ -886,12 +889,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // K / V tile staging through registers, one tile ahead (the next tile's rows travel while this one is multiplied: a synchronous
     // load per 32-key tile was a memory round trip in front of every tile, 10 of them at T = 300)
-    constexpr int NLD = (32 * (DHP / 4) + 255) / 256;         // float4 per thread and operand: 2 (dh 64) or 3 (96)
+    constexpr int NLD = (32 * (DHP / 4) + NT - 1) / NT;       // float4 per thread and operand: 2 (dh 64) or 3 (96) with four waves
     f32x4 kreg[NLD], vreg[NLD];
     auto fetch_kv = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
-            int i = tid + 256 * u; i = i < 32 * (DHP / 4) ? i : 32 * (DHP / 4) - 1;
+            int i = tid + NT * u; i = i < 32 * (DHP / 4) ? i : 32 * (DHP / 4) - 1;
             const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
             const int key = k0 + kr < T ? k0 + kr : T - 1;
             const int cc = c < dh ? c : dh - 4;                  // (dh % 4 == 0: a 4-vector is inside or outside the head as a whole)
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
-            const int i = tid + 256 * u;
+            const int i = tid + NT * u;
             if (i < 32 * (DHP / 4)) {
                 const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
                 const f32x4 kv = c >= dh ? zero4 : kreg[u], vv = c >= dh ? zero4 : vreg[u];
@@ -1066,12 +1069,22 @@ __global__ __launch_bounds__(64) void attention_f32_decode_kernel(AttnDec p) {
 // head width (a multiple of 4) -> the narrowest instantiation that holds it: 32 (MiniLM's 32-wide heads: the sentence encoder used to
 // zero-pad them to 64, i.e. twice the attention and qkv / output-projection work), 64 (the joint model), 96 (EVA-CLIP's 88).  Padded
 // dims are zeros that join the sums last or not at all, so a head gives the same bits in every instantiation that holds it.
+// Queries per block: 128 (four waves), or 32 (one wave) when no sequence is longer than 64 — then at most two blocks of the one-wave
+// form replace one four-wave block that would be at least half empty.
 template <class... Args>
-int launch_attention_f32(int dh, dim3 grid, hipStream_t s, Args... args) {
+int launch_attention_f32(int dh, int64_t BH, int Tq_max, hipStream_t s, Args... args) {
     if (dh <= 0 || dh % 4 != 0 || dh > 96) return HIREST_E_SHAPE;
-    if (dh <= 32) hipLaunchKernelGGL(attention_f32_kernel<32>, grid, dim3(256), 0, s, args...);
-    else if (dh <= 64) hipLaunchKernelGGL(attention_f32_kernel<64>, grid, dim3(256), 0, s, args...);
-    else hipLaunchKernelGGL(attention_f32_kernel<96>, grid, dim3(256), 0, s, args...);
+    const bool narrow = Tq_max <= 64;
+    const dim3 grid((unsigned)(BH * ((Tq_max + (narrow ? 31 : 127)) / (narrow ? 32 : 128))));
+    if (narrow) {
+        if (dh <= 32) hipLaunchKernelGGL((attention_f32_kernel<32, 1>), grid, dim3(64), 0, s, args...);
+        else if (dh <= 64) hipLaunchKernelGGL((attention_f32_kernel<64, 1>), grid, dim3(64), 0, s, args...);
+        else hipLaunchKernelGGL((attention_f32_kernel<96, 1>), grid, dim3(64), 0, s, args...);
+    } else {
+        if (dh <= 32) hipLaunchKernelGGL((attention_f32_kernel<32, 4>), grid, dim3(256), 0, s, args...);
+        else if (dh <= 64) hipLaunchKernelGGL((attention_f32_kernel<64, 4>), grid, dim3(256), 0, s, args...);
+        else hipLaunchKernelGGL((attention_f32_kernel<96, 4>), grid, dim3(256), 0, s, args...);
+    }
     return hirest_launch_status();
 }
 
@@ -1427,8 +1440,7 @@ extern "C" int hirest_attention_f32(const float* qkv, float* out, int32_t B, int
                                     float scale, float add_const, void* stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return HIREST_E_BADARG;
     const int64_t ld = 3 * (int64_t)H * dh;
-    const int qblocks = (T + 127) / 128;
-    return launch_attention_f32(dh, dim3(B * H * qblocks), reinterpret_cast<hipStream_t>(stream), qkv, ld, qkv + H * dh, qkv + 2 * H * dh, ld,
+    return launch_attention_f32(dh, (int64_t)B * H, T, reinterpret_cast<hipStream_t>(stream), qkv, ld, qkv + H * dh, qkv + 2 * H * dh, ld,
                                 out, (int)T, (int)T, (int)H, (int)dh, scale, add_const, 0.f, (const int32_t*)nullptr);
 }
 
@@ -1436,8 +1448,7 @@ extern "C" int hirest_attention_f32_varlen(const float* qkv, float* out, const i
                                            int32_t dh, float scale, float add_const, void* stream) {
     if (!qkv || !out || !seq_off || B <= 0 || max_len <= 0 || H <= 0) return HIREST_E_BADARG;
     const int64_t ld = 3 * (int64_t)H * dh;
-    const int qblocks = (max_len + 127) / 128;
-    return launch_attention_f32(dh, dim3(B * H * qblocks), reinterpret_cast<hipStream_t>(stream), qkv, ld, qkv + H * dh, qkv + 2 * H * dh, ld,
+    return launch_attention_f32(dh, (int64_t)B * H, max_len, reinterpret_cast<hipStream_t>(stream), qkv, ld, qkv + H * dh, qkv + 2 * H * dh, ld,
                                 out, (int)max_len, (int)max_len, (int)H, (int)dh, scale, add_const, 0.f, seq_off);
 }
 
@@ -1446,8 +1457,7 @@ extern "C" int hirest_attention_f32_qkv(const float* q, int64_t ldq, const float
                                         float causal_penalty, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
     if (ldq % 4 != 0 || ldkv % 4 != 0) return HIREST_E_SHAPE;
-    const int qblocks = (Tq + 127) / 128;
-    return launch_attention_f32(dh, dim3(B * H * qblocks), reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk,
+    return launch_attention_f32(dh, (int64_t)B * H, Tq, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk,
                                 (int)H, (int)dh, scale, add_const, causal_penalty, (const int32_t*)nullptr);
 }
 

@@ -129,6 +129,26 @@ def test_attention_f32_narrow_heads_equal_zero_padded_wide_ones(dev, dh):
     assert (out.cpu().double() - ref).abs().max().item() < 1e-5
 
 
+def test_attention_f32_one_wave_blocks_equal_four_wave_blocks(dev):
+    """Calls with at most 64 queries per sequence run 32-query one-wave blocks instead of 128-query four-wave blocks (the sentence
+    encoder's short sentences): a query's arithmetic does not depend on the block it sits in, so 100 queries in one call (four-wave
+    form) equal the same queries in two calls of 50 (one-wave form) bit for bit — same keys and values."""
+    from hirest_amd import _lib, ops
+    lib, st = _lib.load(), ops.stream_ptr()
+    B, T, H, D = 2, 100, 12, 768
+    qkv = synth.tensor("aw.qkv", (B, T, 3 * D), 1.0, 6).to(dev)
+    full = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+    _lib.check(lib.hirest_attention_f32(qkv.data_ptr(), full.data_ptr(), B, T, H, 64, 0.125, -10000.0, st), "four-wave")
+    for b in range(B):
+        k, v = qkv[b, :, D:2 * D], qkv[b, :, 2 * D:]
+        for lo in (0, 50):
+            q = qkv[b, lo:lo + 50, :D]
+            part = torch.empty((50, D), dtype=torch.float32, device=dev)
+            _lib.check(lib.hirest_attention_f32_qkv(q.data_ptr(), 3 * D, k.data_ptr(), v.data_ptr(), 3 * D, part.data_ptr(), 1, 50, T, H, 64, 0.125,
+                                                    -10000.0, 0.0, st), "one-wave")
+            assert torch.equal(part, full[b, lo:lo + 50]), (b, lo)
+
+
 def _case(golden_dir, case):
     from hirest_amd.synth import joint_inputs
     shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
