@@ -1069,22 +1069,24 @@ __global__ __launch_bounds__(64) void attention_f32_decode_kernel(AttnDec p) {
 // head width (a multiple of 4) -> the narrowest instantiation that holds it: 32 (MiniLM's 32-wide heads: the sentence encoder used to
 // zero-pad them to 64, i.e. twice the attention and qkv / output-projection work), 64 (the joint model), 96 (EVA-CLIP's 88).  Padded
 // dims are zeros that join the sums last or not at all, so a head gives the same bits in every instantiation that holds it.
-// Queries per block: 128 (four waves), or 32 (one wave) when no sequence is longer than 64 — then at most two blocks of the one-wave
-// form replace one four-wave block that would be at least half empty.
+// Waves (32 queries each) per block: one when no sequence is longer than 64 — at most two one-wave blocks then replace a four-wave
+// block that would be at least half empty; otherwise four, or three when that wastes fewer waves (257 queries, the fp32 EVA-CLIP
+// tower: 3 x 3 waves instead of 2 four-wave blocks + one that serves a single query).  A query's arithmetic does not depend on it.
+template <int NW, class... Args>
+void launch_attention_f32_nw(int dh, dim3 grid, hipStream_t s, Args... args) {
+    if (dh <= 32) hipLaunchKernelGGL((attention_f32_kernel<32, NW>), grid, dim3(64 * NW), 0, s, args...);
+    else if (dh <= 64) hipLaunchKernelGGL((attention_f32_kernel<64, NW>), grid, dim3(64 * NW), 0, s, args...);
+    else hipLaunchKernelGGL((attention_f32_kernel<96, NW>), grid, dim3(64 * NW), 0, s, args...);
+}
 template <class... Args>
 int launch_attention_f32(int dh, int64_t BH, int Tq_max, hipStream_t s, Args... args) {
     if (dh <= 0 || dh % 4 != 0 || dh > 96) return HIREST_E_SHAPE;
-    const bool narrow = Tq_max <= 64;
-    const dim3 grid((unsigned)(BH * ((Tq_max + (narrow ? 31 : 127)) / (narrow ? 32 : 128))));
-    if (narrow) {
-        if (dh <= 32) hipLaunchKernelGGL((attention_f32_kernel<32, 1>), grid, dim3(64), 0, s, args...);
-        else if (dh <= 64) hipLaunchKernelGGL((attention_f32_kernel<64, 1>), grid, dim3(64), 0, s, args...);
-        else hipLaunchKernelGGL((attention_f32_kernel<96, 1>), grid, dim3(64), 0, s, args...);
-    } else {
-        if (dh <= 32) hipLaunchKernelGGL((attention_f32_kernel<32, 4>), grid, dim3(256), 0, s, args...);
-        else if (dh <= 64) hipLaunchKernelGGL((attention_f32_kernel<64, 4>), grid, dim3(256), 0, s, args...);
-        else hipLaunchKernelGGL((attention_f32_kernel<96, 4>), grid, dim3(256), 0, s, args...);
-    }
+    const int waves = (Tq_max + 31) / 32;
+    const int nw = Tq_max <= 64 ? 1 : ((waves + 2) / 3 * 3 < (waves + 3) / 4 * 4 ? 3 : 4);
+    const dim3 grid((unsigned)(BH * ((waves + nw - 1) / nw)));
+    if (nw == 1) launch_attention_f32_nw<1>(dh, grid, s, args...);
+    else if (nw == 3) launch_attention_f32_nw<3>(dh, grid, s, args...);
+    else launch_attention_f32_nw<4>(dh, grid, s, args...);
     return hirest_launch_status();
 }
 

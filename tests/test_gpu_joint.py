@@ -135,7 +135,7 @@ def test_attention_f32_one_wave_blocks_equal_four_wave_blocks(dev):
     form) equal the same queries in two calls of 50 (one-wave form) bit for bit — same keys and values."""
     from hirest_amd import _lib, ops
     lib, st = _lib.load(), ops.stream_ptr()
-    B, T, H, D = 2, 100, 12, 768
+    B, T, H, D = 2, 100, 12, 768                            # (100 queries = 4 waves: four-wave blocks; the 257-query case below: three-wave)
     qkv = synth.tensor("aw.qkv", (B, T, 3 * D), 1.0, 6).to(dev)
     full = torch.empty((B, T, D), dtype=torch.float32, device=dev)
     _lib.check(lib.hirest_attention_f32(qkv.data_ptr(), full.data_ptr(), B, T, H, 64, 0.125, -10000.0, st), "four-wave")
@@ -147,6 +147,15 @@ def test_attention_f32_one_wave_blocks_equal_four_wave_blocks(dev):
             _lib.check(lib.hirest_attention_f32_qkv(q.data_ptr(), 3 * D, k.data_ptr(), v.data_ptr(), 3 * D, part.data_ptr(), 1, 50, T, H, 64, 0.125,
                                                     -10000.0, 0.0, st), "one-wave")
             assert torch.equal(part, full[b, lo:lo + 50]), (b, lo)
+    # 257 queries (9 waves) take three-wave blocks; the first 128 of them asked for alone take one four-wave block
+    T2 = 257
+    qkv2 = synth.tensor("aw.qkv2", (1, T2, 3 * D), 1.0, 6).to(dev)
+    full2 = torch.empty((T2, D), dtype=torch.float32, device=dev)
+    _lib.check(lib.hirest_attention_f32(qkv2.data_ptr(), full2.data_ptr(), 1, T2, H, 64, 0.125, 0.0, st), "three-wave")
+    part2 = torch.empty((128, D), dtype=torch.float32, device=dev)
+    _lib.check(lib.hirest_attention_f32_qkv(qkv2.data_ptr(), 3 * D, qkv2[0, :, D:].data_ptr(), qkv2[0, :, 2 * D:].data_ptr(), 3 * D, part2.data_ptr(),
+                                            1, 128, T2, H, 64, 0.125, 0.0, 0.0, st), "four-wave")
+    assert torch.equal(part2, full2[:128])
 
 
 def _case(golden_dir, case):
