@@ -379,8 +379,10 @@ int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* ids, const fl
  * instead of scanning the rows for their maximum). */
 int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const float* gamma, const float* beta, float eps, const float* W, int64_t ldw,
                               const float* bias, float* out, int64_t ldo, float* colmax, int32_t M, int32_t N, int32_t K, void* stream);
-/* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*64]; no key masking (the
- * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3). */
+/* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*dh]; no key masking (the
+ * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3).  dh: any multiple of 4 up to 96
+ * (instantiations for 32, 64 and 96 columns; a head gives the same bits in each one that holds it); blocks of one wave (sequences of
+ * at most 64 queries), three or four waves of 32 queries, chosen per call — a query's result does not depend on the choice. */
 int hirest_attention_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t dh,
                          float scale, float add_const, void* stream);
 /* General form: separate q [B*Tq, ldq] and k/v [B*Tk, ldkv] (cross-attention), plus `causal_penalty` added to
