@@ -36,6 +36,7 @@ from . import _lib, ops, synth
 OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)   # eva_clip.py:16
 OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)   # eva_clip.py:17
 
+TOWER_PRECISIONS = ("fp32", "bf16x3", "bf16")
 _NO_GUARD = (1 << 64) - 1           # hirest_vision_guard_offset: (size_t)-1 = this call does not fold
 
 _MODEL_CONFIGS: Dict[str, dict] = {"EVA_CLIP_g_14": synth.EVA_CLIP_G_14, "EVA_CLIP_tiny_test": synth.EVA_CLIP_TINY,
@@ -290,21 +291,35 @@ class VisionTower(_Tower):
         ws = self._ws(nbytes, image.device)
         code = ops._IN_DTYPES[image.dtype]
         self.last_fold_ratio = 0.0
-        for s in range(0, B, step):
+        flags = 0 if self.prune_last_block else _lib.TOWER_NO_PRUNE
+        goff = lib.hirest_vision_guard_offset(C.byref(prep["desc"]), step) if self.fold_guard_ratio is not None else _NO_GUARD
+        starts = list(range(0, B, step))
+        # Guard of the folded LayerNorm (include/hirest_hip.h): every call reports the largest |mean| / sigma any token row had
+        # in any layer, as one float in its workspace.  The workspace is reused by the next micro-batch, so the float is copied
+        # (device -> device, same stream) into a per-call slot and ALL slots are read with one 4 * calls-byte copy after the
+        # last micro-batch has been enqueued: the host never waits for the GPU between micro-batches.
+        guards = torch.zeros(len(starts), dtype=torch.float32, device=image.device) if goff != _NO_GUARD else None
+
+        def call(s, extra=0):
             n = min(step, B - s)
-            args = (C.byref(prep["desc"]), image[s:s + n].data_ptr(), code, n, out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel())
-            flags = 0 if self.prune_last_block else _lib.TOWER_NO_PRUNE
-            _lib.check(lib.hirest_vision_forward(*args, flags, ops.stream_ptr()), "hirest_vision_forward")
-            # Guard of the folded LayerNorm (include/hirest_hip.h): the call reports the largest |mean| / sigma any token row
-            # had in any layer.  Row offsets of more than `fold_guard_ratio` sigma would lose precision in the un-normalised
-            # bf16 operand, so such a call is repeated with the LayerNorm passes (one 4-byte read-back per call).
-            goff = lib.hirest_vision_guard_offset(C.byref(prep["desc"]), n) if self.fold_guard_ratio is not None else _NO_GUARD
-            if goff != _NO_GUARD:
-                ratio = float(ws[goff:goff + 4].view(torch.float32).item())
-                self.last_fold_ratio = max(self.last_fold_ratio, ratio)
-                if not ratio <= self.fold_guard_ratio:                      # non-finite rows report +inf (elementwise.hip)
+            _lib.check(lib.hirest_vision_forward(C.byref(prep["desc"]), image[s:s + n].data_ptr(), code, n, out[s:s + n].data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), flags | extra, ops.stream_ptr()), "hirest_vision_forward")
+            return n
+        for i, s in enumerate(starts):
+            n = call(s)
+            if guards is not None:
+                g = lib.hirest_vision_guard_offset(C.byref(prep["desc"]), n)
+                if g != _NO_GUARD:
+                    guards[i:i + 1].copy_(ws[g:g + 4].view(torch.float32))
+        if guards is not None:
+            ratios = guards.cpu().tolist()
+            self.last_fold_ratio = max(ratios)
+            for s, ratio in zip(starts, ratios):
+                # Row offsets of more than `fold_guard_ratio` sigma would lose precision in the un-normalised bf16 operand: such
+                # a micro-batch is repeated with the LayerNorm passes (non-finite rows report +inf, elementwise.hip).
+                if not ratio <= self.fold_guard_ratio:
                     self.fold_fallbacks += 1
-                    _lib.check(lib.hirest_vision_forward(*args, flags | _lib.TOWER_NO_LNFOLD, ops.stream_ptr()), "hirest_vision_forward")
+                    call(s, _lib.TOWER_NO_LNFOLD)
         return out
 
 
@@ -511,8 +526,18 @@ def create_model(model_name: str, pretrained: str = "", precision: str = "fp32",
     # precision: 'fp32' (the reference's default) runs the exact-fp32 towers, so ranks and indices downstream are the fp32
     # reference's; 'bf16' / 'amp' / 'amp_bf16' select the bf16 MFMA towers (the measured hot path, ~16x faster; embeddings
     # within cos 0.9999 of fp32); 'fp16' as the reference: half-precision outputs (computed on the bf16 towers).
-    if precision == "fp32":
+    # HIREST_PRECISION=<fp32 | bf16x3 | bf16>: opt-in override for UNMODIFIED reference callers, none of which passes
+    # ``precision`` (run.py / inference_video_retrieval.py / extract_features.py all get the fp32 default): the environment
+    # selects the towers without an edit at the call site.  Unset: the argument decides, as in the reference.
+    env = os.environ.get("HIREST_PRECISION", "").strip().lower()
+    if env:
+        if env not in TOWER_PRECISIONS:
+            raise ValueError(f"HIREST_PRECISION={env!r}: expected one of {TOWER_PRECISIONS}")
+        model.set_precision(env)
+    elif precision == "fp32":
         model.set_precision("fp32")
+    elif precision in TOWER_PRECISIONS:
+        model.set_precision(precision)
     elif precision in ("bf16", "amp", "amp_bf16", "amp_bfloat16", "fp16"):
         model.set_precision("bf16")
     else:

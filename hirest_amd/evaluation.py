@@ -2,6 +2,7 @@
 names and dict layouts, so a driver holding predictions can score them without the JSON round trip the reference makes
 (``run.py`` dumps predictions, ``evaluate.py`` re-reads them):
 
+    evaluate_video_retrieval(gt, pred, prompt_to_cat)       # evaluate.py:33-81    R@1/5/10/50 with the (score, name) tie rule
     evaluate_moment_retrieval(gt, pred, prompt_to_cat)      # evaluate.py:83-121   R@0.5 / R@0.7 per prompt category
     compute_step_bound_scores(gt, pred, video_to_cat)       # evaluate.py:123-188  step recall / precision at tIoU
     preprocess_moment_bounds(gt, pred)                      # evaluate.py:322-412  filter + NMS + gap filling
@@ -16,7 +17,7 @@ No CPU fallback.  Caption metrics (CLIPScore / BERTScore / entailment / COCO, :1
 from __future__ import annotations
 
 import json
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -94,6 +95,59 @@ def _ragged(lists: Sequence[Sequence[Sequence[float]]], device):
 
 
 # ------------------------------------------------------------------------------------------------ evaluate.py level
+
+def evaluate_video_retrieval(gt_data, pred_data, prompt_to_cat: Optional[Dict[str, str]] = None, device=None,
+                             ks: Sequence[int] = (1, 5, 10, 50)) -> dict:
+    """evaluate.py:33-81.  ``pred`` is the retrieval script's dict ``{prompt: {"videos": [...], "scores": [...]}}`` (a path, a
+    plain dict, or the ``RetrievalResult`` of ``retrieval.run_corpus``, whose device-resident score matrix is then ranked
+    in place).  The reference sorts ``zip(scores, videos)`` ascending and reverses: score descending, exact ties broken by
+    file name descending; here that order is one top-``max(ks)`` selection per prompt on the device (``hirest_topk_f32`` with
+    the name ranks as tie key), and only the ``[Q, max(ks)]`` index table comes back for the membership test.  Prompts whose
+    ``videos`` lists differ are ranked in groups sharing a list.  ``prompt_to_cat`` None: only the 'all' bucket."""
+    from . import retrieval
+    gt, pred = _load(gt_data), _load(pred_data)
+    device = _dev(device)
+    cat_of = prompt_to_cat or {}
+    cats = _categories(cat_of)
+    ks = [int(k) for k in ks]
+    count = {c: {str(k): 0 for k in ks} for c in cats}
+    total = {c: 0 for c in cats}
+    prompts = list(gt)
+    # group prompts by the identity / content of their video list (the script writes one shared list)
+    by_id: Dict[int, Tuple[List[str], List[str]]] = {}
+    groups: Dict[tuple, Tuple[List[str], List[str]]] = {}
+    for p in prompts:
+        vids = pred[p]["videos"]
+        g = by_id.get(id(vids))
+        if g is None:
+            g = by_id[id(vids)] = groups.setdefault(tuple(vids), (list(vids), []))
+        g[1].append(p)
+    whole = getattr(pred, "scores", None)
+    for vids, members in groups.values():
+        kmax = min(max(ks), len(vids))
+        if whole is not None and vids == getattr(pred, "video_ids", None) and members == getattr(pred, "prompts", None):
+            scores = whole.to(device)
+        else:
+            scores = torch.tensor([pred[p]["scores"] for p in members], dtype=torch.float32, device=device)
+        _, idx = ops.topk(scores.contiguous(), kmax, retrieval.tie_rank_from_names(vids, device))
+        idx = idx.cpu().tolist()
+        for p, row in zip(members, idx):
+            gt_videos = set(gt[p].keys())
+            buckets = ["all"] + ([cat_of[p]] if prompt_to_cat is not None else [])
+            for c in buckets:
+                total[c] += 1
+            for k in ks:
+                if any(vids[v] in gt_videos for v in row[:k]):
+                    for c in buckets:
+                        count[c][str(k)] += 1
+    results = {}
+    for c in cats:
+        if total[c] > 0:
+            results[c] = {"total_prompt_count": total[c]}
+            for k in ks:
+                results[c][f"R@{k}"] = (count[c][str(k)] / total[c]) * 100
+    return results
+
 
 def evaluate_moment_retrieval(gt_data, pred_data, prompt_to_cat: Dict[str, str], device=None) -> dict:
     gt, pred = _load(gt_data), _load(pred_data)

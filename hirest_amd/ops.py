@@ -230,17 +230,24 @@ def to_device(t: torch.Tensor, device) -> torch.Tensor:
 
 
 _F32_GEMM_WS = {}
+_F32_GEMM_RETIRED = []
 
 
-def f32_gemm_workspace(device, nbytes: int, tag: int = 0):
-    """Scratch for hirest_gemm_f32_ws (the split form of few-tile fp32 GEMMs), one buffer per device and `tag`, grown on demand; every
-    user of a tag is on one stream, in order, so sharing it is safe (tag 1: the training step's side stream).  Returns
-    (pointer, bytes) — (None, 0) when the problem wants none."""
+def f32_gemm_workspace(device, nbytes: int, tag: int = 0, stream: Optional[int] = None):
+    """Scratch for hirest_gemm_f32_ws (the split form of few-tile fp32 GEMMs): one buffer per (device, tag, stream), so two
+    streams never share scratch (tag 1: the training step's side stream; `stream` = the raw stream pointer the GEMM is
+    enqueued on, default the current torch stream).  Grown geometrically on demand; an outgrown buffer is RETIRED, not
+    freed: torch's caching allocator only orders a block's reuse against the stream it was allocated on, and the split
+    GEMMs still in flight on this key's stream may be reading it — the retired blocks (their sizes sum to less than the
+    live buffer) stay referenced for the life of the process.  Returns (pointer, bytes) — (None, 0) when the problem
+    wants none."""
     if nbytes <= 0:
         return None, 0
-    key = (device.type, device.index, tag)
+    key = (device.type, device.index, tag, int(stream) if stream is not None else stream_ptr())
     buf = _F32_GEMM_WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 32 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _F32_GEMM_RETIRED.append(buf)
+        buf = torch.empty(max(int(nbytes), 2 * (buf.numel() if buf is not None else 0), 32 << 20), dtype=torch.uint8, device=device)
         _F32_GEMM_WS[key] = buf
     return buf.data_ptr(), buf.numel()

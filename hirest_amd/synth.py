@@ -511,3 +511,44 @@ def c3_names(V: int) -> list:
     exercised; unique for V <= 257."""
     assert V <= 257
     return [f"vid_{(v * 37) % 257:03d}.mp4" for v in range(V)]
+
+
+# ----------------------------------------------------------------------------------
+# BASELINE configs[2] through the feature-file branch (inference_video_retrieval.py:290-355): one [T_v, E] "feature file" per
+# video of a corpus, T_v between 3 and 42 rows (below and above any n_model_frames the tests use, so the linspace
+# subsample both repeats and drops rows).  tests/golden/make_golden.py gen_retrieval_run writes these files and runs the
+# REAL script over them; the tests regenerate the same tensors.
+# ----------------------------------------------------------------------------------
+
+def retrieval_feature_lengths(n_videos: int, seed: int = 9) -> np.ndarray:
+    u = uniform_pm1("vr.len", n_videos, seed)
+    return (3 + np.floor((u + 1.0) * 20.0)).astype(np.int64).clip(3, 42)
+
+
+def retrieval_feature_corpus(n_videos: int, embed_dim: int, seed: int = 9) -> list:
+    """[n_videos] fp32 tensors [T_v, embed_dim]; rows ~ unit-variance noise around a per-video offset (so pooled rows differ)."""
+    lens = retrieval_feature_lengths(n_videos, seed)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    rows = tensor("vr.rows", (int(off[-1]), embed_dim), 1.0, seed)
+    base = tensor("vr.base", (n_videos, embed_dim), 1.0, seed + 1)
+    return [rows[off[v]:off[v + 1]] * 0.25 + base[v] for v in range(n_videos)]
+
+
+def c3_device_block(lo: int, hi: int, n_frames: int, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """Videos [lo, hi) of the full-size C3 corpus (base_v + 0.1 * noise_f), generated ON the device from a
+    per-video seed — 4096 x 32 frames would be 79 GB of host fp32 — so any partition of the corpus (one sweep, 8 rank
+    blocks, 8 real ranks) regenerates identical inputs.  torch's Philox stream: stable for a given torch build, which is
+    why the committed digests are keyed by torch.__version__."""
+    out = torch.empty((hi - lo, n_frames, 3, 224, 224), device=device, dtype=dtype)
+    for i, v in enumerate(range(lo, hi)):
+        gen = torch.Generator(device=device)
+        gen.manual_seed(100000 + v)
+        base = torch.randn((1, 3, 224, 224), device=device, generator=gen)
+        out[i] = (base + 0.1 * torch.randn((n_frames, 3, 224, 224), device=device, generator=gen)).to(dtype)
+    return out
+
+
+def c3_device_names(V: int) -> list:
+    """Unique file names whose string order is not the corpus order (the tie rule of evaluate.py:58-60 sorts by name)."""
+    assert V <= 10007
+    return [f"video_{(v * 7919) % 10007:05d}.mp4" for v in range(V)]

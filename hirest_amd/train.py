@@ -81,7 +81,7 @@ class _K:
     def layouts(a, lda, a_kmajor, w, ldw, w_kmajor, M, N, K, resid=None, stream=None):
         lib = _lib.load()
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-        ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_layouts_workspace_bytes(M, N, K), 0 if stream is None else 1)
+        ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_layouts_workspace_bytes(M, N, K), 0 if stream is None else 1, stream)
         _chk(lib.hirest_gemm_f32_layouts(a.data_ptr(), lda, int(a_kmajor), w.data_ptr(), ldw, int(w_kmajor), None,
                                          resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
                                          out.data_ptr(), N, M, N, K, 0, ws, wsb, ops.stream_ptr() if stream is None else stream),
@@ -225,6 +225,22 @@ class _K:
 def _f32(t):
     t = t.detach()
     return t if t.dtype is torch.float32 and t.is_contiguous() else t.float().contiguous()
+
+
+def _alias_versions(params):       # params: iterable of (name, parameter)
+    """The forward keeps fp32-contiguous parameters by ALIAS (no copy: 63 M parameters per step), and the backward multiplies by
+    them again (dX = dY W).  autograd's saved-tensor version check does not see tensors kept in a side dict, so the versions are
+    recorded here and compared in the backward: an in-place update between a loss's forward and its backward (optimizer.step()
+    between two losses' backwards, an EMA or clipping hook) would silently back-propagate through the updated weights."""
+    return [(n, p, p._version) for n, p in params if p.dtype is torch.float32 and p.is_contiguous()]
+
+
+def _check_alias_versions(saved):
+    for n, p, v in saved:
+        if p._version != v:
+            raise RuntimeError(f"hirest_amd: parameter {n!r} was modified in place between this loss's forward and its backward "
+                               "(the training kernels keep fp32 parameters by reference); call backward() before optimizer.step() "
+                               "or recompute the loss")
 
 
 def _scale_by_upstream(dl: torch.Tensor, gloss) -> None:
@@ -485,7 +501,7 @@ class MomentLoss(torch.autograd.Function):
             for h_i, tgt in enumerate((st, et)):
                 _chk(lib.hirest_bce_masked_f32(logits[h_i].data_ptr(), tgt.data_ptr(), mm32.data_ptr(), B, T, 0.5, loss.data_ptr(),
                                                dl[h_i].data_ptr(), ops.stream_ptr()), "bce_masked")
-        S.update(feats=feats, logits=logits, st=st, et=et, P=P, names=names, model=model)
+        S.update(feats=feats, logits=logits, st=st, et=et, P=P, names=names, model=model, versions=_alias_versions(zip(names, params)))
         ctx.S = S
         ctx.set_materialize_grads(False)
         return loss.reshape(())
@@ -497,6 +513,7 @@ class MomentLoss(torch.autograd.Function):
         if S is None:
             raise RuntimeError("hirest_amd: this loss was already back-propagated (the kernels' saved activations are released after "
                                "the first backward; retain_graph is not supported)")
+        _check_alias_versions(S["versions"])
         lib = _lib.load()
         P, names, model = S["P"], S["names"], S["model"]
         B, T = S["B"], S["T"]
@@ -614,7 +631,7 @@ class CaptionLoss(torch.autograd.Function):
              "ce_rows")
         del dlog
         S.update(enc=enc, L=L, ids32=ids32, e0=e0, dl=dl_layers, xlast=x, tpre=tpre, tg=tg, tnorm=tnorm, Wp=Wp, logits=logits, tgt32=tgt32,
-                 n_tok=n_valid, V=V, Vp=Vp, P=P, names=names, model=model)
+                 n_tok=n_valid, V=V, Vp=Vp, P=P, names=names, model=model, versions=_alias_versions(zip(names, params)))
         ctx.S = S
         ctx.set_materialize_grads(False)
         return loss.reshape(())
@@ -626,6 +643,7 @@ class CaptionLoss(torch.autograd.Function):
         if S is None:
             raise RuntimeError("hirest_amd: this loss was already back-propagated (the kernels' saved activations are released after "
                                "the first backward; retain_graph is not supported)")
+        _check_alias_versions(S["versions"])
         lib = _lib.load()
         P, names, model = S["P"], S["names"], S["model"]
         B, F, L, drop, seed = S["B"], S["T"], S["L"], S["drop"], S["seed"]

@@ -1,13 +1,14 @@
 """CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
 
 Plain-Python restatement of the moment-task metrics of the reference's ``evaluate.py`` (paths relative to
-/root/reference): ``compute_iou`` (:24-31), ``evaluate_moment_retrieval`` (:83-121), ``compute_step_bound_scores``
+/root/reference): ``compute_iou`` (:24-31), ``evaluate_video_retrieval`` (:33-81), ``evaluate_moment_retrieval`` (:83-121), ``compute_step_bound_scores``
 (:123-188), ``NMS`` (:322-356) and ``preprocess_moment_bounds`` (:358-412).  Category maps are passed in instead of
 read from module globals (the reference sets PROMPT_TO_CAT / VIDEOS_TO_CAT in ``__main__``, :444-466).
 
 PARITY PIN: ``tests/test_evaluation.py`` checks every function against ``tests/golden/moment_eval.json``, produced by
 importing and running the real ``evaluate.py`` functions on the same seeded inputs (``tests/golden/make_golden.py
-moment_eval``).
+moment_eval``); ``evaluate_video_retrieval`` against ``tests/golden/retrieval_run.json`` — the real function's result on
+the JSON the real ``inference_video_retrieval.py`` wrote (``make_golden.py retrieval_run``) — in ``tests/test_run_corpus.py``.
 """
 from __future__ import annotations
 
@@ -24,6 +25,34 @@ def compute_iou(interval_1, interval_2) -> float:
 
 def _categories(cat_map: Dict[str, str]) -> List[str]:
     return sorted(set(cat_map.values())) + ["all"]
+
+
+def evaluate_video_retrieval(gt: dict, pred: dict, prompt_to_cat: Dict[str, str], ks=(1, 5, 10, 50)) -> dict:
+    """evaluate.py:33-81: per prompt, sorted(zip(scores, videos)) reversed (score descending, ties by name descending);
+    a prompt counts for R@k when any of its ground-truth videos is among the first k."""
+    cats = _categories(prompt_to_cat)
+    count = {c: {f"{k}": 0 for k in ks} for c in cats}
+    total = {c: 0 for c in cats}
+    for prompt in gt:
+        prompt_cat = prompt_to_cat[prompt]
+        gt_videos = list(gt[prompt].keys()) if isinstance(gt[prompt], dict) else list(gt[prompt])
+        total["all"] += 1
+        total[prompt_cat] += 1
+        scores, videos = zip(*sorted(zip(pred[prompt]["scores"], pred[prompt]["videos"])))
+        videos = videos[::-1]
+        for k in ks:
+            for v in videos[:k]:
+                if v in gt_videos:
+                    count["all"][f"{k}"] += 1
+                    count[prompt_cat][f"{k}"] += 1
+                    break
+    results = {}
+    for c in cats:
+        if total[c] > 0:
+            results[c] = {"total_prompt_count": total[c]}
+            for k in ks:
+                results[c][f"R@{k}"] = (count[c][f"{k}"] / total[c]) * 100
+    return results
 
 
 def evaluate_moment_retrieval(gt: dict, pred: dict, prompt_to_cat: Dict[str, str]) -> dict:

@@ -253,6 +253,28 @@ def similarity(text_n: torch.Tensor, video_n: torch.Tensor) -> torch.Tensor:
     return text_n @ video_n.t()
 
 
+def retrieval_run(text_embeds: torch.Tensor, features: Sequence[torch.Tensor], n_model_frames: int) -> torch.Tensor:
+    """The feature-file branch of the retrieval driver, loop for loop (inference_video_retrieval.py:207-212, 298-334):
+    text rows L2-normalised; every video's [T, E] file subsampled with linspace when n_model_frames > 0 (:311-317), cast to
+    float (:319), mean over rows with keepdim (:323), L2 (:326); scores = T @ V.T (:334)."""
+    t = text_embeds.float()
+    t = t / t.norm(dim=-1, keepdim=True)
+    rows = []
+    for video_embeds in features:
+        if n_model_frames > 0:
+            n_frames = video_embeds.shape[0]
+            frame_ids = torch.from_numpy(np.linspace(0, n_frames - 1, n_model_frames).astype(int))
+            video_embeds = video_embeds[frame_ids]
+        video_embeds = video_embeds.float().mean(dim=0, keepdim=True)
+        rows.append(video_embeds / video_embeds.norm(dim=-1, keepdim=True))
+    return torch.matmul(t, torch.cat(rows, dim=0).T)
+
+
+def retrieval_output(prompts: Sequence[str], video_ids: Sequence[str], scores: torch.Tensor) -> dict:
+    """inference_video_retrieval.py:337-346: every prompt lists ALL video ids (corpus order) and its score row."""
+    return {p: {"videos": list(video_ids), "scores": scores[i].tolist()} for i, p in enumerate(prompts)}
+
+
 def rank_videos(scores_row: Sequence[float], names: Sequence[str]) -> List[str]:
     """evaluate.py:58-60: sorted(zip(scores, videos)) reversed -> descending score, ties broken
     by video NAME descending (hazard H5)."""

@@ -217,6 +217,77 @@ def gen_eval():
 
 
 
+VR_FRAMES, VR_SEED = 8, 11       # gen_retrieval_run: --n_model_frames, seed of the tiny EVA-CLIP text tower
+
+
+def gen_retrieval_run():
+    """BASELINE configs[2] through the REAL driver: runs /root/reference/inference_video_retrieval.py itself (its
+    ``__main__`` block via runpy, feature-file branch :290-355) over the real test split + distractors (546 prompts, 4282
+    videos, data/splits/*.json) with one synthetic [T_v, 64] feature file per video (synth.retrieval_feature_corpus) and
+    ``--n_model_frames 8``, then the REAL evaluate.evaluate_video_retrieval (evaluate.py:33-81) on the JSON the script wrote,
+    with the category globals its ``__main__`` reads from data/evaluation/categories.json (:444-462).  The only stand-in is
+    the checkpoint: ``build_eva_model_and_transforms`` hands the script the reference's own EVA_CLIP class at the tiny test
+    config with synthetic weights instead of the 1 B-parameter g/14 + eva_clip_psz14.pt.  Nothing is written under
+    /root/reference: the script runs from a temporary working directory."""
+    import hashlib
+    import runpy
+    import eva_clip as ref_eva_clip
+    import eva_model
+    sys.path.insert(0, REF)
+    import evaluate as ref_eval
+    gt = json.load(open(f"{REF}/data/splits/all_data_test.json"))
+    neg = json.load(open(f"{REF}/data/splits/all_data_test_negative_samples.json"))
+    video_ids = [v for p in gt for v in gt[p]] + [v for p in neg for v in neg[p]]
+    cfg = synth.EVA_CLIP_TINY
+    work = tempfile.mkdtemp(prefix="hirest_vr_")
+    feat_dir = os.path.join(work, "feats")
+    os.makedirs(feat_dir)
+    for vid, f in zip(video_ids, synth.retrieval_feature_corpus(len(video_ids), cfg["embed_dim"])):
+        torch.save(f.clone(), os.path.join(feat_dir, f"{vid}.pt"))
+
+    def tiny_builder(model_name, pretrained="", **kw):
+        assert model_name == "EVA_CLIP_g_14", model_name
+        torch.manual_seed(0)
+        m = eva_model.EVA_CLIP(**cfg)
+        print(m.load_state_dict(synth.eva_clip_state_dict(cfg, VR_SEED), strict=True))
+        return m.float(), None
+    real_builder = ref_eva_clip.build_eva_model_and_transforms
+    ref_eva_clip.build_eva_model_and_transforms = tiny_builder
+    argv, cwd = sys.argv, os.getcwd()
+    try:
+        os.chdir(work)
+        sys.argv = ["inference_video_retrieval.py", "--data_dir", f"{REF}/data/splits", "--video_feature_dir", feat_dir,
+                    "--device", "cpu", "--video_retrieval_model", "clip_g", "--n_model_frames", str(VR_FRAMES),
+                    "--eval_batch_size", "10", "--run_name", "golden"]
+        runpy.run_path(f"{REF}/inference_video_retrieval.py", run_name="__main__")
+        pred = json.load(open(os.path.join(work, "VR_results", "golden.json")))
+    finally:
+        os.chdir(cwd)
+        sys.argv = argv
+        ref_eva_clip.build_eva_model_and_transforms = real_builder
+    prompts = list(gt.keys())
+    assert list(pred.keys()) == prompts and all(pred[p]["videos"] == video_ids for p in prompts)
+    cats = json.load(open(f"{REF}/data/evaluation/categories.json"))
+    ref_eval.PROMPT_TO_CAT = cats["prompt_to_cat"]
+    ref_eval.PROMPT_CATEGORIES = list(set(cats["prompt_to_cat"].values()) | set(cats["video_to_cat"].values())) + ["all"]
+    recall = ref_eval.evaluate_video_retrieval(gt, pred)
+    scores = np.array([pred[p]["scores"] for p in prompts], dtype=np.float32)
+    assert all(float(np.float32(x)) == x for x in pred[prompts[0]]["scores"])           # the JSON holds fp32 values exactly
+    top10 = []
+    for p in prompts:
+        sc, nm = zip(*sorted(zip(pred[p]["scores"], video_ids)))                          # evaluate.py:58-60
+        top10.append(list(nm[::-1][:10]))
+    index = {v: i for i, v in enumerate(video_ids)}
+    save("retrieval_run.npz", n_model_frames=VR_FRAMES, seed=VR_SEED, scores_head=scores[:24],
+         top10=np.array([[index[v] for v in row] for row in top10], dtype=np.int32),
+         top11_scores=np.sort(scores, axis=1)[:, ::-1][:, :11].copy(),
+         scores_sha256=np.frombuffer(hashlib.sha256(scores.tobytes()).digest(), dtype=np.uint8))
+    with open(os.path.join(HERE, "retrieval_run.json"), "w") as f:
+        json.dump({"video_ids": video_ids, "gt": {p: list(gt[p].keys()) for p in prompts},
+                   "prompt_to_cat": {p: cats["prompt_to_cat"][p] for p in prompts}, "recall": recall}, f)
+    print("wrote retrieval_run.{npz,json}", recall["all"])
+
+
 C3_V, C3_F = 256, 4         # sub-corpus of the matched-R@k check (SURVEY 8d: 256 videos x 4 frames = 1024 frames on the real reference)
 
 
@@ -711,6 +782,7 @@ def main():
         "openai_tiny": lambda: gen_openai("openai_tiny", synth.OPENAI_VIT_TINY, 21, 3, 4),
         "tokenizer": lambda: gen_tokenizer(prompts),
         "eval": gen_eval,
+        "retrieval_run": gen_retrieval_run,
         "openai_b32": lambda: gen_openai("openai_b32", synth.OPENAI_VIT_B32, 1, 64, 16, prompts=prompts),
         "eva_g14": lambda: gen_eva("eva_g14", synth.EVA_CLIP_G_14, 3, 2, 8),
         "c3": lambda: gen_c3(prompts),

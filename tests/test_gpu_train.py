@@ -295,3 +295,21 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_backward(de
                         assert torch.equal(got[n], want[n]), (b["tasks"][0], n, rep)
     finally:
         train.SIDE_STREAM_DW = True
+
+
+def test_backward_refuses_parameters_updated_in_place_after_the_forward(dev, golden_dir):
+    """The forward keeps fp32 parameters by reference and the backward multiplies by them again: forward A, forward B, backward A,
+    optimizer.step(), backward B would back-propagate B through the updated weights.  The version counters recorded in the forward
+    make that a loud error instead (autograd's own check does not see tensors kept outside save_for_backward)."""
+    model, batch, seg_batch, _, _ = _setup(golden_dir, "a", dev)
+    model.train()
+    optim = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    la, lb = model.train_step(batch)["loss"], model.train_step(seg_batch)["loss"]
+    la.backward()
+    optim.step()
+    with pytest.raises(RuntimeError, match="modified in place"):
+        lb.backward()
+    for p in model.parameters():
+        p.grad = None
+    model.train_step(seg_batch)["loss"].backward()          # a fresh forward after the update is fine
+    assert any(p.grad is not None for p in model.parameters())

@@ -1,68 +1,125 @@
 #!/usr/bin/env python3
-"""BASELINE configs[2] at full size on ONE GPU: V = 4096 videos x 32 frames (131 072 frames) of the SURVEY 8d corpus
-(video v's frames = base_v + 0.1 * noise_f), 546 real-prompt queries, EVA-CLIP-g/14 with synthetic weights.
+"""BASELINE configs[2] at full size, on N ranks: V = 4096 videos x 32 frames (131 072 frames) of the SURVEY 8d corpus
+(video v's frames = base_v + 0.1 * noise_f, generated on the device per video), 546 real-prompt queries, EVA-CLIP-g/14
+with synthetic weights, through ``hirest_amd.retrieval.run_corpus``: every rank encodes its ``shard_range`` block, ONE
+``all_gather_into_tensor`` (RCCL over xGMI) of the pooled rows, scoring + top-10 replicated, rank 0 reports.
 
-Pass 1 encodes the corpus in one sweep; pass 2 re-encodes it as 8 rank-sized blocks (shard_range of the 8-GPU run, each
-block encoded separately and concatenated in rank order = what the all-gather assembles) and checks that pooled rows,
-scores and top-10 lists are bit-identical — the 1-GPU == 8-GPU self-consistency of SURVEY 8d without an 8-GPU node.
-Prints one JSON object (throughput, invariance verdict, score statistics)."""
-import argparse, json, os, sys, time
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import hirest_amd  # noqa: E402
-from hirest_amd import retrieval, synth  # noqa: E402
+    python tools/c3_run.py                      # 1 GPU, 4096 x 32 (about 70 s)
+    python tools/c3_run.py --gpus 8             # the 8-GPU run: starts its 8 ranks itself (hirest_amd.launch), one per GPU
+    python tools/c3_run.py --videos 512         # the size tests/golden/c3_rank_blocks.json holds a 1-rank digest for
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--videos", type=int, default=4096)
-ap.add_argument("--frames", type=int, default=32)
-ap.add_argument("--ranks", type=int, default=8)
-ap.add_argument("--block", type=int, default=32, help="videos per encode call (32 x 32 = one 1024-frame tower call)")
-a = ap.parse_args()
-dev = torch.device("cuda:0")
-model = hirest_amd.EVA_CLIP(**synth.EVA_CLIP_G_14).to(dev).eval()
-model.init_random_(seed=1234)
-model.visual.max_frames_per_call = 1024
-prompts = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "test_prompts.json")))
-tokens = hirest_amd.tokenize(prompts).to(dev)
-texts = retrieval.encode_texts(model, tokens)
+The report (one JSON object on rank 0) holds frames/s, the SHA-256 of the gathered [V, 1024] rows and of the top-10 table,
+and — when ``tests/golden/c3_rank_blocks.json`` has a digest for this (V, F, torch build) — ``"equals_committed_1rank_digest"``:
+the 1-GPU ranks == N-GPU ranks check of SURVEY 8d, bit for bit.  With ``--rank-blocks R`` (1 rank only) the corpus is also
+re-encoded as R rank-sized blocks in this process and compared with the single sweep (the same invariance without an N-GPU
+node)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from hirest_amd import launch  # noqa: E402
 
 
-def video_block(lo, hi):
-    """frames of videos [lo, hi): seeded per video, so any partition of the corpus regenerates identical inputs"""
-    out = torch.empty((hi - lo, a.frames, 3, 224, 224), device=dev, dtype=torch.bfloat16)
-    for i, v in enumerate(range(lo, hi)):
-        g = torch.Generator(device=dev); g.manual_seed(100000 + v)
-        base = torch.randn((1, 3, 224, 224), device=dev, generator=g)
-        out[i] = (base + 0.1 * torch.randn((a.frames, 3, 224, 224), device=dev, generator=g)).to(torch.bfloat16)
-    return out
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--videos", type=int, default=4096)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--block", type=int, default=32, help="videos per encode call (32 x 32 = one 1024-frame tower call)")
+    ap.add_argument("--rank-blocks", type=int, default=0, help="1 rank only: also encode the corpus as this many rank blocks")
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--out", default=None, help="also write the report to this path")
+    a = ap.parse_args()
+    import torch
+    launch.ensure_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:], visible_devices=torch.cuda.device_count())
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    rank, _, world = launch.init_ranks(a.gpus, "nccl", dev)
+    import torch.distributed as dist
+    import hirest_amd
+    from hirest_amd import retrieval, synth
+    model = hirest_amd.EVA_CLIP(**synth.EVA_CLIP_G_14).to(dev).eval()
+    model.init_random_(seed=1234)
+    model.set_precision(a.precision)
+    prompts = json.load(open(os.path.join(REPO, "tests", "golden", "test_prompts.json")))
+    ids = synth.c3_device_names(a.videos)
+    src = retrieval.FrameSource(ids, lambda lo, hi: synth.c3_device_block(lo, hi, a.frames, dev), videos_per_call=a.block)
+    gather = retrieval.RowGather()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    sync()
+    t0 = time.perf_counter()
+    res = retrieval.run_corpus(model, src, prompts, a.frames, gather=gather)
+    val, idx = res.topk(10)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # every rank must hold the same gathered matrix and the same ranking
+        mine = torch.tensor([int(x, 16) % (1 << 62) for x in (retrieval.corpus_digest(res.video_rows, idx)["pooled_sha256"][:15],
+                                                               retrieval.corpus_digest(res.video_rows, idx)["top10_sha256"][:15])],
+                            dtype=torch.int64, device=dev)
+        all_d = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(all_d, mine)
+        ranks_agree = all(torch.equal(d, all_d[0]) for d in all_d)
+    else:
+        ranks_agree = True
+    report = None
+    if rank == 0:
+        digest = retrieval.corpus_digest(res.video_rows, idx)
+        key = f"V{a.videos}_F{a.frames}_torch{torch.__version__}"
+        known_path = os.path.join(REPO, "tests", "golden", "c3_rank_blocks.json")
+        known = json.load(open(known_path)) if os.path.isfile(known_path) else {}
+        top2 = res.scores.topk(2, dim=1).values
+        report = {
+            "workload": f"{a.videos} videos x {a.frames} frames, {len(prompts)} queries, EVA-CLIP-g/14 {a.precision}, {world} rank(s)",
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "frames": a.videos * a.frames, "seconds_incl_input_generation": elapsed,
+            "frames_per_s_incl_input_generation": a.videos * a.frames / elapsed,
+            "all_ranks_hold_the_same_rows_and_ranking": bool(ranks_agree),
+            "digest_key": key, **digest,
+            "equals_committed_1rank_digest": (known[key] == digest) if (key in known and a.precision == "bf16") else None,
+            "pooled_row_norm_min_max": [res.video_rows.norm(dim=1).min().item(), res.video_rows.norm(dim=1).max().item()],
+            "score_min_max": [res.scores.min().item(), res.scores.max().item()],
+            "median_top1_margin": (top2[:, 0] - top2[:, 1]).median().item(),
+            "result_dict": {"prompts": len(res), "videos_per_prompt": len(res[prompts[0]]["videos"]),
+                            "layout": "inference_video_retrieval.py:337-346"},
+            "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    if a.rank_blocks > 1 and world == 1:
+        t1 = time.perf_counter()
+        parts = [retrieval.corpus_block_rows(model, src, r, a.rank_blocks, a.frames) for r in range(a.rank_blocks)]
+        rows = torch.cat(parts)
+        again = retrieval.score_corpus(res.text_rows, rows, ids, prompts)
+        _, idx2 = again.topk(10)
+        torch.cuda.synchronize(dev)
+        report.update({"rank_blocks": a.rank_blocks, "seconds_rank_blocks": time.perf_counter() - t1,
+                       "pooled_rows_bit_identical": bool(torch.equal(rows, res.video_rows)),
+                       "scores_bit_identical": bool(torch.equal(again.scores, res.scores)),
+                       "top10_identical": bool(torch.equal(idx2, idx))})
+    if rank == 0:
+        print(json.dumps(report), flush=True)
+        if a.out:
+            os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+            with open(a.out, "w") as f:
+                json.dump(report, f, indent=1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and (not ranks_agree or report.get("equals_committed_1rank_digest") is False
+                      or report.get("pooled_rows_bit_identical") is False or report.get("top10_identical") is False):
+        raise SystemExit(1)
 
 
-def encode_range(lo, hi):
-    rows = []
-    for s in range(lo, hi, a.block):
-        rows.append(retrieval.encode_videos(model, video_block(s, min(hi, s + a.block))))
-    return torch.cat(rows) if rows else torch.empty((0, texts.shape[1]), device=dev)
-
-
-torch.cuda.synchronize(); t0 = time.perf_counter()
-pooled = encode_range(0, a.videos)
-torch.cuda.synchronize(); t1 = time.perf_counter()
-scores, val, idx = retrieval.retrieve(texts, pooled, 10)
-parts = []
-for r in range(a.ranks):
-    lo, hi, per = retrieval.shard_range(a.videos, r, a.ranks)
-    parts.append(encode_range(lo, hi))
-sharded = torch.cat(parts)
-scores2, val2, idx2 = retrieval.retrieve(texts, sharded, 10)
-torch.cuda.synchronize(); t2 = time.perf_counter()
-top2 = scores.topk(2, dim=1).values
-print(json.dumps({
-    "workload": f"{a.videos} videos x {a.frames} frames, {len(prompts)} queries, EVA-CLIP-g/14 bf16, 1 GPU",
-    "frames": a.videos * a.frames, "seconds_single_sweep_incl_input_generation": t1 - t0,
-    "frames_per_s_incl_input_generation": a.videos * a.frames / (t1 - t0),
-    "rank_blocks": a.ranks, "pooled_rows_bit_identical": bool(torch.equal(pooled, sharded)),
-    "scores_bit_identical": bool(torch.equal(scores, scores2)), "top10_identical": bool(torch.equal(idx, idx2)),
-    "pooled_row_norm_min_max": [pooled.norm(dim=1).min().item(), pooled.norm(dim=1).max().item()],
-    "score_min_max": [scores.min().item(), scores.max().item()],
-    "median_top1_margin": (top2[:, 0] - top2[:, 1]).median().item(),
-    "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9}))
+if __name__ == "__main__":
+    main()
