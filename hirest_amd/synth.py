@@ -396,6 +396,9 @@ def joint_inputs(name, B, T, seed):
 
 
 TRAIN_CASES = {"a": (3, 64), "b": (2, 300)}
+# step-captioning goldens (tests/golden/caption_predictions.json): case -> (B, T, beams, moment lengths)
+CAPTION_CASES = {"a": (3, 64, 3, [7, 20, 37]), "b": (2, 300, 5, [7, 20]),
+                 "c3": (5, 300, 3, [15] * 5), "c5": (5, 300, 5, [15] * 5)}
 
 
 def train_targets(name, B, T, seed, bounds):

@@ -517,10 +517,11 @@ def gen_caption():
     sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
     print(model.load_state_dict(sd, strict=False))
     out = {}
-    for case, (B, T, beams) in {"a": (3, 64, 3), "b": (2, 300, 5)}.items():
+    # a / b: moments shorter than, equal to and longer than max_frames (20): all three trim branches.  c3 / c5: BASELINE
+    # configs[4] at its own operating point: B = 5, 15-frame moments -> 20 trimmed frames, beam 3 and beam 5,
+    # 48 words at most.
+    for case, (B, T, beams, lens) in synth.CAPTION_CASES.items():
         vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"cap.{case}", B, T, 47)
-        # moments of different lengths: shorter than, equal to and longer than max_frames (20): all three trim branches
-        lens = [7, 20, 37][:B]
         moment_mask = torch.zeros(B, T, dtype=torch.long)
         for b in range(B):
             moment_mask[b, 5 + b:5 + b + lens[b]] = 1

@@ -61,6 +61,8 @@ def test_bench_line_contract():
             assert e["cpu_baseline"]["kind"] == "port" and e["cpu_baseline"]["value"] > 0 and e["cpu_baseline"]["cores"] >= 1, key
     assert sec["moment_retrieval"]["indices_equal_cpu_oracle"] and sec["moment_segmentation"]["boundaries_equal_cpu_oracle"]
     assert sec["step_captioning_beam5"]["token_ids_equal_cpu_oracle_on_sample"]
+    for beams in (3, 5):           # all five captions of the timed batch equal the REAL reference's (caption_predictions.json c3 / c5)
+        assert sec[f"step_captioning_beam{beams}"]["token_ids_equal_real_reference"] == "5 of 5 captions"
     assert sec["moment_retrieval"]["value"] > 38 and sec["moment_segmentation"]["value"] > 8 and sec["step_captioning_beam3"]["value"] > 48
 
 

@@ -200,7 +200,7 @@ def test_moment_model_vs_reference(dev, golden_dir, case):
         model.test_step({"tasks": ["something_else"]})
 
 
-@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("case", ["a", "b", "c3", "c5"])    # c3 / c5: BASELINE configs[4]'s own operating point (B = 5, beam 3 / 5)
 def test_step_captioning_vs_reference(dev, golden_dir, case):
     """BASELINE configs[4] in miniature: trim_feats + encoder + beam-searched decoder; token ids exact vs the
     REAL reference MomentModel.test_step (tests/golden/caption_predictions.json)."""

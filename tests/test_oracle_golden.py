@@ -162,7 +162,7 @@ def test_joint_model_matches_reference(golden_dir, case):
     assert seg == pred["pred_segmentation"]                        # boundary lists: exact
 
 
-@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("case", ["a", "b", pytest.param("c3", marks=pytest.mark.slow), pytest.param("c5", marks=pytest.mark.slow)])
 def test_step_captioning_matches_reference(golden_dir, case):
     """trim_feats + fusion/encoder on 20 frames + 2-layer decoder + beam search vs the real MomentModel
     (token ids exact; the reference's tokenizer is stubbed to print ids)."""
