@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
 TOWER_NO_LNFOLD = 1
 TOWER_NO_PRUNE = 2
 GEMM_REVERSE = 1
+GEMM_X3 = 2
 ABI_VERSION = 3   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
 
 ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}
@@ -72,6 +73,14 @@ class VisionTowerF32(C.Structure):     # hirest_vision_tower_f32: the same field
 
 class TextTowerF32(C.Structure):
     _fields_ = [(n, t) if n != "blocks" else (n, C.POINTER(BlockWeightsF32)) for n, t in TextTower._fields_]
+
+
+class BlockWeightsX3(C.Structure):    # hirest_block_weights_x3: split (hi | lo) bf16 weights [out, 2 * in]
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w2", "proj_w2", "fc1_w2", "fc2_w2")]
+
+
+class VisionTowerX3(C.Structure):
+    _fields_ = [("base", C.POINTER(VisionTowerF32)), ("blocks", C.POINTER(BlockWeightsX3))]
 
 
 class CaptionLayer(C.Structure):
@@ -240,6 +249,13 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "hirest_vision_guard_offset": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),
     "hirest_vision_workspace_bytes_f32": (C.c_size_t, [C.POINTER(VisionTowerF32), C.c_int32]),
+    "hirest_vision_embed_f32": (C.c_int, [C.POINTER(VisionTowerF32), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hirest_split2_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_layernorm_split2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int32,
+                                          C.c_int32, C.c_void_p]),
+    "hirest_vision_workspace_bytes_x3": (C.c_size_t, [C.POINTER(VisionTowerX3), C.c_int32]),
+    "hirest_vision_forward_x3": (C.c_int, [C.POINTER(VisionTowerX3), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p]),
     "hirest_vision_forward_f32": (C.c_int, [C.POINTER(VisionTowerF32), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "hirest_text_workspace_bytes_f32": (C.c_size_t, [C.POINTER(TextTowerF32), C.c_int32]),

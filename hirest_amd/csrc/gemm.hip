@@ -992,8 +992,13 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
 //        of either group comes after a barrier at which the other group had already passed that lgkmcnt(0).
 // Registers: one A sub-block (8 fragments) + both W sub-blocks (2 x 4): 64 VGPRs — nothing is prefetched across phases.
 // =================================================================================================
-template <int EPI, int RD = 1>
-__global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
+// X3 ("bf16x3", reference-rank precision at 3/16 of the fp32-MFMA cost): both operands are fp32 values split into bf16 hi + lo
+// parts, stored interleaved along K in blocks of 64 = [hi of 32 consecutive k | lo of the same 32 k] (hirest_split2_bf16), so one
+// 64-deep step of the ring holds hi and lo of BOTH operands for 32 real k, and a phase issues three MFMA groups on the fragments
+// it has already read — W_hi A_lo, W_lo A_hi, W_hi A_hi (small terms first; W_lo A_lo, 2^-16 of the product, is dropped) —
+// instead of two: 1.5 x the matrix work per LDS byte of the plain kernel, nothing else changes (same ring, barriers, epilogues).
+template <int EPI, int RD, bool X3>
+__device__ __forceinline__ void pp256_body(const GemmP& p) {
     constexpr int NI = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1118,13 +1123,24 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
     f32x4 acc[8][NI];
     auto mfma_q = [&](int a, int b, FW& fw) {
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (X3) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int g3 = 0; g3 < 3; ++g3)                       // (W half, A half): (hi, lo), (lo, hi), (hi, hi)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.v[n][h], Af.v[m][h], acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n)
+                        acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.v[n][g3 == 1 ? 1 : 0], Af.v[m][g3 == 0 ? 1 : 0],
+                                                                                             acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.v[n][h], Af.v[m][h], acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
@@ -1218,10 +1234,15 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) {
 }
 
 template <int EPI, int RD = 1>
+__global__ __launch_bounds__(512) void gemm_pp256(GemmP p) { pp256_body<EPI, RD, false>(p); }
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp256x3(GemmP p) { pp256_body<EPI, 1, true>(p); }
+
+template <int EPI, int RD = 1, bool X3 = false>
 int launch_pp256(GemmP p, hipStream_t s) {
     static HirestDevCfg cfg;
     int cus = 0;
-    auto kern = gemm_pp256<EPI, RD>;
+    auto kern = [] { if constexpr (X3) return gemm_pp256x3<EPI>; else return gemm_pp256<EPI, RD>; }();
     constexpr int LDS = 2 * Q_STEP + 8 * p_stg_bytes(EPI);
     if (int e = hirest_configure(kern, LDS, cfg, &cus)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
@@ -1357,6 +1378,11 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (!a || a->struct_size != sizeof(hirest_gemm_args) || !out || out_len < 48) return HIREST_E_BADARG;
     const int epi = a->epilogue, f = g_force_kernel;
     if (epi < 0 || epi > HIREST_EPI_LNFOLD_GELU_BF16) return HIREST_E_BADARG;
+    if (a->flags & HIREST_GEMM_X3) {
+        if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32) return HIREST_E_BADARG;
+        snprintf(out, out_len, "gemm_pp256x3<%d>", epi);
+        return 0;
+    }
     const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
     const bool w4_ok = epi != HIREST_EPI_BIAS_QGELU_BF16 && epi != HIREST_EPI_PATCH_POS_F32;
@@ -1400,6 +1426,13 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.ppx = (p.nbm + 7) / 8;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HirestProfScope prof(HIREST_PROF_GEMM, a->epilogue, a->M, a->N, a->K, s);
+    if (a->flags & HIREST_GEMM_X3) {                  // split-operand products: the ping-pong kernel's X3 form, fp32 outputs only
+        switch (a->epilogue) {
+            case HIREST_EPI_BIAS_F32: return launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);
+            case HIREST_EPI_BIAS_RESID_F32: return launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true>(p, s);
+            default: return HIREST_E_BADARG;
+        }
+    }
     switch (a->epilogue) {
         case HIREST_EPI_BIAS_BF16: return launch<HIREST_EPI_BIAS_BF16>(p, s);
         case HIREST_EPI_BIAS_GELU_BF16: return launch<HIREST_EPI_BIAS_GELU_BF16>(p, s);

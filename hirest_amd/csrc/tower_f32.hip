@@ -92,6 +92,35 @@ extern "C" size_t hirest_vision_workspace_bytes_f32(const hirest_vision_tower_f3
     return plan_f32((int64_t)B * T, t->width, wide_of(t->width, t->mlp_dim, t->kpad), B).total;
 }
 
+// Front end of the fp32 (and bf16x3) vision towers: x[b*T + 0] = cls + pos[0], x[b*T + 1 + p] = conv(patch p) + bias + pos[1 + p], then
+// ln_pre when the tower has one (vit_model.py:198-205,330-333; model.py:229-238).  `rows` is scratch of [B*T, kpad] floats.
+extern "C" int hirest_vision_embed_f32(const hirest_vision_tower_f32* t, const void* frames, int32_t in_dtype, int32_t B, float* x,
+                                       float* rows, void* stream) {
+    if (!t || !frames || !x || !rows || B <= 0) return HIREST_E_BADARG;
+    if (t->image_size % t->patch != 0 || t->kpad % 16 != 0 || t->kpad < 3 * t->patch * t->patch) return HIREST_E_SHAPE;
+    if (in_dtype < 0 || in_dtype > 2 || (in_dtype == 2 && (!t->image_mean || !t->image_std))) return HIREST_E_BADARG;
+    const int G = t->image_size / t->patch, T = G * G + 1, D = t->width;
+    const int64_t M = (int64_t)B * T;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // patch embedding: rows b*T + 1 + p = conv(patch p) + bias + pos[1 + p]; the zero row b*T is then overwritten by cls + pos[0]
+    {
+        const int64_t total = M * (t->kpad / 4);
+        int64_t blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
+        dim3 grid((unsigned)blocks), block(256);
+        switch (in_dtype) {
+            case 0: hipLaunchKernelGGL(patch_rows_f32_kernel<0>, grid, block, 0, s, frames, B, t->image_size, t->patch, t->image_mean, t->image_std, rows, t->kpad); break;
+            case 1: hipLaunchKernelGGL(patch_rows_f32_kernel<1>, grid, block, 0, s, frames, B, t->image_size, t->patch, t->image_mean, t->image_std, rows, t->kpad); break;
+            default: hipLaunchKernelGGL(patch_rows_f32_kernel<2>, grid, block, 0, s, frames, B, t->image_size, t->patch, t->image_mean, t->image_std, rows, t->kpad); break;
+        }
+        if (int e = hirest_launch_status()) return e;
+    }
+    CHECK(hirest_gemm_f32(rows, t->kpad, t->patch_w, t->kpad, t->patch_b, nullptr, 0, t->pos, T, x, D, (int)M, D, t->kpad, 0, stream));
+    CHECK(hirest_write_cls_rows(x, D, t->cls, t->pos, B, T, D, stream));
+    if (t->ln_pre_g)
+        CHECK(hirest_layernorm(x, D, nullptr, t->ln_pre_g, t->ln_pre_b, t->ln_eps, x, D, 1, (int)M, D, stream));
+    return 0;
+}
+
 extern "C" int hirest_vision_forward_f32(const hirest_vision_tower_f32* t, const void* frames, int32_t in_dtype, int32_t B, float* out,
                                          void* workspace, size_t workspace_bytes, void* stream) {
     if (!t || !frames || !out || !workspace || B <= 0 || !t->blocks) return HIREST_E_BADARG;
@@ -106,24 +135,7 @@ extern "C" int hirest_vision_forward_f32(const hirest_vision_tower_f32* t, const
     float* x = reinterpret_cast<float*>(ws + r.x);
     float* h = reinterpret_cast<float*>(ws + r.h);
     float* big = reinterpret_cast<float*>(ws + r.big);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-
-    // patch embedding: rows b*T + 1 + p = conv(patch p) + bias + pos[1 + p]; the zero row b*T is then overwritten by cls + pos[0]
-    {
-        const int64_t total = M * (t->kpad / 4);
-        int64_t blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
-        dim3 grid((unsigned)blocks), block(256);
-        switch (in_dtype) {
-            case 0: hipLaunchKernelGGL(patch_rows_f32_kernel<0>, grid, block, 0, s, frames, B, t->image_size, t->patch, t->image_mean, t->image_std, big, t->kpad); break;
-            case 1: hipLaunchKernelGGL(patch_rows_f32_kernel<1>, grid, block, 0, s, frames, B, t->image_size, t->patch, t->image_mean, t->image_std, big, t->kpad); break;
-            default: hipLaunchKernelGGL(patch_rows_f32_kernel<2>, grid, block, 0, s, frames, B, t->image_size, t->patch, t->image_mean, t->image_std, big, t->kpad); break;
-        }
-        if (int e = hirest_launch_status()) return e;
-    }
-    CHECK(hirest_gemm_f32(big, t->kpad, t->patch_w, t->kpad, t->patch_b, nullptr, 0, t->pos, T, x, D, (int)M, D, t->kpad, 0, stream));
-    CHECK(hirest_write_cls_rows(x, D, t->cls, t->pos, B, T, D, stream));
-    if (t->ln_pre_g)
-        CHECK(hirest_layernorm(x, D, nullptr, t->ln_pre_g, t->ln_pre_b, t->ln_eps, x, D, 1, (int)M, D, stream));
+    CHECK(hirest_vision_embed_f32(t, frames, in_dtype, B, x, big, stream));
     for (int l = 0; l < t->layers; ++l)
         CHECK(run_block_f32(t->blocks[l], x, h, big, B, T, D, t->heads, t->head_dim, t->mlp_dim, t->ln_eps, t->act, 0, stream));
     if (t->out_all_tokens) {

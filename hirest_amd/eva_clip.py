@@ -150,6 +150,7 @@ class VisionTower(_Tower):
         self.image_mean, self.image_std = OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
         self.max_frames_per_call = 1024  # micro-batch per tower call (workspace ~5.4 GB at 1024 frames)
         self.max_frames_per_call_f32 = 256   # fp32 towers: 35.8 KB of activations per token -> 2.4 GB at 256 frames
+        self.max_frames_per_call_x3 = 1024   # bf16x3: 66 KB per token -> 17.4 GB at 1024 frames (the persistent GEMMs want large M)
         self.fold_layernorm = True       # tower calls of >= 64 frames fold both LayerNorms of a block into its GEMMs
         self.fold_guard_ratio = 4.0      # a call whose worst token row sits > 4 sigma off zero is redone with LayerNorm passes
         self.last_fold_ratio = 0.0       # (None: never check).  Largest |mean| / sigma seen by the last forward()
@@ -244,6 +245,41 @@ class VisionTower(_Tower):
         self._prepared = {"device": device, "desc": desc, "blocks": blocks, "keep": keep, "f32": True}
         return self._prepared
 
+    def _prepare_x3(self, device):
+        """bf16x3: the fp32 descriptor plus, per block, the four linear weights split into bf16 hi | lo halves (ops.split2), once."""
+        prep = self._prepare_f32(device)
+        if "x3" in prep:
+            return prep
+        blocks = (_lib.BlockWeightsX3 * self.layers)()
+        keep = prep["keep"]
+
+        def split(w):
+            t = ops.split2(w.detach().float().contiguous())
+            keep.append(t)
+            return t.data_ptr()
+        for i, b in enumerate(self.blocks):
+            blocks[i] = _lib.BlockWeightsX3(split(b.attn.qkv.weight), split(b.attn.proj.weight), split(b.mlp.fc1.weight), split(b.mlp.fc2.weight))
+        prep["x3_blocks"] = blocks
+        prep["x3"] = _lib.VisionTowerX3(C.pointer(prep["desc"]), blocks)
+        return prep
+
+    def _forward_x3(self, image: torch.Tensor) -> torch.Tensor:
+        prep = self._prepare_x3(image.device)
+        lib = _lib.load()
+        B = image.shape[0]
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=image.device)
+        if B == 0:
+            return out
+        calls = -(-B // max(1, int(self.max_frames_per_call_x3)))
+        step = -(-B // calls)
+        ws = self._ws(lib.hirest_vision_workspace_bytes_x3(C.byref(prep["x3"]), step), image.device)
+        code = ops._IN_DTYPES[image.dtype]
+        for s in range(0, B, step):
+            n = min(step, B - s)
+            _lib.check(lib.hirest_vision_forward_x3(C.byref(prep["x3"]), image[s:s + n].data_ptr(), code, n, out[s:s + n].data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), ops.stream_ptr()), "hirest_vision_forward_x3")
+        return out
+
     def _forward_f32(self, image: torch.Tensor) -> torch.Tensor:
         prep = self._prepare_f32(image.device)
         lib = _lib.load()
@@ -276,6 +312,8 @@ class VisionTower(_Tower):
         image = image.contiguous()
         if self.precision == "fp32":
             return self._forward_f32(image)
+        if self.precision == "bf16x3":
+            return self._forward_x3(image)
         prep = self._prepare(image.device)
         lib = _lib.load()
         B = image.shape[0]
@@ -439,10 +477,13 @@ class EVA_CLIP(nn.Module):
         self.output_dtype = torch.float32
 
     def set_precision(self, precision: str):
-        """'fp32' = the reference's own arithmetic (exact-fp32 kernels, eva_clip.py:90 default); 'bf16' = the bf16 MFMA towers."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
-        self.visual.precision = self.text.precision = precision
+        """'fp32' = the reference's own arithmetic (exact-fp32 kernels, eva_clip.py:90 default); 'bf16' = the bf16 MFMA towers;
+        'bf16x3' = the fp32 forward with the vision tower's weight GEMMs on bf16 hi + lo splits of both operands (csrc/tower_x3.hip:
+        ~16-bit products at 3/16 of the fp32 matrix cost; the text tower, 2 % of a retrieval run's work, stays exact fp32)."""
+        if precision not in TOWER_PRECISIONS:
+            raise ValueError(f"precision must be one of {TOWER_PRECISIONS}, got {precision!r}")
+        self.visual.precision = precision
+        self.text.precision = "fp32" if precision == "bf16x3" else precision
         return self
 
     @torch.no_grad()

@@ -169,6 +169,33 @@ def to_bf16(t: torch.Tensor) -> torch.Tensor:
 
 
 @on_tensor_device
+def split2(x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
+    """[rows, D] fp32 -> [rows, 2D] bf16 in the bf16x3 operand format (hirest_split2_bf16): every 64-column block holds the bf16 hi
+    parts of 32 consecutive columns, then their lo parts (lo = bf16(x - hi)).  D % 32 == 0."""
+    lib = _lib.load()
+    rows, D = x.shape
+    out = torch.empty((rows, 2 * D), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.hirest_split2_bf16(_dev(x, torch.float32, "split2.in"), D, out.data_ptr(), 2 * D, rows, D, int(bool(gelu)), stream_ptr()),
+               "hirest_split2_bf16")
+    return out
+
+
+@on_tensor_device
+def gemm_x3(a2: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = None, resid_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [M, N] = A W^T (+ bias) from split operands a2 [M, 2K], w2 [N, 2K] (ops.split2): HIREST_GEMM_X3.  With `resid_out` (fp32 [M, N])
+    the product is added into it (x += ...)."""
+    lib = _lib.load()
+    M, K2 = a2.shape
+    N = w2.shape[0]
+    out = resid_out if resid_out is not None else torch.empty((M, N), dtype=torch.float32, device=a2.device)
+    args = _lib.GemmArgs.make(_dev(a2, torch.bfloat16, "gemm_x3.a"), K2, _dev(w2, torch.bfloat16, "gemm_x3.w"), K2,
+                              _opt(bias, torch.float32, "gemm_x3.bias"), out.data_ptr(), N, M, N, K2,
+                              _lib.EPI_BIAS_RESID_F32 if resid_out is not None else _lib.EPI_BIAS_F32, None, 0, None, None, _lib.GEMM_X3)
+    _lib.check(lib.hirest_gemm_bf16(C.byref(args), stream_ptr()), "hirest_gemm_bf16 (x3)")
+    return out
+
+
+@on_tensor_device
 def pool_l2norm(frame_embeds: torch.Tensor, normalize_frames_first: bool = False) -> torch.Tensor:
     """[V,F,E] f32 -> [V,E]: mean over frames then L2 (inference_video_retrieval.py:283-285)."""
     lib = _lib.load()

@@ -91,7 +91,11 @@ typedef struct hirest_gemm_args {
                                              last ~256 MB in the Infinity Cache (the tower runs fc2 backwards: it reads fc1's
                                              output, and the next qkv reads fc2's) */
 } hirest_gemm_args;
-enum { HIREST_GEMM_REVERSE = 1 };
+enum { HIREST_GEMM_REVERSE = 1,
+       HIREST_GEMM_X3 = 2 };   /* "bf16x3": A and W are fp32 matrices split by hirest_split2_bf16 ([rows, 2K] bf16, each block of 64 columns
+                                * = hi parts of 32 consecutive k | their lo parts), K = 2 x the real depth; the kernel adds W_hi A_lo + W_lo A_hi
+                                * + W_hi A_hi per 32 k in fp32 (products carry ~16 mantissa bits at 3 bf16 MFMAs each).  Epilogues
+                                * HIREST_EPI_BIAS_F32 / HIREST_EPI_BIAS_RESID_F32 only; always the persistent ping-pong kernel. */
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
 /* Kernel selection for tests / A-B timing: 0 = automatic (default), 1 = force the 128x128 kernel,
@@ -330,9 +334,42 @@ typedef struct hirest_text_tower_f32 {
 size_t hirest_vision_workspace_bytes_f32(const hirest_vision_tower_f32* t, int32_t B);
 int hirest_vision_forward_f32(const hirest_vision_tower_f32* t, const void* frames, int32_t in_dtype, int32_t B, float* out,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* Front end of hirest_vision_forward_f32 alone: patch embedding (+ bias + position rows), CLS rows, ln_pre when present, into the fp32
+ * residual stream x [B*T, width].  `rows`: scratch of B*T*kpad floats (the im2col rows). */
+int hirest_vision_embed_f32(const hirest_vision_tower_f32* t, const void* frames, int32_t in_dtype, int32_t B, float* x, float* rows,
+                            void* stream);
 size_t hirest_text_workspace_bytes_f32(const hirest_text_tower_f32* t, int32_t B);
 int hirest_text_forward_f32(const hirest_text_tower_f32* t, const int64_t* tokens, int32_t B, float* out,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * "bf16x3" vision tower (precision='bf16x3'): the fp32 forward above with the four weight GEMMs of every block computed from bf16
+ * hi + lo splits of both fp32 operands (HIREST_GEMM_X3: w_hi a_lo + w_lo a_hi + w_hi a_hi, fp32 accumulation) — ~16-bit products at
+ * 3 bf16 MFMAs each, i.e. 3/16 of the exact-fp32 matrix cost; LayerNorm, attention, GELU, the residual stream, patch embedding and
+ * head stay fp32 (tower_f32's kernels).  Meant to reproduce the fp32 reference's retrieval RANKS (EVA_clip/eva_clip.py:90) at
+ * several times the exact-fp32 tower's throughput.  EVA towers only (GELU, no ln_pre, CLS head); width, mlp_dim % 32 == 0.
+ *   hirest_split2_bf16        [rows, D] fp32 -> [rows, 2D] bf16 in the X3 operand format (each 64-column block: hi of 32 k | lo of
+ *                             the same k); act 1 applies nn.GELU()'s erf form in fp32 first.  Also splits the weights (once).
+ *   hirest_layernorm_split2   LayerNorm over the last dim (hirest_layernorm's arithmetic) stored in that format.
+ * ------------------------------------------------------------------------------------ */
+typedef struct hirest_block_weights_x3 {
+    const hirest_bf16* qkv_w2;  /* [3*width, 2*width]   split of hirest_block_weights_f32.qkv_w  */
+    const hirest_bf16* proj_w2; /* [width,   2*width]  */
+    const hirest_bf16* fc1_w2;  /* [mlp_dim, 2*width]  */
+    const hirest_bf16* fc2_w2;  /* [width,   2*mlp_dim] */
+} hirest_block_weights_x3;
+
+typedef struct hirest_vision_tower_x3 {
+    const hirest_vision_tower_f32* base;       /* dimensions, fp32 patch / cls / pos / LayerNorm / bias / head parameters (HOST struct) */
+    const hirest_block_weights_x3* blocks;     /* HOST array [layers] */
+} hirest_vision_tower_x3;
+
+int hirest_split2_bf16(const float* x, int64_t ldx, hirest_bf16* out, int64_t ldo, int64_t rows, int32_t D, int32_t act, void* stream);
+int hirest_layernorm_split2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, hirest_bf16* out, int64_t ldo,
+                            int32_t rows, int32_t D, void* stream);
+size_t hirest_vision_workspace_bytes_x3(const hirest_vision_tower_x3* t, int32_t B);
+int hirest_vision_forward_x3(const hirest_vision_tower_x3* t, const void* frames, int32_t in_dtype, int32_t B, float* out,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Joint model (MomentModel) path — fp32 end to end, because its outputs are frame INDICES

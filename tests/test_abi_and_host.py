@@ -203,7 +203,10 @@ def test_profiled_kernels_are_the_dispatched_ones(lib):
     dispatched = {name(*p) for p in problems}
     assert {"gemm_p256<7, 64, false, 1>", "gemm_p256<6, 64, false, 1>", "gemm_p256<8, 64, false, 1>", "gemm_pp256<6, 1>"} <= dispatched
     rounds = sorted(d for d in os.listdir(os.path.join(REPO, "profiles")) if re.fullmatch(r"r\d\d", d))
-    newest = os.path.join(REPO, "profiles", rounds[-1])
+    # the newest round that holds a traffic profile (a round's directory exists from its first committed measurement on; its
+    # counters are collected on the final build)
+    with_traffic = [r for r in rounds if os.path.isfile(os.path.join(REPO, "profiles", r, "pmc_traffic.json"))]
+    newest = os.path.join(REPO, "profiles", with_traffic[-1])
     src = open(os.path.join(REPO, "bench.py")).read()
     assert f'"{rounds[-1]}"' in src.split("PROFILE_ROUNDS")[1].split("\n")[0]      # bench.py reads the newest round first
     prof = json.load(open(os.path.join(newest, "pmc_traffic.json")))
