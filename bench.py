@@ -61,7 +61,7 @@ def matched_recall(model, dev):
     V, F, seed = int(g["V"]), int(g["F"]), int(g["seed"])
     saved = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.load_state_dict(synth.eva_clip_state_dict(synth.EVA_CLIP_G_14, seed), strict=True)
-    fp32 = None
+    fp32 = x3 = None
     try:
         frames = synth.c3_corpus(V, F).to(dev)
         names = synth.c3_names(V)
@@ -90,6 +90,42 @@ def matched_recall(model, dev):
                 "max_abs_score_error": (scores32.cpu() - torch.from_numpy(g["scores"])).abs().max().item(),
                 "pooled_min_cosine_vs_reference": torch.nn.functional.cosine_similarity(
                     pooled32.cpu(), torch.from_numpy(g["pooled"]), dim=-1).min().item()}
+        # precision='bf16x3' (csrc/tower_x3.hip): the fp32 forward with the weight GEMMs on bf16 hi + lo splits of both operands — the
+        # reference-rank operating point that is not 10x slower.  Its own roofline line: three bf16 MFMAs per product, so the
+        # matrix-pipe peak for ALGORITHMIC flops is 2500 / 3 TFLOP/s.
+        from hirest_amd import _lib as _l
+        lib = _l.load()
+        model.set_precision("bf16x3")
+        retrieval.encode_videos(model, frames[:16])                   # warm-up: weight split (once), workspace
+        torch.cuda.synchronize()
+        lib.hirest_profile_enable(1)
+        t0 = time.perf_counter()
+        pooled3 = retrieval.encode_videos(model, frames)
+        torch.cuda.synchronize(); dt3 = time.perf_counter() - t0
+        recs = (_l.ProfRecord * 4096)()
+        nrec = lib.hirest_profile_collect(recs, len(recs))
+        lib.hirest_profile_enable(0)
+        fc = [recs[i] for i in range(max(nrec, 0)) if recs[i].kind == 0 and recs[i].d1 == _DM]      # fc1: N = 6144, K = 2 x 1408
+        scores3, _, idx3 = retrieval.retrieve(texts32, pooled3, 10, tie)          # (text tower: exact fp32 in this mode)
+        idx3 = idx3.cpu().long()
+        x3 = {"frames_per_s": V * F / dt3, "frames": V * F,
+              "dtype": "bf16 hi + lo splits of fp32 operands, 3 MFMAs per product, fp32 accumulation; fp32 LayerNorm / attention / GELU",
+              **{f"matched_R@{k}": 100.0 * (idx3[:, :k] == gt_[:, None]).any(dim=1).float().mean().item() for k in (1, 5, 10)},
+              "top1_flips": int((idx3[:, 0] != gt_).sum()),
+              "top10_lists_identical": int((idx3 == torch.from_numpy(g["top10"].astype(np.int64))).all(dim=1).sum()),
+              "max_abs_score_error": (scores3.cpu() - torch.from_numpy(g["scores"])).abs().max().item(),
+              "pooled_min_cosine_vs_reference": torch.nn.functional.cosine_similarity(
+                  pooled3.cpu(), torch.from_numpy(g["pooled"]), dim=-1).min().item(),
+              "whole_tower_tflops": V * F / dt3 * GFLOP_PER_FRAME / 1e3,
+              "whole_tower_frac_of_peak_over_3": V * F / dt3 * GFLOP_PER_FRAME / 1e3 / (MFMA_BF16_PEAK_TFLOPS / 3)}
+        if fc:
+            ms = sum(r.ms for r in fc) / len(fc)
+            tf = 2.0 * fc[0].d0 * fc[0].d1 * (fc[0].d2 // 2) / (ms * 1e-3) / 1e12
+            x3["roofline"] = {"bound": "mfma", "kernel": f"gemm_pp256x3<bias->f32> fc1 M={fc[0].d0} N={fc[0].d1} K={fc[0].d2 // 2} (x2 split columns)",
+                              "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS / 3, "unit": "TFLOP/s", "frac": tf / (MFMA_BF16_PEAK_TFLOPS / 3),
+                              "avg_launch_ms": ms, "launches": len(fc),
+                              "note": "algorithmic flops (2 M N K) over the kernel's live hipEvent time; peak = dense bf16 MFMA peak / 3 "
+                                      "because every product costs three bf16 MFMAs"}
     finally:
         model.set_precision("bf16")
         model.load_state_dict(saved, strict=True)
@@ -110,7 +146,7 @@ def matched_recall(model, dev):
                     pooled.cpu(), torch.from_numpy(g["pooled"]), dim=-1).min().item(),
                 "ground_truth": "top-1 of the real reference EVA_CLIP (fp32, CPU) on the same corpus / prompts / synthetic "
                                 "weights: tests/golden/eva_g14_c3.npz",
-                "precision_fp32": fp32})
+                "precision_fp32": fp32, "precision_bf16x3": x3})
     return res
 
 
@@ -200,6 +236,8 @@ def main():
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 force t128, 2 force t256 (A/B timing)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: run the LayerNorm passes instead of folding them into the GEMMs")
     ap.add_argument("--no-prune", action="store_true", help="A/B: run the last block on every token (results identical)")
+    ap.add_argument("--no-profile", action="store_true", help="A/B: no per-launch hipEvent pairs inside the timed region (the line then "
+                    "carries no roofline; profiles/r04/README.md holds the comparison)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the joint-model / captioning / training / ASR figures")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="hirest_gemm_debug_mode bits: TIMING EXPERIMENTS ONLY, the line is not a valid result")
     args = ap.parse_args()
@@ -250,7 +288,7 @@ def main():
         return idx
 
     elapsed, idx = launch.timed_steps(step, args.warmup, args.steps, torch.cuda.synchronize,
-                                      on_timed_start=lambda: lib.hirest_profile_enable(1), reduce_device=dev)
+                                      on_timed_start=(None if args.no_profile else (lambda: lib.hirest_profile_enable(1))), reduce_device=dev)
     # per-launch records of the timed steps (this rank)
     recs = (_lib.ProfRecord * 200000)()
     nrec = lib.hirest_profile_collect(recs, len(recs))
@@ -305,6 +343,7 @@ def main():
                    6: "bias+residual+ln-stats", 7: "ln-fold+bias", 8: "ln-fold+bias+gelu"}
             roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_missing": traffic is None,      # loud: no committed profile matches the kernels this run dispatched
                         "traffic_note": "bytes per launch through the L2's memory side (Infinity-Cache hits included), from the "
                                         "newest committed profiles/rNN/pmc_traffic.json (rocprofv3 PMC passes of this same "
                                         "command; tests/test_abi_and_host.py checks its kernel names against the current "
@@ -329,6 +368,8 @@ def main():
                           "frames_per_gpu_per_step": args.frames, "global_batch": args.frames * world,
                           "micro_batch": args.chunk, "parallelism": f"dp{world}"},
                "roofline": roofline}
+        if args.no_profile:
+            out["profile"] = "off (--no-profile: no per-launch event pairs in the timed region, hence no roofline in this line)"
         if args.gemm_dbg & ~512:                       # bit 9 only switches the kernels' walk direction off (A/B), results unchanged
             out["INVALID"] = f"timing experiment: hirest_gemm_debug_mode({args.gemm_dbg})"
 

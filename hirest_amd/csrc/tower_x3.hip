@@ -12,6 +12,7 @@
 // Workspace (B frames, M = B*T tokens): x f32 [M, D] residual stream, h f32 [M, D] attention output, big f32 [M, max(3D, Dm, kpad)]
 // qkv / pre-activation / patch rows, a2 bf16 [M, 2D] split operand of qkv / proj / fc1, b2 bf16 [M, 2Dm] split operand of fc2.
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -175,18 +176,25 @@ extern "C" int hirest_vision_forward_x3(const hirest_vision_tower_x3* t, const v
     // patch embedding + cls + pos: tower_f32.hip's own front end (exact fp32; 0.08 % of the tower's products)
     CHECK(hirest_vision_embed_f32(f, frames, in_dtype, B, x, big, stream));
     const float scale = 1.0f / sqrtf((float)f->head_dim);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     for (int l = 0; l < f->layers; ++l) {
         const hirest_block_weights_f32& w = f->blocks[l];
         const hirest_block_weights_x3& w2 = t->blocks[l];
-        CHECK(hirest_layernorm_split2(x, D, w.ln1_g, w.ln1_b, f->ln_eps, a2, 2 * D, M, D, stream));
+        // (profile records of the non-GEMM kernels: kind LAYERNORM tags 10 LayerNorm + split, 11 split, 12 GELU + split; kind ATTENTION tag 2)
+        { HirestProfScope pr(HIREST_PROF_LAYERNORM, 10, M, D, 0, s);
+          CHECK(hirest_layernorm_split2(x, D, w.ln1_g, w.ln1_b, f->ln_eps, a2, 2 * D, M, D, stream)); }
         CHECK(gemm_x3(a2, 2 * D, w2.qkv_w2, 2 * D, w.qkv_b, big, 3 * D, M, 3 * D, D, HIREST_EPI_BIAS_F32, stream));
-        CHECK(hirest_attention_f32_qkv(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, h, B, T, T, f->heads, f->head_dim, scale, 0.f,
-                                       0.f, stream));
-        CHECK(hirest_split2_bf16(h, D, a2, 2 * D, M, D, 0, stream));
+        { HirestProfScope pr(HIREST_PROF_ATTENTION, 2, (int64_t)B * f->heads, T, f->head_dim, s);
+          CHECK(hirest_attention_f32_qkv(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, h, B, T, T, f->heads, f->head_dim, scale, 0.f,
+                                         0.f, stream)); }
+        { HirestProfScope pr(HIREST_PROF_LAYERNORM, 11, M, D, 0, s);
+          CHECK(hirest_split2_bf16(h, D, a2, 2 * D, M, D, 0, stream)); }
         CHECK(gemm_x3(a2, 2 * D, w2.proj_w2, 2 * D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_F32, stream));
-        CHECK(hirest_layernorm_split2(x, D, w.ln2_g, w.ln2_b, f->ln_eps, a2, 2 * D, M, D, stream));
+        { HirestProfScope pr(HIREST_PROF_LAYERNORM, 10, M, D, 0, s);
+          CHECK(hirest_layernorm_split2(x, D, w.ln2_g, w.ln2_b, f->ln_eps, a2, 2 * D, M, D, stream)); }
         CHECK(gemm_x3(a2, 2 * D, w2.fc1_w2, 2 * D, w.fc1_b, big, Dm, M, Dm, D, HIREST_EPI_BIAS_F32, stream));
-        CHECK(hirest_split2_bf16(big, Dm, b2, 2 * Dm, M, Dm, 1, stream));
+        { HirestProfScope pr(HIREST_PROF_LAYERNORM, 12, M, Dm, 0, s);
+          CHECK(hirest_split2_bf16(big, Dm, b2, 2 * Dm, M, Dm, 1, stream)); }
         CHECK(gemm_x3(b2, 2 * Dm, w2.fc2_w2, 2 * Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_F32, stream));
     }
     CHECK(hirest_layernorm(x, (int64_t)T * D, nullptr, f->norm_g, f->norm_b, f->ln_eps, h, D, 1, B, D, stream));
