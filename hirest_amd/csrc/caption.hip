@@ -200,12 +200,14 @@ __global__ __launch_bounds__(256) void tail_scan_kernel(const float* __restrict_
 
 // one block per sample: scores of its beam x nsel x beam candidates, their top `beam`, then beam_advance_kernel's bookkeeping
 __global__ __launch_bounds__(256) void tail_select_kernel(const float* __restrict__ cx, const int32_t* __restrict__ ci,
-                                                         const float* __restrict__ stat, const float* __restrict__ row_add, int nsel,
+                                                         const float* __restrict__ stat, const float* row_add, int nsel,
                                                          int beam, int vocab, int step, int max_steps, int eos, float* __restrict__ scores,
                                                          int32_t* __restrict__ tokens, int32_t* __restrict__ backptr,
                                                          int32_t* __restrict__ n_steps, int32_t* __restrict__ done,
                                                          int32_t* __restrict__ next_ids, int32_t* __restrict__ next_parents,
-                                                         float* __restrict__ next_add, int32_t* __restrict__ done_host) {
+                                                         float* next_add, int32_t* __restrict__ done_host) {
+    // row_add and next_add MAY ALIAS (hirest_caption_beam_step passes one buffer: this step's running scores in, the next step's
+    // out), hence no __restrict__ on either; every read of row_add happens before the block's first store to next_add.
     __shared__ float top_s[16];
     __shared__ int top_i[16];
     __shared__ float row_mx[16], row_lse[16], row_ad[16];
@@ -325,7 +327,9 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const float eps = 1e-12f, scale = 0.125f;            // BertLayerNorm eps; 1 / sqrt(64)
 
-    const bool fused_ln = g_caption_mode == 0 && R <= 32 && D % 256 == 0 && D <= 1024;
+    // (the LM head's LayerNorm-prologue form exists as the streaming kernel for D = 768 only: hirest_gemm_f32_ln rejects N >= 8192
+    //  with another depth, so such a decoder takes the separate-kernel path instead of failing the step)
+    const bool fused_ln = g_caption_mode == 0 && R <= 32 && D % 256 == 0 && D <= 1024 && (d->vocab_padded < 8192 || D == 768);
     if (fused_ln) {
         // every LayerNorm (and the token + position embedding) is the prologue of the GEMM that consumes it (hirest_gemm_f32_ln):
         // a = the pre-LayerNorm sum of the previous sub-layer, x / b = the normalised rows (written by the GEMM, residual of the next)

@@ -562,14 +562,14 @@ class MomentModel(nn.Module):
             add0[:, 0] = 0.0                                                   # (beam.py:78)
             init = self._beam_init[key] = (
                 torch.cat([torch.full((R,), BOS_ID, dtype=torch.int32), torch.arange(R, dtype=torch.int32)]).to(dev),
-                torch.cat([add0.reshape(-1), torch.zeros(R)]).to(dev),
-                torch.zeros((max_words, B), dtype=torch.int32).pin_memory())
+                torch.cat([add0.reshape(-1), torch.zeros(R)]).to(dev))
         ibuf[2 * nt + 2 * B:].copy_(init[0])
         fbuf = init[1].clone()                             # float32 = add | scores
         add, scores = fbuf[:R].view(B, num_beams), fbuf[R:]
-        # the stamped done flags of every step, pinned (the previous batch ended with a device synchronisation: nothing still writes here)
-        done_rows = init[2]
-        done_rows.zero_()
+        # the stamped done flags of every step, pinned, ONE TABLE PER CALL: a table cached per shape could still be written by kernels of
+        # an earlier call that left its loop by an exception, or by a concurrent call of the same shape on another stream
+        # (caption_batches), and a stale stamp would end this search early
+        done_rows = torch.zeros((max_words, B), dtype=torch.int32).pin_memory()
         done_host = [done_rows[t] for t in range(max_words)]
         fused_tail = bool(getattr(self, "caption_fused_tail", True)) and num_beams <= 16 and Vp <= 32768    # (the tail kernels' limits)
         copied = None if fused_tail else [torch.cuda.Event() for _ in range(max_words)]
@@ -662,6 +662,48 @@ class MomentModel(nn.Module):
             if not active:
                 break
         return self._caption_result(beams, return_ids)
+
+    @torch.no_grad()
+    def caption_batches(self, batches, num_beams=5, streams=3, return_ids=False):
+        """Step captioning over a LIST of loader batches (the evaluation loop of run.py:328-336 / modeling.py:556-632 calls
+        test_step once per batch) with up to `streams` batches in flight, each on its own HIP stream and host thread.
+
+        Why: one batch of 5 videos x 5 beams is 25 rows — a word step is ~20 dependent kernels of a few microseconds each, bound by
+        launch and memory latency, not by the 162 MB of weights it streams: the GPU is mostly idle.  Independent batches
+        fill those gaps; only the LM head (HBM-bound, all CUs) serialises.  Every call owns its buffers (workspace, K / V cache, beam
+        state, pinned done table), the weight cache is read-only, and every kernel is batch-invariant, so each batch's result is
+        exactly what ``test_step`` returns for it alone.  Returns the per-batch result dicts in order."""
+        import threading
+        batches = list(batches)
+        n = max(1, min(int(streams), len(batches)))
+        c = self._w()                                       # weight cache built (and the kernels' per-device setup done) before the threads
+        dev = c["dev"]
+        if n == 1 or len(batches) <= 1:
+            return [self.test_step_captioning(b, num_beams=num_beams, return_ids=return_ids) for b in batches]
+        results, errors = [None] * len(batches), []
+        results[0] = self.test_step_captioning(batches[0], num_beams=num_beams, return_ids=return_ids)   # warm: one-time kernel configuration
+        main = torch.cuda.current_stream(dev)
+        side = [torch.cuda.Stream(device=dev) for _ in range(n)]
+
+        def work(w):
+            try:
+                torch.cuda.set_device(dev)
+                side[w].wait_stream(main)
+                with torch.cuda.stream(side[w]):
+                    for i in range(1 + w, len(batches), n):
+                        results[i] = self.test_step_captioning(batches[i], num_beams=num_beams, return_ids=return_ids)
+            except BaseException as e:      # surfaced after the join
+                errors.append(e)
+        threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for st in side:
+            main.wait_stream(st)
+        if errors:
+            raise errors[0]
+        return results
 
     def _caption_result(self, beams, return_ids):
         hyps = [bm.best_hypothesis() for bm in beams]

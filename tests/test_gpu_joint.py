@@ -449,3 +449,36 @@ def test_clip_text_ids_path_equals_text_feat_path(dev, golden_dir):
     bare = bare.to(dev).eval()
     with pytest.raises(RuntimeError):
         bare.test_step(dict(batches["moment_retrieval"], tasks=["moment_retrieval"], clip_text_ids=ids))
+
+
+def test_caption_batches_with_three_in_flight_equal_sequential_calls(dev, golden_dir):
+    """MomentModel.caption_batches: loader batches captioned concurrently (one HIP stream + host thread each) give exactly the token
+    ids of one test_step call per batch — every call owns its buffers and every kernel is batch-invariant — including the batch the
+    real reference captioned (caption_predictions.json c5)."""
+    import hirest_amd
+    from hirest_amd.synth import joint_inputs, CAPTION_CASES
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, "joint_schema.json"))).items()}
+    sd = synth.joint_state_dict(shapes, 31)
+    sd["clip4cap_model.decoder.classifier.cls.predictions.bias"][102] += 1.5
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).eval()
+    B, T, beams, lens = CAPTION_CASES["c5"]
+    batches = []
+    for i in range(7):
+        vis, asr, text, vis_mask, _, _ = joint_inputs("cap.c5" if i == 0 else f"cap.pipe{i}", B, T, 47 + 3 * i)
+        mm = torch.zeros(B, T, dtype=torch.long)
+        for b in range(B):
+            n = lens[b] if i == 0 else 6 + ((5 * i + 3 * b) % 30)         # shorter than, equal to and longer than the 20 trimmed frames
+            mm[b, 5 + b:5 + b + n] = 1
+        batches.append({"tasks": ["step_captioning"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": mm, "asr_feats": asr,
+                        "text_feat": text})
+    want = [model.test_step(b, num_beams=beams, return_ids=True) for b in batches]
+    pred = json.load(open(os.path.join(golden_dir, "caption_predictions.json")))["c5"]
+    assert want[0]["prediction"] == pred["prediction"]
+    for streams in (3, 2, 8):
+        got = model.caption_batches(batches, num_beams=beams, streams=streams, return_ids=True)
+        assert [g["token_ids"] for g in got] == [w["token_ids"] for w in want], streams
+        assert [g["prediction"] for g in got] == [w["prediction"] for w in want]
+    assert model.caption_batches(batches[:1], num_beams=beams, streams=3, return_ids=True)[0]["token_ids"] == want[0]["token_ids"]
+    assert model.caption_batches([], num_beams=beams) == []
