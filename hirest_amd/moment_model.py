@@ -621,6 +621,122 @@ class MomentModel(nn.Module):
             beams[b].tokens = [[BOS_ID] * num_beams] + [tok_h[b][j] for j in range(n_h[b])]
         return self._caption_result(beams, return_ids)
 
+    # -------------------------------------------------------------------------------------------------------------------
+    # The same search replayed from hipGraphs (caption_batches): a word step is ~22 launches of ~3 us of host time each, and HIP
+    # serialises launches across host threads, so three batches in flight were HOST-bound (532 -> 766 captions/s instead of the ~2x
+    # the idle CUs allow).  Here all buffers of a search are static per (shape, slot), the word steps are captured once in chunks of
+    # CAPTION_GRAPH_CHUNK words, and a batch costs max_words / chunk graph launches.  Same kernels, same arguments, same tokens.
+    # -------------------------------------------------------------------------------------------------------------------
+    CAPTION_GRAPH_CHUNK = 8
+
+    def _caption_graph_ctx(self, B, num_beams, max_words, F, nl, slot):
+        from .beam import BOS_ID
+        c, lib = self._w(), _lib.load()
+        ctxs = c.setdefault("caption_graphs", {})           # lives and dies with the weight cache: the graphs hold its pointers
+        key = (B, num_beams, max_words, F, nl, slot)
+        ctx = ctxs.get(key)
+        if ctx is not None:
+            return ctx
+        dev, desc = c["dev"], c["dec_desc"]
+        R, Dm, Vp = B * num_beams, 768, desc.vocab_padded
+        nt = B * max_words * num_beams
+        add0 = torch.full((B, num_beams), -3.0e38, dtype=torch.float32)
+        add0[:, 0] = 0.0
+        ctx = {
+            "enc": [torch.empty((R, F, 2 * Dm), dtype=torch.float32, device=dev) for _ in range(nl)],
+            "ws": torch.empty(lib.hirest_caption_step_workspace_bytes(C.byref(desc), R), dtype=torch.uint8, device=dev),
+            "cache": [torch.empty((2 * nl, R, max_words, Dm), dtype=torch.float32, device=dev) for _ in range(2)],
+            "logp": torch.empty((R, Vp), dtype=torch.float32, device=dev),
+            "ibuf": torch.zeros((2 * nt + 2 * B + 2 * R,), dtype=torch.int32, device=dev),
+            "fbuf": torch.zeros((2 * R,), dtype=torch.float32, device=dev),
+            "ibuf0": torch.cat([torch.full((R,), BOS_ID, dtype=torch.int32), torch.arange(R, dtype=torch.int32)]).to(dev),
+            "fbuf0": torch.cat([add0.reshape(-1), torch.zeros(R)]).to(dev),
+            "tail_ws": torch.empty(max(int(lib.hirest_caption_beam_tail_workspace_bytes(B, num_beams, Vp)), 16), dtype=torch.uint8, device=dev),
+            "done_rows": torch.zeros((max_words, B), dtype=torch.int32).pin_memory(),
+            "graphs": [],
+        }
+        ctx["enc_ptrs"] = (C.c_void_p * nl)(*[e.data_ptr() for e in ctx["enc"]])
+        ctx["ptrs"] = [(C.c_void_p * (2 * nl))(*[cb[i].data_ptr() for i in range(2 * nl)]) for cb in ctx["cache"]]
+        ctxs[key] = ctx
+        return ctx
+
+    def _caption_issue_step(self, ctx, B, num_beams, max_words, F, t, st):
+        """One word (1-based t) of the search on the static buffers of `ctx`: hirest_caption_beam_step on stream pointer `st`."""
+        from .beam import EOS_ID
+        c, lib = self._w(), _lib.load()
+        R, nt = B * num_beams, B * max_words * num_beams
+        ibuf, fbuf = ctx["ibuf"], ctx["fbuf"]
+        tokens, backptr = ibuf[:nt], ibuf[nt:2 * nt]
+        n_steps, done = ibuf[2 * nt:2 * nt + B], ibuf[2 * nt + B:2 * nt + 2 * B]
+        ids, parents = ibuf[2 * nt + 2 * B:2 * nt + 2 * B + R], ibuf[2 * nt + 2 * B + R:]
+        add, scores = fbuf[:R], fbuf[R:]
+        _lib.check(lib.hirest_caption_beam_step(
+            C.byref(c["dec_desc"]), B, num_beams, t - 1, ids.data_ptr(), parents.data_ptr(), ctx["ptrs"][t & 1] if t > 1 else None,
+            ctx["ptrs"][(t + 1) & 1], ctx["enc_ptrs"], F, add.data_ptr(), ctx["logp"].data_ptr(), max_words, EOS_ID, scores.data_ptr(),
+            tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(), done.data_ptr(), ctx["done_rows"][t - 1].data_ptr(),
+            ctx["ws"].data_ptr(), ctx["ws"].numel(), ctx["tail_ws"].data_ptr(), ctx["tail_ws"].numel(), st), "hirest_caption_beam_step")
+
+    def _caption_capture(self, ctx, B, num_beams, max_words, F):
+        """Capture the word steps of one search shape into hipGraphs (once per context; call from ONE thread while no other thread
+        issues HIP work: stream capture is process-global)."""
+        if ctx["graphs"]:
+            return
+        ctx["ibuf"][2 * B * max_words * num_beams + 2 * B:].copy_(ctx["ibuf0"])
+        ctx["fbuf"].copy_(ctx["fbuf0"])
+        for e in ctx["enc"]:
+            e.zero_()
+        for t in range(1, min(3, max_words) + 1):          # eager warm-up on these buffers (one-time kernel configuration must not be captured)
+            self._caption_issue_step(ctx, B, num_beams, max_words, F, t, ops.stream_ptr())
+        torch.cuda.synchronize()
+        step = max(1, int(self.CAPTION_GRAPH_CHUNK))
+        for lo in range(1, max_words + 1, step):
+            hi = min(max_words, lo + step - 1)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st = ops.stream_ptr()
+                for t in range(lo, hi + 1):
+                    self._caption_issue_step(ctx, B, num_beams, max_words, F, t, st)
+            ctx["graphs"].append((lo, hi, g))
+        torch.cuda.synchronize()
+
+    def _beam_search_graph(self, beams, enc_kv_all, num_beams, max_words, return_ids, slot):
+        from .beam import BOS_ID
+        B, F = enc_kv_all[0].shape[0], enc_kv_all[0].shape[1]
+        nl = len(enc_kv_all)
+        ctx = self._caption_graph_ctx(B, num_beams, max_words, F, nl, slot)
+        if not ctx["graphs"]:
+            raise RuntimeError("hirest_amd: caption graphs are captured by caption_batches before its threads start")
+        R, nt = B * num_beams, B * max_words * num_beams
+        for e, kv in zip(ctx["enc"], enc_kv_all):
+            e.copy_(kv.repeat_interleave(num_beams, 0))
+        ctx["ibuf"].zero_()
+        ctx["ibuf"][2 * nt + 2 * B:].copy_(ctx["ibuf0"])
+        ctx["fbuf"].copy_(ctx["fbuf0"])
+        # (the previous search on this context ended with the blocking read-out below: nothing still writes the pinned table)
+        done_rows = ctx["done_rows"]
+        done_rows.zero_()
+        events = []
+        for k, (lo, hi, g) in enumerate(ctx["graphs"]):
+            # at most two chunks ahead of the GPU, so that a search whose samples have all emitted [SEP] stops within two chunks: the
+            # flags are those of the last word of chunk k - 2, which has completed (a finished sample's rows are inert meanwhile)
+            if k >= 2:
+                events[k - 2].synchronize()
+                last = ctx["graphs"][k - 2][1]
+                if all((v >> 1) == last and (v & 1) for v in done_rows[last - 1].tolist()):
+                    break
+            g.replay()
+            ev = torch.cuda.Event()
+            ev.record()
+            events.append(ev)
+        ih = ctx["ibuf"][:2 * nt + B].cpu()
+        tok_h, bp_h = ih[:nt].view(B, max_words, num_beams).tolist(), ih[nt:2 * nt].view(B, max_words, num_beams).tolist()
+        n_h, sc_h = ih[2 * nt:].tolist(), ctx["fbuf"][R:].view(B, -1).cpu().tolist()
+        for b in range(B):
+            beams[b].scores = sc_h[b]
+            beams[b].backptr = [bp_h[b][j] for j in range(n_h[b])]
+            beams[b].tokens = [[BOS_ID] * num_beams] + [tok_h[b][j] for j in range(n_h[b])]
+        return self._caption_result(beams, return_ids)
+
     @torch.no_grad()
     def test_step_captioning(self, batch, num_beams=5, return_ids=False, **kwargs):
         """modeling.py:556-632.  Returns {'prediction': [str]} (token strings joined like the reference; ids are
@@ -646,6 +762,10 @@ class MomentModel(nn.Module):
         beams = [BeamState(num_beams) for _ in range(B)]
         active = list(range(B))
         if bool(getattr(self, "caption_kv_cache", True)):
+            if kwargs.get("graph_slot") is not None:         # caption_batches: replay the captured word steps of this slot's context
+                ctx = self._caption_graph_ctx(B, num_beams, max_words, max_frames, len(enc_kv_all), kwargs["graph_slot"])
+                if ctx["graphs"]:                            # (a batch of another size, e.g. the loader's last one, runs eagerly)
+                    return self._beam_search_graph(beams, enc_kv_all, num_beams, max_words, return_ids, kwargs["graph_slot"])
             return self._beam_search_cached(beams, enc_kv_all, num_beams, max_words, return_ids)
         for t in range(1, max_words + 1):
             sel = torch.tensor([b for b in active for _ in range(num_beams)], dtype=torch.long, device=dev)
@@ -664,7 +784,7 @@ class MomentModel(nn.Module):
         return self._caption_result(beams, return_ids)
 
     @torch.no_grad()
-    def caption_batches(self, batches, num_beams=5, streams=3, return_ids=False):
+    def caption_batches(self, batches, num_beams=5, streams=3, return_ids=False, graphs=True):
         """Step captioning over a LIST of loader batches (the evaluation loop of run.py:328-336 / modeling.py:556-632 calls
         test_step once per batch) with up to `streams` batches in flight, each on its own HIP stream and host thread.
 
@@ -684,6 +804,19 @@ class MomentModel(nn.Module):
         results[0] = self.test_step_captioning(batches[0], num_beams=num_beams, return_ids=return_ids)   # warm: one-time kernel configuration
         main = torch.cuda.current_stream(dev)
         side = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        if graphs and bool(getattr(self, "caption_kv_cache", True)) and bool(getattr(self, "caption_fused_tail", True)) and num_beams <= 16:
+            # the word steps of this batch shape, captured once per slot (hipGraphs: a batch then costs max_words / 8 launches instead
+            # of ~22 per word — three host threads issuing ~3-us launches through HIP's one launch lock were the bottleneck)
+            max_frames = int(getattr(self.args, "max_frames_step_captioning", 20)) if self.args is not None else 20
+            max_words = int(getattr(self.args, "max_words", 48)) if self.args is not None else 48
+            B0 = batches[1]["vis_feats"].shape[0]
+            nl = len(self.clip4cap_model.decoder.decoder.layer)
+            with torch.cuda.device(dev):
+                for w in range(n):
+                    self._caption_capture(self._caption_graph_ctx(B0, num_beams, max_words, max_frames, nl, w), B0, num_beams, max_words, max_frames)
+            slot_of = lambda w: w
+        else:
+            slot_of = lambda w: None
 
         def work(w):
             try:
@@ -691,7 +824,7 @@ class MomentModel(nn.Module):
                 side[w].wait_stream(main)
                 with torch.cuda.stream(side[w]):
                     for i in range(1 + w, len(batches), n):
-                        results[i] = self.test_step_captioning(batches[i], num_beams=num_beams, return_ids=return_ids)
+                        results[i] = self.test_step_captioning(batches[i], num_beams=num_beams, return_ids=return_ids, graph_slot=slot_of(w))
             except BaseException as e:      # surfaced after the join
                 errors.append(e)
         threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(n)]
