@@ -784,7 +784,7 @@ class MomentModel(nn.Module):
         return self._caption_result(beams, return_ids)
 
     @torch.no_grad()
-    def caption_batches(self, batches, num_beams=5, streams=3, return_ids=False, graphs=True):
+    def caption_batches(self, batches, num_beams=5, streams=4, return_ids=False, graphs=True):
         """Step captioning over a LIST of loader batches (the evaluation loop of run.py:328-336 / modeling.py:556-632 calls
         test_step once per batch) with up to `streams` batches in flight, each on its own HIP stream and host thread.
 

@@ -154,7 +154,7 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         # the same batch as an evaluation loop sees it: several loader batches in flight (MomentModel.caption_batches, one HIP stream +
         # host thread each).  One batch alone is latency-bound (25 rows, ~20 dependent kernels per word); independent batches fill
         # the idle CUs and only the HBM-bound LM head serialises.  Same token ids per batch (tests/test_gpu_joint.py).
-        nb, ns = 9, 3
+        nb, ns = 12, 4
         many = [bcp] * nb
         model.caption_batches(many[:ns], num_beams=beams, streams=ns)                      # warm-up: streams, allocator pools
         sync(); t0 = time.perf_counter()
@@ -163,7 +163,7 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         gbs = bytes_per_word * 48 / dtp / 1e9
         out[f"step_captioning_beam{beams}_pipelined"] = {
             "value": B / dtp, "unit": "captions/s", "ms_per_batch": dtp * 1e3, "beam": beams, "max_words": 48, "batches": nb,
-            "batches_in_flight": ns, "how": "MomentModel.caption_batches: loader batches of 5 videos captioned concurrently on 3 HIP streams",
+            "batches_in_flight": ns, "how": "MomentModel.caption_batches: loader batches of 5 videos captioned concurrently on 4 HIP streams (word steps replayed from hipGraphs)",
             "token_ids_equal_real_reference": f"{sum(int(list(a) == b) for r_ in res for a, b in zip(r_['token_ids'], want))} of {nb * len(want)} captions",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_word_step": bytes_per_word,
