@@ -1318,7 +1318,6 @@ int launch256(GemmP p, hipStream_t s) {
 
 }  // namespace
 int g_gemm_dbg = 0;
-int hirest_launch_d2(int epi, const void* gemm_p, hipStream_t s, int flags);   // gemm_d2.hip
 namespace {
 
 int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
@@ -1331,7 +1330,6 @@ int launch_fused(const GemmP& p, hipStream_t s) {
     if (!big || !p.aux0 || !p.aux1) return !big ? HIREST_E_SHAPE : HIREST_E_BADARG;
     if (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
     GemmP q = p; q.dbg = 0;
-    if (g_force_kernel >= 18) return hirest_launch_d2(EPI, &q, s, g_force_kernel - 18);
     if (p.K >= 4096 && g_force_kernel != 6) return launch_pp256<EPI>(q, s);
     return launch_p256_impl<EPI, 64, false>(q, s);
 }
@@ -1344,9 +1342,6 @@ int launch(const GemmP& p, hipStream_t s) {
     if (g_force_kernel == 0 && big && p.K >= 4096) return launch_pp256<EPI>(p, s);
     if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);
     if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
-    if constexpr (EPI != HIREST_EPI_BIAS_QGELU_BF16 && EPI != HIREST_EPI_PATCH_POS_F32) {
-        if (g_force_kernel >= 18 && big) return hirest_launch_d2(EPI, &p, s, g_force_kernel - 18);
-    }
     if (g_force_kernel == 8) return launch_pp256<EPI>(p, s);
     if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4) return launch256p<EPI>(p, s);
@@ -1362,10 +1357,9 @@ int launch(const GemmP& p, hipStream_t s) {
 extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 0; }
 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
-    // 18: d2 (two 256x128 workgroups per CU, gemm_d2.hip); 19: d2 without its LDS-DMA (timing experiment, plain epilogue); 20: d2
-    // addressing its operands as if K-blocked (timing experiment).  9..17 were the 4-wave kernel gemm_w4 and its schedule
-    // experiments (round 2; measured 3-7 % slower than p256 / pp256 on every shape, retired in round 3: DESIGN 4.1c, git history).
-    if (which < 0 || which > 20 || (which >= 9 && which <= 17)) return HIREST_E_BADARG;
+    // 9..17 were the 4-wave kernel gemm_w4 and its schedule experiments (round 2; 3-7 % slower than p256 / pp256 on every shape, retired in
+    // round 3), 18..20 the two-workgroup kernel gemm_d2 (round 3; 5-34 % slower, retired in round 4): DESIGN 4.1c / 4.1d, git history.
+    if (which < 0 || which > 8) return HIREST_E_BADARG;
     g_force_kernel = which;
     return 0;
 }
@@ -1385,13 +1379,9 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     }
     const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
-    const bool w4_ok = epi != HIREST_EPI_BIAS_QGELU_BF16 && epi != HIREST_EPI_PATCH_POS_F32;
     const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
-    if (f >= 18 && big && (fused || w4_ok)) {
-        snprintf(out, out_len, "gemm_d2<%d, %d>", epi, (f == 19 && epi == HIREST_EPI_BIAS_BF16) ? 1 :
-                 (f == 20 && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_RESID_LNSTATS_F32)) ? 2 : 0);
-    } else if (fused) {
+    if (fused) {
         if (a->K >= 4096 && f != 6) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
         else snprintf(out, out_len, "gemm_p256<%d, 64, false, 1>", epi);
     } else if (f == 0 && big && a->K >= 4096) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);

@@ -218,7 +218,8 @@ def test_profiled_kernels_are_the_dispatched_ones(lib):
     assert named, "no GEMM kernels found in the newest profile"
     assert named <= dispatched, f"profiled but no longer dispatched: {sorted(named - dispatched)}"
     # selection switches change the answer (the entry point mirrors the dispatch, it is not a constant table)
-    lib.hirest_gemm_select_kernel(18)
-    assert name(Mv, 6144, 1408, _lib.EPI_LNFOLD_GELU_BF16) == "gemm_d2<8, 0>"
-    assert lib.hirest_gemm_select_kernel(9) != 0 and lib.hirest_gemm_select_kernel(17) != 0      # the retired 4-wave kernel
+    lib.hirest_gemm_select_kernel(6)
+    assert name(Mv, 1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32) == "gemm_p256<6, 64, false, 1>"
+    for retired in (9, 17, 18, 20):                                      # the 4-wave kernel (round 2) and gemm_d2 (round 3)
+        assert lib.hirest_gemm_select_kernel(retired) != 0
     lib.hirest_gemm_select_kernel(0)
