@@ -844,8 +844,10 @@ __device__ __forceinline__ float attn_lsum(float lrun, float alpha, float psum) 
 // dh = the real head dim (the packed layouts are addressed with it; padded dims are zeros and their outputs are not stored).
 // NW = waves per block (32 queries each): 4, or 1 for short sequences (the sentence encoder's 4 .. 40-token sentences left three of
 // four waves without a query, staging and synchronising for nothing).
+// (min 2 waves per SIMD for the multi-wave blocks: left alone the compiler gave the 96-wide, three-wave instantiation — EVA's 88-wide heads
+//  at 257 tokens — 214 VGPRs + 48 AGPRs = one wave per SIMD, i.e. one 3-wave block per CU with a SIMD idle: 40 % matrix-pipe duty.)
 template <int DHP, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void attention_f32_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : (DHP > 64 ? 3 : 3)) void attention_f32_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
                                                            const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
                                                            int Tq, int T, int H, int dh, float scale, float add_const,
                                                            float causal_penalty, const int32_t* __restrict__ seq_off) {
@@ -920,9 +922,17 @@ __global__ __launch_bounds__(64 * NW) void attention_f32_kernel(const float* __r
         f32x16 st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
+        // (operand reads in groups of eight, fenced: left to itself the scheduler hoists all DHP / 2 LDS reads of the chain — and the
+        //  48 of the P V loop below — in front of the first MFMA, 40-odd live registers that cost the kernel a wave per SIMD)
 #pragma unroll
-        for (int s = 0; s < DHP / 2; ++s)   // A operand: K[key = l31][d = 2s + half]
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * ALD + 2 * s + half], qf[s], st, 0, 0, 0);
+        for (int g8 = 0; g8 < DHP / 2; g8 += 8) {
+            float kf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kf[i] = Ks[l31 * ALD + 2 * (g8 + i) + half];   // A operand: K[key = l31][d = 2s + half]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[i], qf[g8 + i], st, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float tmax = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -950,6 +960,7 @@ __global__ __launch_bounds__(64 * NW) void attention_f32_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < NO; ++j)
                 o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kr * ALD + 32 * j + l31], st[r], o[j], 0, 0, 0);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (!qvalid) return;
