@@ -1,0 +1,193 @@
+// Flash attention of the bf16x3 vision tower (tower_x3.hip): softmax(q k^T * scale) v over fp32 q / k / v rows, both matrix products formed
+// like the tower's GEMMs — from bf16 hi + lo splits of both operands, three v_mfma_f32_32x32x16_bf16 each (x_hi y_lo + x_lo y_hi + x_hi y_hi,
+// fp32 accumulation: 16-bit products) — with the softmax in fp32.  Replaces the exact-fp32 attention (joint.hip: v_mfma_f32_32x32x2_f32,
+// 6144 matrix-pipe cycles per 32 x 32 tile of scores) in that mode: 1152 cycles per tile, same online-softmax structure.
+//   reference: EVA_clip/vit_model.py:127-147 (q k^T, softmax, @ v); no mask, no causal term (the vision tower only).
+//
+// One wave owns 32 queries (S^T = K Q^T puts the query in the lane: row max / sum = local reduce + one half-wave exchange); a block of NW
+// waves shares the K / V tiles of 32 keys, staged global -> registers (one tile ahead) -> LDS as bf16 hi / lo images:
+//   K image [32 keys][DHP + 8] (A operand of S^T: 8 consecutive d per lane, one ds_read_b128), V image TRANSPOSED [DHP][32 keys + 4]
+//   (A operand of O^T = V^T P^T: keys contiguous per d, two ds_read_b64 per fragment).
+// P stays in registers: the C layout of S^T (lane = query; register r <-> key (r & 3) + 8 (r >> 2) + 4 half) is re-used as the B operand
+// of the second product by giving k-slot (half, i) of MFMA step s2 the key 16 s2 + 4 half + (i & 3) + 8 (i >> 2) on BOTH operands.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)v[e]; lo[e] = (bf16_t)(v[e] - (float)hi[e]); }
+}
+
+template <int DHP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
+                                                                 const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
+                                                                 int Tq, int T, int H, int dh, float scale) {
+    constexpr int KLD = DHP + 8, VLD = 36, NO = DHP / 32, NS = DHP / 16;     // NS: 16-deep steps of the score product
+    __shared__ __attribute__((aligned(16))) bf16_t Kh[32 * KLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Kl[32 * KLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vh[DHP * VLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vl[DHP * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int QB = 32 * NW, NT = 64 * NW;
+    const int qblocks = (Tq + QB - 1) / QB;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
+    const int b = bh / H, h = bh - b * H;
+    const int D = H * dh;
+    const float* qbase = qp + (int64_t)b * Tq * ldq + h * dh;
+    const float* kbase = kp + (int64_t)b * T * ldkv + h * dh;
+    const float* vbase = vp + (int64_t)b * T * ldkv + h * dh;
+    const int q = qb * QB + wave * 32 + l31;
+    const bool qvalid = q < Tq;
+    // Q^T fragments (B operand of S^T): lane (query, half) holds d = 16 s + 8 half .. + 7 for s = 0 .. NS - 1, as bf16 hi and lo
+    bf16x8 qh[NS], ql[NS];
+    {
+        const float* qrow = qbase + (int64_t)(qvalid ? q : Tq - 1) * ldq;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int d = 16 * s + 8 * half + 4 * g;
+                f32x4 v = *reinterpret_cast<const f32x4*>(qrow + (d + 4 <= dh ? d : dh - 4));       // dh % 4 == 0
+                if (!(qvalid && d < dh)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x4 a, c;
+                split4(v, a, c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qh[s][4 * g + e] = a[e]; ql[s][4 * g + e] = c[e]; }
+            }
+        }
+    }
+    f32x16 o[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
+    float mrun = -3.0e38f, lrun = 0.f;
+    // K / V tile staging through registers, one tile ahead
+    constexpr int NV4 = 32 * (DHP / 4), NLD = (NV4 + NT - 1) / NT;
+    f32x4 kreg[NLD], vreg[NLD];
+    auto fetch_kv = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            int i = tid + NT * u; i = i < NV4 ? i : NV4 - 1;
+            const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
+            const int key = k0 + kr < T ? k0 + kr : T - 1;
+            const int cc = c < dh ? c : dh - 4;
+            kreg[u] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + cc);
+            vreg[u] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + cc);
+        }
+    };
+    fetch_kv(0);
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        __syncthreads();                                            // every wave has finished reading the previous tile's images
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + NT * u;
+            if (i < NV4) {
+                const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
+                const bool in = c < dh && k0 + kr < T;               // rows past T and padded head columns are zeros (a zero V row adds nothing)
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                bf16x4 a, l;
+                split4(in ? kreg[u] : z, a, l);
+                *reinterpret_cast<bf16x4*>(&Kh[kr * KLD + c]) = a;
+                *reinterpret_cast<bf16x4*>(&Kl[kr * KLD + c]) = l;
+                split4(in ? vreg[u] : z, a, l);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Vh[(c + e) * VLD + kr] = a[e]; Vl[(c + e) * VLD + kr] = l[e]; }
+            }
+        }
+        __syncthreads();
+        if (k0 + 32 < T) fetch_kv(k0 + 32);
+        // ---- S^T = K Q^T: A = K[key = l31][d = 16 s + 8 half ..], B = Q^T; small terms first
+        f32x16 st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&Kh[l31 * KLD + 16 * s + 8 * half]);
+            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(&Kl[l31 * KLD + 16 * s + 8 * half]);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
+        }
+        // ---- online softmax (fp32): st[r] = score of key k0 + (r & 3) + 8 (r >> 2) + 4 half for query l31
+        float tmax = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float sv = key < T ? st[r] * scale : -3.0e38f;
+            st[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        { float pa = tmax, pb = tmax; lane_swap32(pa, pb); tmax = fmaxf(pa, pb); }
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+        bf16x8 ph[2], pl[2];                                        // P^T fragments of the two 16-key MFMA steps: registers 8 s2 .. 8 s2 + 7
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pz = __expf(st[r] - mnew);
+            psum += pz;
+            const bf16_t hi = (bf16_t)pz;
+            ph[r >> 3][r & 7] = hi;
+            pl[r >> 3][r & 7] = (bf16_t)(pz - (float)hi);
+        }
+        { float pa = psum, pb = psum; lane_swap32(pa, pb); psum = pa + pb; }
+        lrun = __builtin_fmaf(lrun, alpha, psum);
+        mrun = mnew;
+#pragma unroll
+        for (int j = 0; j < NO; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+        // ---- O^T += V^T P^T: A = V^T[d = l31 + 32 j][key slots of this half], k-slot i <-> key 16 s2 + 4 half + (i & 3) + 8 (i >> 2)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const int ro = (32 * j + l31) * VLD + 16 * s2 + 4 * half;
+                union { bf16x8 v; bf16x4 h[2]; } vh, vl;
+                vh.h[0] = *reinterpret_cast<const bf16x4*>(&Vh[ro]); vh.h[1] = *reinterpret_cast<const bf16x4*>(&Vh[ro + 8]);
+                vl.h[0] = *reinterpret_cast<const bf16x4*>(&Vl[ro]); vl.h[1] = *reinterpret_cast<const bf16x4*>(&Vl[ro + 8]);
+                o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.v, pl[s2], o[j], 0, 0, 0);
+                o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl.v, ph[s2], o[j], 0, 0, 0);
+                o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.v, ph[s2], o[j], 0, 0, 0);
+            }
+        }
+    }
+    if (!qvalid) return;
+    const float inv = 1.0f / lrun;
+    float* orow = out + ((int64_t)b * Tq + q) * D + h * dh;
+#pragma unroll
+    for (int j = 0; j < NO; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // O^T rows (reg & 3) + 8 (reg >> 2) + 4 half = d
+            const int d = 32 * j + 8 * g + 4 * half;
+            if (d < dh)
+                *reinterpret_cast<f32x4*>(orow + d) = f32x4{o[j][4 * g] * inv, o[j][4 * g + 1] * inv, o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv};
+        }
+}
+
+template <int DHP, class... Args>
+void launch_x3(int nw, dim3 grid, hipStream_t s, Args... args) {
+    if (nw == 3) hipLaunchKernelGGL((attention_x3_kernel<DHP, 3>), grid, dim3(192), 0, s, args...);
+    else hipLaunchKernelGGL((attention_x3_kernel<DHP, 4>), grid, dim3(256), 0, s, args...);
+}
+
+}  // namespace
+
+extern "C" int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int32_t B,
+                                       int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (dh <= 0 || dh % 4 != 0 || dh > 96 || ldq % 4 != 0 || ldkv % 4 != 0) return HIREST_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15)
+        return HIREST_E_SHAPE;
+    const int waves = (Tq + 31) / 32;
+    const int nw = (waves + 2) / 3 * 3 < (waves + 3) / 4 * 4 ? 3 : 4;         // three-wave blocks when they waste fewer waves (257 queries: 9)
+    const dim3 grid((unsigned)((int64_t)B * H * ((waves + nw - 1) / nw)));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dh <= 32) launch_x3<32>(nw, grid, s, q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
+    else if (dh <= 64) launch_x3<64>(nw, grid, s, q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
+    else launch_x3<96>(nw, grid, s, q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
+    return hirest_launch_status();
+}

@@ -3,7 +3,8 @@
 //     a w  ~=  w_hi a_lo + w_lo a_hi + w_hi a_hi        (hi = bf16(v), lo = bf16(v - hi); the dropped w_lo a_lo is 2^-16 of the product)
 // accumulated in fp32: products carry ~16 mantissa bits (fp32 MFMA: 24, the bf16 towers: 8) at three bf16 MFMAs each, i.e. 3/16 of
 // the exact-fp32 matrix cost.  Everything that is not a weight GEMM stays what tower_f32.hip runs: fp32 residual stream, fp32
-// LayerNorm, fp32 flash attention, erf-GELU in fp32, fp32 patch embedding and head.
+// LayerNorm, the softmax of the attention (whose two products are split-operand products as well: attention_x3.hip), erf-GELU in fp32,
+// fp32 patch embedding and head.
 //
 // Operand format (HIREST_GEMM_X3, include/hirest_hip.h): a [rows, K] fp32 matrix becomes [rows, 2K] bf16 whose 64-column block c holds
 // hi(k = 32c .. 32c+31) | lo(same k).  The split is fused into the kernel that produces the operand: LayerNorm (qkv / fc1 input), GELU
@@ -147,6 +148,13 @@ extern "C" int hirest_layernorm_split2(const float* x, int64_t ldx, const float*
     return hirest_launch_status();
 }
 
+static int g_x3_attention = 0;     // 0: split-operand flash attention (attention_x3.hip); 1: the exact-fp32 attention of tower_f32 (A/B, tests)
+extern "C" int hirest_vision_x3_select_attention(int32_t which) {
+    if (which < 0 || which > 1) return HIREST_E_BADARG;
+    g_x3_attention = which;
+    return 0;
+}
+
 extern "C" size_t hirest_vision_workspace_bytes_x3(const hirest_vision_tower_x3* t, int32_t B) {
     if (!t || !t->base || B <= 0) return 0;
     const hirest_vision_tower_f32* f = t->base;
@@ -185,8 +193,11 @@ extern "C" int hirest_vision_forward_x3(const hirest_vision_tower_x3* t, const v
           CHECK(hirest_layernorm_split2(x, D, w.ln1_g, w.ln1_b, f->ln_eps, a2, 2 * D, M, D, stream)); }
         CHECK(gemm_x3(a2, 2 * D, w2.qkv_w2, 2 * D, w.qkv_b, big, 3 * D, M, 3 * D, D, HIREST_EPI_BIAS_F32, stream));
         { HirestProfScope pr(HIREST_PROF_ATTENTION, 2, (int64_t)B * f->heads, T, f->head_dim, s);
-          CHECK(hirest_attention_f32_qkv(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, h, B, T, T, f->heads, f->head_dim, scale, 0.f,
-                                         0.f, stream)); }
+          if (g_x3_attention == 0)
+              CHECK(hirest_attention_x3_qkv(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, h, B, T, T, f->heads, f->head_dim, scale, stream));
+          else
+              CHECK(hirest_attention_f32_qkv(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, h, B, T, T, f->heads, f->head_dim, scale, 0.f,
+                                             0.f, stream)); }
         { HirestProfScope pr(HIREST_PROF_LAYERNORM, 11, M, D, 0, s);
           CHECK(hirest_split2_bf16(h, D, a2, 2 * D, M, D, 0, stream)); }
         CHECK(gemm_x3(a2, 2 * D, w2.proj_w2, 2 * D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_F32, stream));

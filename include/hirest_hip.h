@@ -366,6 +366,13 @@ typedef struct hirest_vision_tower_x3 {
 int hirest_split2_bf16(const float* x, int64_t ldx, hirest_bf16* out, int64_t ldo, int64_t rows, int32_t D, int32_t act, void* stream);
 int hirest_layernorm_split2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, hirest_bf16* out, int64_t ldo,
                             int32_t rows, int32_t D, void* stream);
+/* softmax(q k^T * scale) v for fp32 q / k / v rows (row strides ldq / ldkv, head h at column h * dh; out [B * Tq, H * dh]) with both products
+ * formed from bf16 hi + lo splits (three bf16 MFMAs per product, fp32 accumulation), softmax in fp32: the attention of the bf16x3 tower
+ * (vit_model.py:127-147; no mask).  dh % 4 == 0, dh <= 96; pointers 16-B aligned. */
+int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int32_t B, int32_t Tq,
+                            int32_t Tk, int32_t H, int32_t dh, float scale, void* stream);
+/* A/B and tests: 0 = the tower's attention is hirest_attention_x3_qkv (default), 1 = the exact-fp32 hirest_attention_f32_qkv */
+int hirest_vision_x3_select_attention(int32_t which);
 size_t hirest_vision_workspace_bytes_x3(const hirest_vision_tower_x3* t, int32_t B);
 int hirest_vision_forward_x3(const hirest_vision_tower_x3* t, const void* frames, int32_t in_dtype, int32_t B, float* out,
                              void* workspace, size_t workspace_bytes, void* stream);

@@ -154,3 +154,49 @@ def test_eva_g14_bf16x3_vs_reference_and_c3_ranks(dev, golden_dir):
     safe = margin > 2 * serr
     assert torch.equal(idx[safe, 0], gt[safe])                     # exact wherever the reference's own margin decides
     assert int(flips.sum()) <= int((~safe).sum())
+
+
+@pytest.mark.parametrize("B,T,H,dh", [(2, 257, 16, 88), (1, 300, 12, 64), (3, 77, 4, 32), (1, 33, 2, 96), (2, 64, 3, 40), (1, 1, 1, 64)])
+def test_attention_x3_against_fp64(dev, B, T, H, dh):
+    """hirest_attention_x3_qkv (both products from bf16 hi + lo splits, softmax in fp32) against softmax(q k^T * scale) v in fp64 on packed
+    q | k | v rows, and against the exact-fp32 kernel it replaces in the bf16x3 tower; ragged tails (257 = 8 x 32 + 1 keys), padded head
+    widths (88 -> 96, 40 -> 64) and large score magnitudes included."""
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    D = H * dh
+    qkv = synth.tensor(f"x3.attn.{B}.{T}.{H}.{dh}", (B * T, 3 * D), 1.0, 13).to(dev)
+    qkv[:, :D] *= 3.0                                                  # peaked softmax rows as well as flat ones
+    scale = dh ** -0.5
+    q, k, v = (qkv[:, i * D:(i + 1) * D].double().reshape(B, T, H, dh).permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, D)
+    out = torch.full((B * T, D), 7.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.hirest_attention_x3_qkv(qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, out.data_ptr(), B, T, T, H,
+                                           dh, scale, ops.stream_ptr()), "hirest_attention_x3_qkv")
+    f32 = torch.empty_like(out)
+    _lib.check(lib.hirest_attention_f32_qkv(qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, f32.data_ptr(), B, T, T, H,
+                                            dh, scale, 0.0, 0.0, ops.stream_ptr()), "hirest_attention_f32_qkv")
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    err32 = (f32.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"attention x3 B={B} T={T} H={H} dh={dh}: max err / max |ref| {err:.2e} (exact-fp32 kernel: {err32:.2e})")
+    assert torch.isfinite(out).all() and err < 3e-5
+
+
+def test_x3_tower_attention_ab(dev, golden_dir):
+    """The tower with its split-operand attention (default) and with the exact-fp32 attention agree to the level of the split products."""
+    import hirest_amd
+    from hirest_amd import _lib
+    g = np.load(os.path.join(golden_dir, "eva_tiny.npz"))
+    seed = int(g["seed"])
+    model, _ = hirest_amd.build_eva_model_and_transforms("EVA_CLIP_tiny_test", pretrained=f"synth:{seed}", precision="bf16x3")
+    model = model.to(dev).eval()
+    img = synth.frames("eva_tiny.img", (int(g["n_img"]), 3, 224, 224), seed + 1).to(dev)
+    a = model.encode_image(img)
+    _lib.load().hirest_vision_x3_select_attention(1)
+    try:
+        b = model.encode_image(img)
+    finally:
+        _lib.load().hirest_vision_x3_select_attention(0)
+    ref = torch.from_numpy(g["image_embed"]).to(dev)
+    ea, eb = ((x - ref).abs().max().item() / ref.abs().max().item() for x in (a, b))
+    print(f"tiny bf16x3 tower vs reference: split-operand attention {ea:.2e}, exact-fp32 attention {eb:.2e}")
+    assert ea <= 1e-4 and eb <= 1e-4
