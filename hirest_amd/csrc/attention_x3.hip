@@ -5,7 +5,7 @@
 //   reference: EVA_clip/vit_model.py:127-147 (q k^T, softmax, @ v); no mask, no causal term (the vision tower only).
 //
 // One wave owns 32 queries (S^T = K Q^T puts the query in the lane: row max / sum = local reduce + one half-wave exchange); a block of NW
-// waves shares the K / V tiles of 32 keys, staged global -> registers (one tile ahead) -> LDS as bf16 hi / lo images:
+// waves shares the K / V tiles of 32 keys, staged global -> registers -> LDS (double-buffered, one barrier per tile) as bf16 hi / lo images:
 //   K image [32 keys][DHP + 8] (A operand of S^T: 8 consecutive d per lane, one ds_read_b128), V image TRANSPOSED [DHP][32 keys + 4]
 //   (A operand of O^T = V^T P^T: keys contiguous per d, two ds_read_b64 per fragment).
 // P stays in registers: the C layout of S^T (lane = query; register r <-> key (r & 3) + 8 (r >> 2) + 4 half) is re-used as the B operand
@@ -24,10 +24,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* _
                                                                  const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
                                                                  int Tq, int T, int H, int dh, float scale) {
     constexpr int KLD = DHP + 8, VLD = 36, NO = DHP / 32, NS = DHP / 16;     // NS: 16-deep steps of the score product
-    __shared__ __attribute__((aligned(16))) bf16_t Kh[32 * KLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Kl[32 * KLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Vh[DHP * VLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Vl[DHP * VLD];
+    constexpr int KSZ = 32 * KLD, VSZ = DHP * VLD;
+    __shared__ __attribute__((aligned(16))) bf16_t Kh[2 * KSZ];             // two tiles: tile t + 1 is stored while tile t is multiplied
+    __shared__ __attribute__((aligned(16))) bf16_t Kl[2 * KSZ];
+    __shared__ __attribute__((aligned(16))) bf16_t Vh[2 * VSZ];
+    __shared__ __attribute__((aligned(16))) bf16_t Vl[2 * VSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int QB = 32 * NW, NT = 64 * NW;
@@ -64,49 +65,82 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* _
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
     float mrun = -3.0e38f, lrun = 0.f;
-    // K / V tile staging through registers, one tile ahead
+    // K / V tile staging through registers, one tile ahead of the LDS images, which are one tile ahead of the MFMAs.
+    //   K: thread -> (key = i / (DHP / 4), 4 consecutive d): whole 128-B lines per wave-load, 8-B hi / lo stores along a row: conflict-free.
+    //   V: its image is TRANSPOSED ([d][key], 2-byte stores), so a wave-load covers 16 keys x 4 float4 instead — lane = key (16) + 16 chunk —
+    //      which puts a store instruction's 64 lanes on 32 distinct banks (key / 2 + 8 chunk words); with K's mapping 24 lanes of one key
+    //      hit 4 banks (57 % of the LDS cycles were conflicts).
     constexpr int NV4 = 32 * (DHP / 4), NLD = (NV4 + NT - 1) / NT;
-    f32x4 kreg[NLD], vreg[NLD];
+    constexpr int VINS = 2 * (DHP / 16);                              // V wave-instructions per tile: (16-key half) x (group of 4 chunks)
+    constexpr int NLV = (VINS + NW - 1) / NW;
+    f32x4 kreg[NLD], vreg[NLV];
+    auto v_slot = [&](int u, int& kr, int& c) {                       // (wave-uniform instruction index; false: nothing to do)
+        const int t = wave + NW * u;
+        kr = 16 * (t & 1) + (lane & 15);
+        c = 16 * (t >> 1) + 4 * (lane >> 4);
+        return t < VINS;
+    };
     auto fetch_kv = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             int i = tid + NT * u; i = i < NV4 ? i : NV4 - 1;
             const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
             const int key = k0 + kr < T ? k0 + kr : T - 1;
-            const int cc = c < dh ? c : dh - 4;
-            kreg[u] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + cc);
-            vreg[u] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + cc);
+            kreg[u] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + (c < dh ? c : dh - 4));
+        }
+#pragma unroll
+        for (int u = 0; u < NLV; ++u) {
+            int kr, c;
+            v_slot(u, kr, c);
+            const int key = k0 + kr < T ? k0 + kr : T - 1;
+            c = c < DHP ? c : DHP - 4;
+            vreg[u] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + (c < dh ? c : dh - 4));
         }
     };
-    fetch_kv(0);
-    for (int k0 = 0; k0 < T; k0 += 32) {
-        __syncthreads();                                            // every wave has finished reading the previous tile's images
+    auto store_kv = [&](int k0, int buf) {                            // registers (tile at k0) -> LDS images `buf`; rows past T and padded columns: zeros
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int i = tid + NT * u;
             if (i < NV4) {
                 const int kr = i / (DHP / 4), c = (i - kr * (DHP / 4)) * 4;
-                const bool in = c < dh && k0 + kr < T;               // rows past T and padded head columns are zeros (a zero V row adds nothing)
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 bf16x4 a, l;
-                split4(in ? kreg[u] : z, a, l);
-                *reinterpret_cast<bf16x4*>(&Kh[kr * KLD + c]) = a;
-                *reinterpret_cast<bf16x4*>(&Kl[kr * KLD + c]) = l;
-                split4(in ? vreg[u] : z, a, l);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { Vh[(c + e) * VLD + kr] = a[e]; Vl[(c + e) * VLD + kr] = l[e]; }
+                split4((c < dh && k0 + kr < T) ? kreg[u] : z, a, l);
+                *reinterpret_cast<bf16x4*>(&Kh[buf * KSZ + kr * KLD + c]) = a;
+                *reinterpret_cast<bf16x4*>(&Kl[buf * KSZ + kr * KLD + c]) = l;
             }
         }
+#pragma unroll
+        for (int u = 0; u < NLV; ++u) {
+            int kr, c;
+            if (v_slot(u, kr, c)) {
+                bf16x4 a, l;
+                split4((c < dh && k0 + kr < T) ? vreg[u] : z, a, l);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Vh[buf * VSZ + (c + e) * VLD + kr] = a[e]; Vl[buf * VSZ + (c + e) * VLD + kr] = l[e]; }
+            }
+        }
+    };
+    fetch_kv(0);
+    store_kv(0, 0);
+    if (32 < T) fetch_kv(32);
+    int buf = 0;
+    for (int k0 = 0; k0 < T; k0 += 32, buf ^= 1) {
+        // one barrier per tile: it publishes this tile's images (stored during the previous iteration) and tells every wave that the
+        // other buffer — read during the previous iteration — is free for the next tile
         __syncthreads();
-        if (k0 + 32 < T) fetch_kv(k0 + 32);
+        if (k0 + 32 < T) store_kv(k0 + 32, buf ^ 1);
+        if (k0 + 64 < T) fetch_kv(k0 + 64);
+        const bf16_t* Khb = Kh + buf * KSZ; const bf16_t* Klb = Kl + buf * KSZ;
+        const bf16_t* Vhb = Vh + buf * VSZ; const bf16_t* Vlb = Vl + buf * VSZ;
         // ---- S^T = K Q^T: A = K[key = l31][d = 16 s + 8 half ..], B = Q^T; small terms first
         f32x16 st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&Kh[l31 * KLD + 16 * s + 8 * half]);
-            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(&Kl[l31 * KLD + 16 * s + 8 * half]);
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&Khb[l31 * KLD + 16 * s + 8 * half]);
+            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(&Klb[l31 * KLD + 16 * s + 8 * half]);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
@@ -147,8 +181,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* _
             for (int j = 0; j < NO; ++j) {
                 const int ro = (32 * j + l31) * VLD + 16 * s2 + 4 * half;
                 union { bf16x8 v; bf16x4 h[2]; } vh, vl;
-                vh.h[0] = *reinterpret_cast<const bf16x4*>(&Vh[ro]); vh.h[1] = *reinterpret_cast<const bf16x4*>(&Vh[ro + 8]);
-                vl.h[0] = *reinterpret_cast<const bf16x4*>(&Vl[ro]); vl.h[1] = *reinterpret_cast<const bf16x4*>(&Vl[ro + 8]);
+                vh.h[0] = *reinterpret_cast<const bf16x4*>(&Vhb[ro]); vh.h[1] = *reinterpret_cast<const bf16x4*>(&Vhb[ro + 8]);
+                vl.h[0] = *reinterpret_cast<const bf16x4*>(&Vlb[ro]); vl.h[1] = *reinterpret_cast<const bf16x4*>(&Vlb[ro + 8]);
                 o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.v, pl[s2], o[j], 0, 0, 0);
                 o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl.v, ph[s2], o[j], 0, 0, 0);
                 o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.v, ph[s2], o[j], 0, 0, 0);
