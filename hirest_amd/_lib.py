@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
 
 (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_POS_F32,
- EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16) = range(9)
+ EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16, EPI_BIAS_GELU_SPLIT2) = range(10)
 
 TOWER_NO_LNFOLD = 1
 TOWER_NO_PRUNE = 2

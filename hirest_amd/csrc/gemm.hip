@@ -1371,12 +1371,13 @@ extern "C" int hirest_gemm_select_kernel(int32_t which) {
 extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, int32_t out_len) {
     if (!a || a->struct_size != sizeof(hirest_gemm_args) || !out || out_len < 48) return HIREST_E_BADARG;
     const int epi = a->epilogue, f = g_force_kernel;
-    if (epi < 0 || epi > HIREST_EPI_LNFOLD_GELU_BF16) return HIREST_E_BADARG;
+    if (epi < 0 || epi > HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
     if (a->flags & HIREST_GEMM_X3) {
-        if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32) return HIREST_E_BADARG;
+        if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32 && epi != HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
         snprintf(out, out_len, "gemm_pp256x3<%d>", epi);
         return 0;
     }
+    if (epi == HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;      // exists in the X3 form only
     const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
     const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
@@ -1420,6 +1421,9 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
         switch (a->epilogue) {
             case HIREST_EPI_BIAS_F32: return launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);
             case HIREST_EPI_BIAS_RESID_F32: return launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true>(p, s);
+            case HIREST_EPI_BIAS_GELU_SPLIT2:
+                if (a->N % 32 != 0 || a->ldo < 2 * (int64_t)a->N || a->ldo % 8 != 0) return HIREST_E_SHAPE;
+                return launch_pp256<HIREST_EPI_BIAS_GELU_SPLIT2, 1, true>(p, s);
             default: return HIREST_E_BADARG;
         }
     }
@@ -1435,6 +1439,6 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
         case HIREST_EPI_BIAS_RESID_LNSTATS_F32: return launch_fused<HIREST_EPI_BIAS_RESID_LNSTATS_F32>(p, s);
         case HIREST_EPI_LNFOLD_BF16: return launch_fused<HIREST_EPI_LNFOLD_BF16>(p, s);
         case HIREST_EPI_LNFOLD_GELU_BF16: return launch_fused<HIREST_EPI_LNFOLD_GELU_BF16>(p, s);
-        default: return HIREST_E_BADARG;
+        default: return HIREST_E_BADARG;     // (HIREST_EPI_BIAS_GELU_SPLIT2 without HIREST_GEMM_X3 included)
     }
 }

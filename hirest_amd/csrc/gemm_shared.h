@@ -37,6 +37,9 @@ constexpr int Q_BK = 64;
 constexpr int Q_STEP = (T_BM + T_BN) * Q_BK * 2;   // 64 KiB
 constexpr int Q_WOFF = T_BM * Q_BK * 2;
 
+#ifndef HIREST_X3_GELU_POLY
+#define HIREST_X3_GELU_POLY 1
+#endif
 constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128 B
 constexpr bool epi_is_lnfold(int epi) { return epi == HIREST_EPI_LNFOLD_BF16 || epi == HIREST_EPI_LNFOLD_GELU_BF16; }
 // the LN-fold consumers keep the (mean, rstd) pairs of the wave's 128 rows behind their staging area
@@ -232,6 +235,51 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
                         if (n + 8 <= p.N) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst));
                         else if (n + 4 <= p.N) *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
                     }
+                }
+                HX_LDS_ORDER();
+            }
+        }
+    } else if constexpr (EPI == HIREST_EPI_BIAS_GELU_SPLIT2) {
+        // GELU (erf form, fp32) of acc + bias, stored as bf16 hi | lo in the split operand format: a 32-column group of the output is one
+        // 64-element (128-B) block of the [M, 2N] row — exactly one staging row — so the read-back leaves as whole lines like the bf16 path
+        bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+        for (int jp = 0; jp < NI; jp += 2) {                     // 32-column groups
+            if (Nw + jp * 16 >= p.N) continue;                   // (N % 32 == 0: a group is inside or outside as a whole)
+            f32x4 bv[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = Nw + (jp + n) * 16 + 4 * kg;
+                bv[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int mi = 0; mi < NM; ++mi) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const f32x4 v = acc[mi][jp + n] + bv[n];
+                    bf16x4 hi, lo;
+#if HIREST_X3_GELU_POLY
+                    // the bf16 towers' erf-form GELU (common.h: max abs error 1.1e-6): an fp32 erff here costs the epilogue 2 ms per launch
+                    const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+                    const f32x4 gv = {g0[0], g0[1], g1[0], g1[1]};
+#else
+                    f32x4 gv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gv[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+#endif
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)gv[e]; lo[e] = (bf16_t)(gv[e] - (float)hi[e]); }
+                    *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((n * 2 + (kg >> 1)) ^ sw) << 4) + (kg & 1) * 8) = hi;
+                    *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((4 + n * 2 + (kg >> 1)) ^ sw) << 4) + (kg & 1) * 8) = lo;
+                }
+                HX_LDS_ORDER();
+                const int mb = Mw + mi * 16;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int r = it * 8 + rr;
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
+                    const int m = mb + r;
+                    if (m < p.M) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(outp + (int64_t)m * p.ldo + 2 * (Nw + jp * 16) + rc * 8));
                 }
                 HX_LDS_ORDER();
             }

@@ -148,10 +148,12 @@ extern "C" int hirest_layernorm_split2(const float* x, int64_t ldx, const float*
     return hirest_launch_status();
 }
 
+static int g_x3_gelu_pass = 0;     // hirest_vision_x3_select_attention bit 1: GELU + split as a separate pass over an fp32 hidden activation (A/B)
 static int g_x3_attention = 0;     // 0: split-operand flash attention (attention_x3.hip); 1: the exact-fp32 attention of tower_f32 (A/B, tests)
 extern "C" int hirest_vision_x3_select_attention(int32_t which) {
-    if (which < 0 || which > 1) return HIREST_E_BADARG;
-    g_x3_attention = which;
+    if (which < 0 || which > 3) return HIREST_E_BADARG;
+    g_x3_attention = which & 1;
+    g_x3_gelu_pass = (which >> 1) & 1;
     return 0;
 }
 
@@ -203,9 +205,13 @@ extern "C" int hirest_vision_forward_x3(const hirest_vision_tower_x3* t, const v
         CHECK(gemm_x3(a2, 2 * D, w2.proj_w2, 2 * D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_F32, stream));
         { HirestProfScope pr(HIREST_PROF_LAYERNORM, 10, M, D, 0, s);
           CHECK(hirest_layernorm_split2(x, D, w.ln2_g, w.ln2_b, f->ln_eps, a2, 2 * D, M, D, stream)); }
-        CHECK(gemm_x3(a2, 2 * D, w2.fc1_w2, 2 * D, w.fc1_b, big, Dm, M, Dm, D, HIREST_EPI_BIAS_F32, stream));
-        { HirestProfScope pr(HIREST_PROF_LAYERNORM, 12, M, Dm, 0, s);
-          CHECK(hirest_split2_bf16(big, Dm, b2, 2 * Dm, M, Dm, 1, stream)); }
+        if (g_x3_gelu_pass == 0) {                              // GELU + split in fc1's epilogue: the hidden activation never exists in fp32
+            CHECK(gemm_x3(a2, 2 * D, w2.fc1_w2, 2 * D, w.fc1_b, reinterpret_cast<float*>(b2), 2 * Dm, M, Dm, D, HIREST_EPI_BIAS_GELU_SPLIT2, stream));
+        } else {
+            CHECK(gemm_x3(a2, 2 * D, w2.fc1_w2, 2 * D, w.fc1_b, big, Dm, M, Dm, D, HIREST_EPI_BIAS_F32, stream));
+            HirestProfScope pr(HIREST_PROF_LAYERNORM, 12, M, Dm, 0, s);
+            CHECK(hirest_split2_bf16(big, Dm, b2, 2 * Dm, M, Dm, 1, stream));
+        }
         CHECK(gemm_x3(b2, 2 * Dm, w2.fc2_w2, 2 * Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_F32, stream));
     }
     CHECK(hirest_layernorm(x, (int64_t)T * D, nullptr, f->norm_g, f->norm_b, f->ln_eps, h, D, 1, B, D, stream));

@@ -181,12 +181,21 @@ def split2(x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
 
 
 @on_tensor_device
-def gemm_x3(a2: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = None, resid_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_x3(a2: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = None, resid_out: Optional[torch.Tensor] = None,
+            gelu_split: bool = False) -> torch.Tensor:
     """fp32 [M, N] = A W^T (+ bias) from split operands a2 [M, 2K], w2 [N, 2K] (ops.split2): HIREST_GEMM_X3.  With `resid_out` (fp32 [M, N])
-    the product is added into it (x += ...)."""
+    the product is added into it (x += ...); with `gelu_split` the result is nn.GELU()(A W^T + bias) as a split operand [M, 2N] bf16
+    (HIREST_EPI_BIAS_GELU_SPLIT2: the next layer's A operand, no fp32 round trip)."""
     lib = _lib.load()
     M, K2 = a2.shape
     N = w2.shape[0]
+    if gelu_split:
+        out = torch.empty((M, 2 * N), dtype=torch.bfloat16, device=a2.device)
+        args = _lib.GemmArgs.make(_dev(a2, torch.bfloat16, "gemm_x3.a"), K2, _dev(w2, torch.bfloat16, "gemm_x3.w"), K2,
+                                  _opt(bias, torch.float32, "gemm_x3.bias"), out.data_ptr(), 2 * N, M, N, K2, _lib.EPI_BIAS_GELU_SPLIT2, None, 0,
+                                  None, None, _lib.GEMM_X3)
+        _lib.check(lib.hirest_gemm_bf16(C.byref(args), stream_ptr()), "hirest_gemm_bf16 (x3, gelu + split)")
+        return out
     out = resid_out if resid_out is not None else torch.empty((M, N), dtype=torch.float32, device=a2.device)
     args = _lib.GemmArgs.make(_dev(a2, torch.bfloat16, "gemm_x3.a"), K2, _dev(w2, torch.bfloat16, "gemm_x3.w"), K2,
                               _opt(bias, torch.float32, "gemm_x3.bias"), out.data_ptr(), N, M, N, K2,

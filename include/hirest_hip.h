@@ -67,7 +67,10 @@ enum hirest_epilogue {
     HIREST_EPI_LNFOLD_BF16 = 7,      /* consumer: A = that bf16 copy, W = W', bias = b', aux0 = f32 [M,2] (mean, rstd; the buffer
                                         must be readable up to an EVEN number of rows, i.e. M + 1 rows when M is odd),
                                         aux1 = s [N];  out bf16 = rstd * (acc - mean * s) + b' */
-    HIREST_EPI_LNFOLD_GELU_BF16 = 8  /* same, then gelu_erf */
+    HIREST_EPI_LNFOLD_GELU_BF16 = 8, /* same, then gelu_erf */
+    HIREST_EPI_BIAS_GELU_SPLIT2 = 9  /* HIREST_GEMM_X3 only: out bf16 [M, 2N] = nn.GELU()(acc + bias) (erf form, fp32) in the split operand format
+                                        of hirest_split2_bf16 (per 64 columns: hi of 32 outputs | their lo): fc1 of the bf16x3 tower feeding fc2
+                                        without an fp32 round trip.  N % 32 == 0, ldo >= 2N. */
 };
 
 typedef struct hirest_gemm_args {
@@ -371,7 +374,8 @@ int hirest_layernorm_split2(const float* x, int64_t ldx, const float* gamma, con
  * (vit_model.py:127-147; no mask).  dh % 4 == 0, dh <= 96; pointers 16-B aligned. */
 int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int32_t B, int32_t Tq,
                             int32_t Tk, int32_t H, int32_t dh, float scale, void* stream);
-/* A/B and tests: 0 = the tower's attention is hirest_attention_x3_qkv (default), 1 = the exact-fp32 hirest_attention_f32_qkv */
+/* A/B and tests: bit 0 = the tower's attention is the exact-fp32 hirest_attention_f32_qkv instead of hirest_attention_x3_qkv; bit 1 = fc1 writes fp32
+ * and GELU + split run as a separate pass (hirest_split2_bf16) instead of in its epilogue (HIREST_EPI_BIAS_GELU_SPLIT2).  Default 0. */
 int hirest_vision_x3_select_attention(int32_t which);
 size_t hirest_vision_workspace_bytes_x3(const hirest_vision_tower_x3* t, int32_t B);
 int hirest_vision_forward_x3(const hirest_vision_tower_x3* t, const void* frames, int32_t in_dtype, int32_t B, float* out,

@@ -76,6 +76,13 @@ def test_gemm_x3_against_fp64(dev, M, N, K):
     if M >= 300:                                                             # a row's result does not depend on its neighbours
         part = ops.gemm_x3(a2[100:300].contiguous(), w2, bias)
         assert torch.equal(part, got[100:300])
+    if N % 32 == 0:                                                          # GELU + split in the epilogue == the separate pass on the fp32 output
+        fused = ops.gemm_x3(a2, w2, bias, gelu_split=True)
+        sep = ops.split2(got, gelu=True)
+        back = lambda t: t.reshape(M, N // 32, 2, 32).float().sum(dim=2).reshape(M, N)
+        assert (back(fused) - back(sep)).abs().max().item() <= 2.0 ** -16 * max(1.0, back(sep).abs().max().item())
+        same = (fused.view(torch.int16) == sep.view(torch.int16)).float().mean().item()
+        print(f"   gelu + split epilogue: {100 * same:.3f} % of the bf16 words equal to the separate pass")
 
 
 def test_layernorm_split2_equals_layernorm_then_split(dev):
@@ -197,6 +204,11 @@ def test_x3_tower_attention_ab(dev, golden_dir):
     finally:
         _lib.load().hirest_vision_x3_select_attention(0)
     ref = torch.from_numpy(g["image_embed"]).to(dev)
-    ea, eb = ((x - ref).abs().max().item() / ref.abs().max().item() for x in (a, b))
-    print(f"tiny bf16x3 tower vs reference: split-operand attention {ea:.2e}, exact-fp32 attention {eb:.2e}")
-    assert ea <= 1e-4 and eb <= 1e-4
+    _lib.load().hirest_vision_x3_select_attention(2)                 # GELU + split as a separate pass over an fp32 hidden activation
+    try:
+        c = model.encode_image(img)
+    finally:
+        _lib.load().hirest_vision_x3_select_attention(0)
+    ea, eb, ec = ((x - ref).abs().max().item() / ref.abs().max().item() for x in (a, b, c))
+    print(f"tiny bf16x3 tower vs reference: default {ea:.2e}, exact-fp32 attention {eb:.2e}, separate GELU pass {ec:.2e}")
+    assert ea <= 1e-4 and eb <= 1e-4 and ec <= 1e-4
