@@ -255,6 +255,8 @@ _SIGNATURES = {
                                           C.c_int32, C.c_void_p]),
     "hirest_attention_x3_qkv": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "hirest_attention_x3_qkv_split2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "hirest_vision_x3_select_attention": (C.c_int, [C.c_int32]),
     "hirest_vision_workspace_bytes_x3": (C.c_size_t, [C.POINTER(VisionTowerX3), C.c_int32]),
     "hirest_vision_forward_x3": (C.c_int, [C.POINTER(VisionTowerX3), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,

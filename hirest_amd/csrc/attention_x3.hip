@@ -22,7 +22,7 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
 template <int DHP, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
                                                                  const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
-                                                                 int Tq, int T, int H, int dh, float scale) {
+                                                                 bf16_t* __restrict__ out2, int Tq, int T, int H, int dh, float scale) {
     constexpr int KLD = DHP + 8, VLD = 36, NO = DHP / 32, NS = DHP / 16;     // NS: 16-deep steps of the score product
     constexpr int KSZ = 32 * KLD, VSZ = DHP * VLD;
     __shared__ __attribute__((aligned(16))) bf16_t Kh[2 * KSZ];             // two tiles: tile t + 1 is stored while tile t is multiplied
@@ -191,14 +191,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* _
     }
     if (!qvalid) return;
     const float inv = 1.0f / lrun;
-    float* orow = out + ((int64_t)b * Tq + q) * D + h * dh;
+    float* orow = out ? out + ((int64_t)b * Tq + q) * D + h * dh : nullptr;
+    bf16_t* orow2 = out2 ? out2 + ((int64_t)b * Tq + q) * 2 * D : nullptr;      // split operand format of the next GEMM (hirest_split2_bf16)
 #pragma unroll
     for (int j = 0; j < NO; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {   // O^T rows (reg & 3) + 8 (reg >> 2) + 4 half = d
             const int d = 32 * j + 8 * g + 4 * half;
-            if (d < dh)
-                *reinterpret_cast<f32x4*>(orow + d) = f32x4{o[j][4 * g] * inv, o[j][4 * g + 1] * inv, o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv};
+            if (d < dh) {
+                const f32x4 y = {o[j][4 * g] * inv, o[j][4 * g + 1] * inv, o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv};
+                if (orow) *reinterpret_cast<f32x4*>(orow + d) = y;
+                if (orow2) {            // (four consecutive columns from a multiple of 4 never straddle a 32-column block)
+                    const int col = h * dh + d;
+                    bf16x4 hi, lo;
+                    split4(y, hi, lo);
+                    bf16_t* o2 = orow2 + (col >> 5) * 64 + (col & 31);
+                    *reinterpret_cast<bf16x4*>(o2) = hi;
+                    *reinterpret_cast<bf16x4*>(o2 + 32) = lo;
+                }
+            }
         }
 }
 
@@ -210,18 +221,29 @@ void launch_x3(int nw, dim3 grid, hipStream_t s, Args... args) {
 
 }  // namespace
 
-extern "C" int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int32_t B,
-                                       int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, void* stream) {
-    if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
+static int attention_x3(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, bf16_t* out2, int32_t B,
+                        int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, void* stream) {
+    if (!q || !k || !v || (!out && !out2) || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return HIREST_E_BADARG;
+    if (out2 && ((H * dh) % 32 != 0 || (reinterpret_cast<uintptr_t>(out2) & 7))) return HIREST_E_SHAPE;
     if (dh <= 0 || dh % 4 != 0 || dh > 96 || ldq % 4 != 0 || ldkv % 4 != 0) return HIREST_E_SHAPE;
-    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15)
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15)   // (out may be NULL)
         return HIREST_E_SHAPE;
     const int waves = (Tq + 31) / 32;
     const int nw = (waves + 2) / 3 * 3 < (waves + 3) / 4 * 4 ? 3 : 4;         // three-wave blocks when they waste fewer waves (257 queries: 9)
     const dim3 grid((unsigned)((int64_t)B * H * ((waves + nw - 1) / nw)));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dh <= 32) launch_x3<32>(nw, grid, s, q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
-    else if (dh <= 64) launch_x3<64>(nw, grid, s, q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
-    else launch_x3<96>(nw, grid, s, q, ldq, k, v, ldkv, out, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
+    if (dh <= 32) launch_x3<32>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
+    else if (dh <= 64) launch_x3<64>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
+    else launch_x3<96>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
     return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int32_t B,
+                                       int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, void* stream) {
+    return attention_x3(q, ldq, k, v, ldkv, out, nullptr, B, Tq, Tk, H, dh, scale, stream);
+}
+// the same with the output written as the split operand [B * Tq, 2 * H * dh] bf16 of the GEMM that follows (hirest_split2_bf16's format)
+extern "C" int hirest_attention_x3_qkv_split2(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, hirest_bf16* out2,
+                                              int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, void* stream) {
+    return attention_x3(q, ldq, k, v, ldkv, nullptr, reinterpret_cast<bf16_t*>(out2), B, Tq, Tk, H, dh, scale, stream);
 }

@@ -195,13 +195,16 @@ extern "C" int hirest_vision_forward_x3(const hirest_vision_tower_x3* t, const v
           CHECK(hirest_layernorm_split2(x, D, w.ln1_g, w.ln1_b, f->ln_eps, a2, 2 * D, M, D, stream)); }
         CHECK(gemm_x3(a2, 2 * D, w2.qkv_w2, 2 * D, w.qkv_b, big, 3 * D, M, 3 * D, D, HIREST_EPI_BIAS_F32, stream));
         { HirestProfScope pr(HIREST_PROF_ATTENTION, 2, (int64_t)B * f->heads, T, f->head_dim, s);
-          if (g_x3_attention == 0)
-              CHECK(hirest_attention_x3_qkv(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, h, B, T, T, f->heads, f->head_dim, scale, stream));
+          if (g_x3_attention == 0)        // writes proj's split operand itself
+              CHECK(hirest_attention_x3_qkv_split2(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, a2, B, T, T, f->heads, f->head_dim, scale,
+                                                   stream));
           else
               CHECK(hirest_attention_f32_qkv(big, 3 * (int64_t)D, big + D, big + 2 * D, 3 * (int64_t)D, h, B, T, T, f->heads, f->head_dim, scale, 0.f,
                                              0.f, stream)); }
-        { HirestProfScope pr(HIREST_PROF_LAYERNORM, 11, M, D, 0, s);
-          CHECK(hirest_split2_bf16(h, D, a2, 2 * D, M, D, 0, stream)); }
+        if (g_x3_attention != 0) {
+            HirestProfScope pr(HIREST_PROF_LAYERNORM, 11, M, D, 0, s);
+            CHECK(hirest_split2_bf16(h, D, a2, 2 * D, M, D, 0, stream));
+        }
         CHECK(gemm_x3(a2, 2 * D, w2.proj_w2, 2 * D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_F32, stream));
         { HirestProfScope pr(HIREST_PROF_LAYERNORM, 10, M, D, 0, s);
           CHECK(hirest_layernorm_split2(x, D, w.ln2_g, w.ln2_b, f->ln_eps, a2, 2 * D, M, D, stream)); }

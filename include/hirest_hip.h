@@ -374,6 +374,9 @@ int hirest_layernorm_split2(const float* x, int64_t ldx, const float* gamma, con
  * (vit_model.py:127-147; no mask).  dh % 4 == 0, dh <= 96; pointers 16-B aligned. */
 int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int32_t B, int32_t Tq,
                             int32_t Tk, int32_t H, int32_t dh, float scale, void* stream);
+/* the same with the output stored as the split operand [B * Tq, 2 * H * dh] bf16 of the GEMM that follows ((H * dh) % 32 == 0) */
+int hirest_attention_x3_qkv_split2(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, hirest_bf16* out2, int32_t B,
+                                   int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, void* stream);
 /* A/B and tests: bit 0 = the tower's attention is the exact-fp32 hirest_attention_f32_qkv instead of hirest_attention_x3_qkv; bit 1 = fc1 writes fp32
  * and GELU + split run as a separate pass (hirest_split2_bf16) instead of in its epilogue (HIREST_EPI_BIAS_GELU_SPLIT2).  Default 0. */
 int hirest_vision_x3_select_attention(int32_t which);

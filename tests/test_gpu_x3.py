@@ -186,6 +186,11 @@ def test_attention_x3_against_fp64(dev, B, T, H, dh):
     err32 = (f32.double() - ref).abs().max().item() / ref.abs().max().item()
     print(f"attention x3 B={B} T={T} H={H} dh={dh}: max err / max |ref| {err:.2e} (exact-fp32 kernel: {err32:.2e})")
     assert torch.isfinite(out).all() and err < 3e-5
+    if D % 32 == 0:                                                    # the split-operand output == split of the fp32 output, bit for bit
+        out2 = torch.empty((B * T, 2 * D), dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.hirest_attention_x3_qkv_split2(qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, out2.data_ptr(), B, T,
+                                                      T, H, dh, scale, ops.stream_ptr()), "hirest_attention_x3_qkv_split2")
+        assert torch.equal(out2.view(torch.int16), ops.split2(out).view(torch.int16))
 
 
 def test_x3_tower_attention_ab(dev, golden_dir):
