@@ -239,6 +239,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="A/B: no per-launch hipEvent pairs inside the timed region (the line then "
                     "carries no roofline; profiles/r04/README.md holds the comparison)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the joint-model / captioning / training / ASR figures")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="nccl = RCCL over xGMI (the measured path); gloo: functional tests")
+    ap.add_argument("--share-gpu", action="store_true", help="FUNCTIONAL TEST ONLY (needs --backend gloo): rank r runs on device r %% device_count, "
+                    "so the N-rank code path — launcher, timing protocol, gather, rank-0 report — runs on a one-GPU box.  The line is marked INVALID")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="hirest_gemm_debug_mode bits: TIMING EXPERIMENTS ONLY, the line is not a valid result")
     args = ap.parse_args()
 
@@ -247,12 +250,16 @@ def main():
                          "in frames/s without being encoded")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    launch.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], visible_devices=torch.cuda.device_count())
+    if args.share_gpu and args.backend != "gloo":
+        raise SystemExit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+    launch.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:],
+                        visible_devices=None if args.share_gpu else torch.cuda.device_count())
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    rank, local_rank, world = launch.init_ranks(args.gpus, "nccl", device=dev)   # "nccl" is RCCL on ROCm
+    rank, local_rank, world = launch.init_ranks(args.gpus, args.backend, device=dev)   # "nccl" is RCCL on ROCm
     assert world == args.gpus and (world == 1 or dist.get_world_size() == args.gpus)
 
     import hirest_amd
@@ -370,6 +377,8 @@ def main():
                "roofline": roofline}
         if args.no_profile:
             out["profile"] = "off (--no-profile: no per-launch event pairs in the timed region, hence no roofline in this line)"
+        if args.share_gpu or args.backend != "nccl":
+            out["INVALID"] = f"functional run of the N-rank path: backend {args.backend}" + (", ranks sharing the GPU(s)" if args.share_gpu else "")
         if args.gemm_dbg & ~512:                       # bit 9 only switches the kernels' walk direction off (A/B), results unchanged
             out["INVALID"] = f"timing experiment: hirest_gemm_debug_mode({args.gemm_dbg})"
 

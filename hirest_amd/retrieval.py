@@ -85,13 +85,17 @@ class RowGather:
         per = (n_total + world - 1) // world
         if local.shape[0] > per:
             raise RuntimeError(f"gather_rows: {local.shape[0]} local rows > ceil({n_total}/{world}) = {per}")
-        send, recv = self._buffers(per, tuple(local.shape[1:]), local.dtype, local.device, world)
-        if local.shape[0] == per and local.is_contiguous():
+        # gloo has no all-gather on device tensors: stage through the host (functional runs of the multi-rank path on a box without
+        # RCCL peers, e.g. two ranks sharing one GPU in tests/test_run_corpus.py; production is "nccl" = RCCL, device to device)
+        staged = local.is_cuda and dist.get_backend(self.group) == "gloo"
+        dev = torch.device("cpu") if staged else local.device
+        send, recv = self._buffers(per, tuple(local.shape[1:]), local.dtype, dev, world)
+        if local.shape[0] == per and local.is_contiguous() and not staged:
             send = local                                   # full block: gather straight from the caller's tensor
         else:
             send[: local.shape[0]].copy_(local)            # the last rank's short block; the pad rows stay zero
         dist.all_gather_into_tensor(recv, send, group=self.group)
-        return recv[:n_total]
+        return recv[:n_total].to(local.device) if staged else recv[:n_total]
 
 
 _default_gather: Dict[object, RowGather] = {}

@@ -87,3 +87,25 @@ def test_bench_rejects_partial_videos():
         pytest.skip("needs a GPU")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--frames", "100"], capture_output=True, text=True, timeout=300, cwd=REPO)
     assert r.returncode != 0 and "multiple of 32" in r.stderr
+
+
+def test_bench_two_rank_path_runs_on_one_gpu_over_gloo():
+    """The N-rank code path of bench.py — self-launch under torch.distributed.run, per-rank model and frames, timed_steps' barrier + MAX
+    over ranks, RowGather of the pooled rows, replicated ranking, rank-0 JSON line — as two processes sharing this box's GPU over gloo
+    (RCCL refuses two ranks on one device).  Functional only: the line says so (INVALID) and its value is not a 2-GPU result."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1",
+                        "--frames", "64", "--chunk", "64", "--no-cpu-baseline", "--no-matched-recall", "--no-secondary"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]     # whole-job frames / max-over-ranks time
+    assert "functional run" in d["INVALID"] and d["roofline"]["launches"] > 0

@@ -259,3 +259,30 @@ def test_gpu_c3_eight_rank_blocks_equal_the_single_sweep():
         json.dump({key: digest}, f)
     assert key in known, f"no committed digest for {key}: copy gpurun_out/c3_rank_blocks_digest.json into {C3_HASHES}"
     assert known[key] == digest
+
+
+@pytest.mark.gpu
+def test_gpu_two_rank_driver_on_one_gpu_equals_one_rank(tmp_path):
+    """tools/c3_run.py as TWO PROCESSES (launcher, shard_range blocks, RowGather, replicated text tower + ranking, cross-rank agreement
+    check) against the same script as one process: identical SHA-256 of the gathered [V, E] rows and of the top-10 table.  The two ranks
+    share the one GPU of a test box and gather through gloo (RCCL refuses two ranks on one device) — the transport is the only part of
+    the 8-GPU command (`python tools/c3_run.py --gpus 8`) this run does not exercise."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "c3_run.py")
+    common = [sys.executable, tool, "--model", "tiny", "--videos", "64", "--frames", "4", "--block", "16"]   # 64-frame tower calls on every rank
+    reports = {}
+    for n in (1, 2):
+        out = str(tmp_path / f"c3_{n}.json")
+        extra = ["--gpus", "2", "--backend", "gloo", "--share-gpu"] if n == 2 else []
+        env = dict(os.environ)
+        env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+        r = subprocess.run(common + extra + ["--out", out], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        reports[n] = json.load(open(out))
+    one, two = reports[1], reports[2]
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["backend"] == "gloo" and two["all_ranks_hold_the_same_rows_and_ranking"]
+    assert (two["pooled_sha256"], two["top10_sha256"]) == (one["pooled_sha256"], one["top10_sha256"])
+    assert two["result_dict"] == one["result_dict"] and two["result_dict"]["videos_per_prompt"] == 64

@@ -33,17 +33,24 @@ def main():
     ap.add_argument("--rank-blocks", type=int, default=0, help="1 rank only: also encode the corpus as this many rank blocks")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--out", default=None, help="also write the report to this path")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="nccl = RCCL (one rank per GPU); gloo = host-staged gather")
+    ap.add_argument("--share-gpu", action="store_true", help="FUNCTIONAL TEST ONLY: all ranks on the GPUs that exist (rank r on device r %% "
+                    "device_count; needs --backend gloo: RCCL refuses two ranks on one device).  Exercises the multi-process driver — launcher, "
+                    "shard, gather, replicated ranking, digest check — on a one-GPU box; its frames/s is not an N-GPU result and is labelled so")
+    ap.add_argument("--model", default="g14", choices=("g14", "tiny"), help="tiny = the 2-layer test config (functional runs)")
     a = ap.parse_args()
     import torch
-    launch.ensure_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:], visible_devices=torch.cuda.device_count())
+    if a.share_gpu and a.backend != "gloo":
+        raise SystemExit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+    launch.ensure_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:], visible_devices=None if a.share_gpu else torch.cuda.device_count())
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if a.share_gpu else local_rank)
     torch.cuda.set_device(dev)
-    rank, _, world = launch.init_ranks(a.gpus, "nccl", dev)
+    rank, _, world = launch.init_ranks(a.gpus, a.backend, dev)
     import torch.distributed as dist
     import hirest_amd
     from hirest_amd import retrieval, synth
-    model = hirest_amd.EVA_CLIP(**synth.EVA_CLIP_G_14).to(dev).eval()
+    model = hirest_amd.EVA_CLIP(**(synth.EVA_CLIP_G_14 if a.model == "g14" else synth.EVA_CLIP_TINY)).to(dev).eval()
     model.init_random_(seed=1234)
     model.set_precision(a.precision)
     prompts = json.load(open(os.path.join(REPO, "tests", "golden", "test_prompts.json")))
@@ -54,7 +61,7 @@ def main():
     def sync():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev.index]) if a.backend == "nccl" else dist.barrier()
 
     sync()
     t0 = time.perf_counter()
@@ -63,13 +70,13 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank must hold the same gathered matrix and the same ranking
         mine = torch.tensor([int(x, 16) % (1 << 62) for x in (retrieval.corpus_digest(res.video_rows, idx)["pooled_sha256"][:15],
                                                                retrieval.corpus_digest(res.video_rows, idx)["top10_sha256"][:15])],
-                            dtype=torch.int64, device=dev)
+                            dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
         all_d = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(all_d, mine)
         ranks_agree = all(torch.equal(d, all_d[0]) for d in all_d)
@@ -78,12 +85,14 @@ def main():
     report = None
     if rank == 0:
         digest = retrieval.corpus_digest(res.video_rows, idx)
-        key = f"V{a.videos}_F{a.frames}_torch{torch.__version__}"
+        key = f"V{a.videos}_F{a.frames}_torch{torch.__version__}" + ("" if a.model == "g14" else f"_{a.model}")
         known_path = os.path.join(REPO, "tests", "golden", "c3_rank_blocks.json")
         known = json.load(open(known_path)) if os.path.isfile(known_path) else {}
         top2 = res.scores.topk(2, dim=1).values
         report = {
-            "workload": f"{a.videos} videos x {a.frames} frames, {len(prompts)} queries, EVA-CLIP-g/14 {a.precision}, {world} rank(s)",
+            "workload": f"{a.videos} videos x {a.frames} frames, {len(prompts)} queries, EVA-CLIP-{a.model} {a.precision}, {world} rank(s)"
+                        + (", ranks SHARING the GPU(s) over gloo: functional run, not an N-GPU result" if a.share_gpu else ""),
+            "backend": a.backend,
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "frames": a.videos * a.frames, "seconds_incl_input_generation": elapsed,
             "frames_per_s_incl_input_generation": a.videos * a.frames / elapsed,
