@@ -337,7 +337,8 @@ def main():
                 same_tag = [e for e in breakdown if e["kernel"] == "gemm" and e["tag"] == dom["tag"]
                             and e["launches"] == dom["launches"]]
                 same_tag.sort(key=lambda e: -e["dims"][0] * e["dims"][2])            # more operand bytes first
-                cands = [k for k in prof["kernels"] if (f"gemm_p256<{dom['tag']}," in k["kernel"] or f"gemm_pp256<{dom['tag']}>" in k["kernel"] or f"gemm_pp256<{dom['tag']}," in k["kernel"])
+                cands = [k for k in prof["kernels"] if (f"gemm_p256<{dom['tag']}," in k["kernel"] or f"gemm_pp256<{dom['tag']}>" in k["kernel"] or f"gemm_pp256<{dom['tag']}," in k["kernel"]
+                                                          or f"gemm_pq256<{dom['tag']}>" in k["kernel"])
                          and k["launches"] * args.steps in (dom["launches"], dom["launches"] - args.steps)]
                 cands.sort(key=lambda k: -k["fetch_bytes_per_launch"])
                 which = same_tag.index(dom)

@@ -997,7 +997,19 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
 // 64-deep step of the ring holds hi and lo of BOTH operands for 32 real k, and a phase issues three MFMA groups on the fragments
 // it has already read — W_hi A_lo, W_lo A_hi, W_hi A_hi (small terms first; W_lo A_lo, 2^-16 of the product, is dropped) —
 // instead of two: 1.5 x the matrix work per LDS byte of the plain kernel, nothing else changes (same ring, barriers, epilogues).
-template <int EPI, int RD, bool X3>
+// PH2 (round 4): TWO phases per 64-deep step instead of four — Q1 = (a0; b0, b1), Q2 = (a1; b1, b0), 32 MFMAs each (48 with X3) — on the same
+// ring, fragments and DMA pieces.  Why: the X3 form showed that a phase pair costs ~544 cycles + its MFMA issue time whatever the MFMA count
+// (DESIGN 4.1f), i.e. a per-phase cost (two workgroup barriers, the LDS round trip of the phase's fragments, the MFMA pipe's fill) that
+// longer phases amortise.  Differences from the four-phase schedule: a phase's fragment reads are RETIRED (lgkmcnt(0)) before its first
+// barrier — they run under the other group's 32 MFMAs — so a region may be refilled in the very next LOAD of either group:
+//     Q1 LOAD(g): wait own a1(g) pieces [vmcnt(6)] | read a0, b0, b1 of slot g & 1 | issue a1(g + 1) (pending group) | lgkmcnt(0)
+//     Q2 LOAD(g): wait own a0 / b0 / b1(g + 1) pieces [vmcnt(2)] | read a1 | issue a0, b0, b1 of step g + 2 into slot g & 1 | lgkmcnt(0)
+//   RAW  a wave's counted wait for the pieces of a group lies one LOAD before the LOAD that reads the group; every reader passes at least
+//        one barrier in between at which the other group had executed that wait (hardware barrier k pairs group 0's k-th with group 1's
+//        (k - 1)-th: group 0's Q1 LOAD(g) follows hardware barrier 4 g - 1, group 1's Q2 LOAD(g - 1) — its wait — precedes it).
+//   WAR  reads of LOAD(p) are retired before that phase's first barrier; the refill is issued in LOAD(p + 1), which for group 0 follows
+//        hardware barrier 2 p + 1 (group 1's LOAD(p) precedes it) and for group 1 follows 2 p + 2.
+template <int EPI, int RD, bool X3, bool PH2 = false>
 __device__ __forceinline__ void pp256_body(const GemmP& p) {
     constexpr int NI = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1172,7 +1184,45 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
 #pragma unroll
                 for (int jn = 0; jn < NI; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (active) {
+        if (active && PH2) {
+            for (int t = 0; t < nst; ++t, ++g) {
+                const char* cur = smem + (g & 1) * Q_STEP;
+                // ---- Q1 (a0; b0, b1)
+                HX_WAIT_VM(6);
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(cur, 0); read_w(cur, 0, W0); read_w(cur, 1, W1);
+                if (a1_valid) issue_a1_pending();
+                HX_WAIT_LGKM0();
+                bar();
+                mfma_q(0, 0, W0);
+                mfma_q(0, 1, W1);
+                bar();
+                // ---- Q2 (a1; b1, b0)
+                HX_WAIT_VM(2);
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(cur, 1);
+                issue_a0(); issue_w(0); issue_w(1);
+                advance();
+                a1_valid = true;
+                HX_WAIT_LGKM0();
+                bar();
+                mfma_q(1, 1, W1);
+                mfma_q(1, 0, W0);
+                bar();
+            }
+            epilogue_p<EPI, NI, false, 8, RD>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
+        } else if (PH2) {
+            for (int t = 0; t < nst; ++t, ++g) {             // the same wait / DMA / barrier skeleton for a wave in the padding of an edge tile
+                HX_WAIT_VM(6);
+                if (a1_valid) issue_a1_pending();
+                bar(); bar();
+                HX_WAIT_VM(2);
+                issue_a0(); issue_w(0); issue_w(1);
+                advance();
+                a1_valid = true;
+                bar(); bar();
+            }
+        } else if (active) {
             for (int t = 0; t < nst; ++t, ++g) {
                 const char* cur = smem + (g & 1) * Q_STEP;
                 // ---- P1 (a0,b0): wait b1(g); read a0, b0; refill a1 of step g+1 (its rows were last read in P3 of step g-1)
@@ -1237,12 +1287,21 @@ template <int EPI, int RD = 1>
 __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) { pp256_body<EPI, RD, false>(p); }
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp256x3(GemmP p) { pp256_body<EPI, 1, true>(p); }
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, 1, false, true>(p); }      // two-phase schedule (PH2)
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pq256x3(GemmP p) { pp256_body<EPI, 1, true, true>(p); }
 
-template <int EPI, int RD = 1, bool X3 = false>
+template <int EPI, int RD = 1, bool X3 = false, bool PH2 = false>
 int launch_pp256(GemmP p, hipStream_t s) {
     static HirestDevCfg cfg;
     int cus = 0;
-    auto kern = [] { if constexpr (X3) return gemm_pp256x3<EPI>; else return gemm_pp256<EPI, RD>; }();
+    auto kern = [] {
+        if constexpr (X3 && PH2) return gemm_pq256x3<EPI>;
+        else if constexpr (X3) return gemm_pp256x3<EPI>;
+        else if constexpr (PH2) return gemm_pq256<EPI>;
+        else return gemm_pp256<EPI, RD>;
+    }();
     constexpr int LDS = 2 * Q_STEP + 8 * p_stg_bytes(EPI);
     if (int e = hirest_configure(kern, LDS, cfg, &cus)) return e;
     p.nbm = (p.M + T_BM - 1) / T_BM; p.nbn = (p.N + T_BN - 1) / T_BN;
@@ -1330,19 +1389,24 @@ int launch_fused(const GemmP& p, hipStream_t s) {
     if (!big || !p.aux0 || !p.aux1) return !big ? HIREST_E_SHAPE : HIREST_E_BADARG;
     if (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
     GemmP q = p; q.dbg = 0;
-    if (p.K >= 4096 && g_force_kernel != 6) return launch_pp256<EPI>(q, s);
-    return launch_p256_impl<EPI, 64, false>(q, s);
+    // default since round 4: the two-phase ping-pong kernel (pq256) on every shape — 1-3.3 % faster than p256 (K = 1408) / pp256 (K = 6144),
+    // same bits; 6 / 8 select those for A/B
+    if (g_force_kernel == 6) return launch_p256_impl<EPI, 64, false>(q, s);
+    if (g_force_kernel == 8) return launch_pp256<EPI>(q, s);
+    return launch_pp256<EPI, 1, false, true>(q, s);
 }
 
 
 template <int EPI>
 int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
-    // long-K shapes (fc2: K = 6144, A streaming from HBM) run 4-5 % faster on the ping-pong kernel, K = 1408 shapes do not
-    if (g_force_kernel == 0 && big && p.K >= 4096) return launch_pp256<EPI>(p, s);
-    if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);
+    // large problems: the two-phase ping-pong kernel (round 4; p256 / pp256 stay selectable: 6 / 8)
+    constexpr bool has_dbg_inst = EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_RESID_F32;
+    if (g_force_kernel == 0 && big && !(p.dbg && has_dbg_inst)) return launch_pp256<EPI, 1, false, true>(p, s);
+    if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);      // (timing-experiment bits exist in p256 only)
     if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
     if (g_force_kernel == 8) return launch_pp256<EPI>(p, s);
+    if (g_force_kernel == 9) return launch_pp256<EPI, 1, false, true>(p, s);
     if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
@@ -1359,7 +1423,7 @@ extern "C" int hirest_gemm_debug_mode(int32_t bits) { g_gemm_dbg = bits; return 
 extern "C" int hirest_gemm_select_kernel(int32_t which) {
     // 9..17 were the 4-wave kernel gemm_w4 and its schedule experiments (round 2; 3-7 % slower than p256 / pp256 on every shape, retired in
     // round 3), 18..20 the two-workgroup kernel gemm_d2 (round 3; 5-34 % slower, retired in round 4): DESIGN 4.1c / 4.1d, git history.
-    if (which < 0 || which > 8) return HIREST_E_BADARG;
+    if (which < 0 || which > 9) return HIREST_E_BADARG;      // 9: the persistent ping-pong kernel with two phases per step (pq256)
     g_force_kernel = which;
     return 0;
 }
@@ -1374,19 +1438,19 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (epi < 0 || epi > HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
     if (a->flags & HIREST_GEMM_X3) {
         if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32 && epi != HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
-        snprintf(out, out_len, "gemm_pp256x3<%d>", epi);
+        snprintf(out, out_len, g_force_kernel == 9 ? "gemm_pq256x3<%d>" : "gemm_pp256x3<%d>", epi);
         return 0;
     }
     if (epi == HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;      // exists in the X3 form only
     const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
-    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
+    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x10000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
-    if (fused) {
-        if (a->K >= 4096 && f != 6) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
+    if (f == 9 || (fused && f != 6 && f != 8) || (!fused && f == 0 && big && !dbg_inst)) snprintf(out, out_len, "gemm_pq256<%d>", epi);
+    else if (fused) {
+        if (f == 8) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
         else snprintf(out, out_len, "gemm_p256<%d, 64, false, 1>", epi);
-    } else if (f == 0 && big && a->K >= 4096) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
-    else if (f == 6 || (f == 0 && big)) snprintf(out, out_len, "gemm_p256<%d, 64, %s, 1>", epi, dbg_inst ? "true" : "false");
+    } else if (f == 6 || (f == 0 && big)) snprintf(out, out_len, "gemm_p256<%d, 64, %s, 1>", epi, dbg_inst ? "true" : "false");
     else if (f == 7) snprintf(out, out_len, "gemm_p256<%d, 128, false, 1>", epi);
     else if (f == 8) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
     else if (f == 5) snprintf(out, out_len, "gemm_t256q<%d>", epi);
@@ -1419,11 +1483,15 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     HirestProfScope prof(HIREST_PROF_GEMM, a->epilogue, a->M, a->N, a->K, s);
     if (a->flags & HIREST_GEMM_X3) {                  // split-operand products: the ping-pong kernel's X3 form, fp32 outputs only
         switch (a->epilogue) {
-            case HIREST_EPI_BIAS_F32: return launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);
-            case HIREST_EPI_BIAS_RESID_F32: return launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true>(p, s);
+            case HIREST_EPI_BIAS_F32:
+                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_F32, 1, true, true>(p, s) : launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);
+            case HIREST_EPI_BIAS_RESID_F32:
+                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true, true>(p, s)
+                                           : launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true>(p, s);
             case HIREST_EPI_BIAS_GELU_SPLIT2:
                 if (a->N % 32 != 0 || a->ldo < 2 * (int64_t)a->N || a->ldo % 8 != 0) return HIREST_E_SHAPE;
-                return launch_pp256<HIREST_EPI_BIAS_GELU_SPLIT2, 1, true>(p, s);
+                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_GELU_SPLIT2, 1, true, true>(p, s)
+                                           : launch_pp256<HIREST_EPI_BIAS_GELU_SPLIT2, 1, true>(p, s);
             default: return HIREST_E_BADARG;
         }
     }

@@ -131,7 +131,8 @@ int run_block_lnfold_cls(const hirest_block_weights& w, float* x, hirest_bf16* h
 extern "C" int hirest_abi_version(void) { return HIREST_ABI_VERSION; }
 
 extern "C" const char* hirest_build_info(void) {
-    return "hirest_hip gfx950 (CDNA4) | gemm p256 (persistent, 16x16x32 bf16 MFMA) / t128 + LDS-DMA | attention 16x16x32 bf16 MFMA + tr16 reads | " __VERSION__;
+    return "hirest_hip gfx950 (CDNA4) | gemm pq256 (persistent ping-pong, 2 phases per K step, 16x16x32 bf16 MFMA) / p256 / t128 + LDS-DMA | "
+           "bf16x3 split-operand GEMM + attention | attention 16x16x32 bf16 MFMA + tr16 reads | " __VERSION__;
 }
 
 extern "C" size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B) {

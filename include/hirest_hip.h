@@ -104,7 +104,8 @@ int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
 /* Kernel selection for tests / A-B timing: 0 = automatic (default), 1 = force the 128x128 kernel,
  * 2 / 3 = the 256x256 ping-pong kernel with a 4- / 5-slot LDS ring, 4 = t256p (32-deep slabs), 5 = t256q
  * (64-deep steps), 6 / 7 = the persistent 256x256 kernel with 8 / 4 waves, 8 = the persistent ping-pong kernel (default for
- * K >= 4096).  9..17 (the 4-wave kernel of round 2) and 18..20 (the two-workgroup kernel gemm_d2 of round 3) are retired and rejected.
+ * K >= 4096), 9 = that kernel with two phases of 32 MFMAs per 64-deep step instead of four of 16 (pq256; also selects the two-phase form of the
+ * HIREST_GEMM_X3 kernel).  10..17 (the 4-wave kernel of round 2) and 18..20 (the two-workgroup kernel gemm_d2 of round 3) are retired and rejected.
  * Results are identical for every valid selection (same k order per output element). */
 int hirest_gemm_select_kernel(int32_t which);
 /* TIMING EXPERIMENTS ONLY (results become wrong): bit0 = skip the main-loop LDS-DMA, bit1 = skip the

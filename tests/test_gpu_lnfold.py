@@ -16,7 +16,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[0], ids=["auto"])
+@pytest.fixture(params=[0, 9], ids=["auto", "pq256"])
 def fused_kernel(request):
     """The LN-fold epilogues exist in the persistent kernels: the default dispatch (p256 / pp256; the two-workgroup kernel gemm_d2 of round 3 is retired)."""
     from hirest_amd import ops

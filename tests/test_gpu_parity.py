@@ -53,7 +53,7 @@ def cos_rows(a, b):
 # ----------------------------------------------------------------------------------------
 # kernels
 # ----------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8], ids=["t128", "t256x4", "t256x5", "t256p", "t256q", "p256w8", "p256w4", "pp256"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9], ids=["t128", "t256x4", "t256x5", "t256p", "t256q", "p256w8", "p256w4", "pp256", "pq256"])
 def gemm_kernel(request, ops):
     ops.gemm_select_kernel(request.param)
     yield request.param
