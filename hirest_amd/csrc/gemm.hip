@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
 //        (k - 1)-th: group 0's Q1 LOAD(g) follows hardware barrier 4 g - 1, group 1's Q2 LOAD(g - 1) — its wait — precedes it).
 //   WAR  reads of LOAD(p) are retired before that phase's first barrier; the refill is issued in LOAD(p + 1), which for group 0 follows
 //        hardware barrier 2 p + 1 (group 1's LOAD(p) precedes it) and for group 1 follows 2 p + 2.
-template <int EPI, int RD, bool X3, bool PH2 = false>
+template <int EPI, int RD, bool X3, int PH2 = 0>      // PH2: 0 four phases per step, 1 two phases (issuing the LDS-DMA before the fragment reads
+                                                      // of a LOAD instead of after them measured 0.3-0.7 % slower: not kept)
 __device__ __forceinline__ void pp256_body(const GemmP& p) {
     constexpr int NI = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1288,11 +1289,12 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) { pp256_body<EPI, RD,
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp256x3(GemmP p) { pp256_body<EPI, 1, true>(p); }
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, 1, false, true>(p); }      // two-phase schedule (PH2)
+__global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, 1, false, 1>(p); }      // two-phase schedule (PH2)
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pq256x3(GemmP p) { pp256_body<EPI, 1, true, true>(p); }
+__global__ __launch_bounds__(512) void gemm_pq256x3(GemmP p) { pp256_body<EPI, 1, true, 1>(p); }
 
-template <int EPI, int RD = 1, bool X3 = false, bool PH2 = false>
+
+template <int EPI, int RD = 1, bool X3 = false, int PH2 = 0>
 int launch_pp256(GemmP p, hipStream_t s) {
     static HirestDevCfg cfg;
     int cus = 0;
@@ -1393,7 +1395,7 @@ int launch_fused(const GemmP& p, hipStream_t s) {
     // same bits; 6 / 8 select those for A/B
     if (g_force_kernel == 6) return launch_p256_impl<EPI, 64, false>(q, s);
     if (g_force_kernel == 8) return launch_pp256<EPI>(q, s);
-    return launch_pp256<EPI, 1, false, true>(q, s);
+    return launch_pp256<EPI, 1, false, 1>(q, s);
 }
 
 
@@ -1402,11 +1404,11 @@ int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
     // large problems: the two-phase ping-pong kernel (round 4; p256 / pp256 stay selectable: 6 / 8)
     constexpr bool has_dbg_inst = EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_RESID_F32;
-    if (g_force_kernel == 0 && big && !(p.dbg && has_dbg_inst)) return launch_pp256<EPI, 1, false, true>(p, s);
+    if (g_force_kernel == 0 && big && !(p.dbg && has_dbg_inst)) return launch_pp256<EPI, 1, false, 1>(p, s);
     if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);      // (timing-experiment bits exist in p256 only)
     if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
     if (g_force_kernel == 8) return launch_pp256<EPI>(p, s);
-    if (g_force_kernel == 9) return launch_pp256<EPI, 1, false, true>(p, s);
+    if (g_force_kernel == 9) return launch_pp256<EPI, 1, false, 1>(p, s);
     if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
@@ -1484,13 +1486,13 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     if (a->flags & HIREST_GEMM_X3) {                  // split-operand products: the ping-pong kernel's X3 form, fp32 outputs only
         switch (a->epilogue) {
             case HIREST_EPI_BIAS_F32:
-                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_F32, 1, true, true>(p, s) : launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);
+                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_F32, 1, true, 1>(p, s) : launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);
             case HIREST_EPI_BIAS_RESID_F32:
-                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true, true>(p, s)
+                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true, 1>(p, s)
                                            : launch_pp256<HIREST_EPI_BIAS_RESID_F32, 1, true>(p, s);
             case HIREST_EPI_BIAS_GELU_SPLIT2:
                 if (a->N % 32 != 0 || a->ldo < 2 * (int64_t)a->N || a->ldo % 8 != 0) return HIREST_E_SHAPE;
-                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_GELU_SPLIT2, 1, true, true>(p, s)
+                return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_GELU_SPLIT2, 1, true, 1>(p, s)
                                            : launch_pp256<HIREST_EPI_BIAS_GELU_SPLIT2, 1, true>(p, s);
             default: return HIREST_E_BADARG;
         }
