@@ -27,4 +27,15 @@ timeout 300 python tools/gemm_f32_sweep.py 2>&1 | grep -v amdgpu.ids > $out/gemm
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_f32_peak_probe tools/probes/mfma_f32_peak_probe.hip && timeout 120 /tmp/mfma_f32_peak_probe > $out/mfma_f32_peak_probe.txt 2>&1
 for b in 5 3; do timeout 300 python tools/caption_batch_breakdown.py $b 2>&1 | tail -1; done > $out/caption_batch_breakdown.txt
 bash tools/train_prof.sh > $out/train_prof.log 2>&1; cp gpurun_out/train/train_kernel_stats.csv $out/rocprofv3_kernel_stats_train_step.csv
+# round 4: the bf16x3 tower (per-kernel breakdown + SQ counters), the profile-instrumentation A/B, captioning with batches in flight, the
+# grid-barrier probe, configs[2] at 512 x 32 with its 8-rank-block invariance
+timeout 300 python tools/x3_bench.py > $out/x3_bench.json 2> /dev/null
+bash tools/pmc_sq.sh $out/pmcx3 "gemm_pp256x3|attention_x3|attention_f32|split2" -- python $GRAFT_REPO_ROOT/tools/x3_bench.py --frames 512 --steps 1 > $out/pmc_x3_kernels.txt 2>&1
+python tools/pmc_summary.py $out/pmc_x3_kernels.txt > $out/pmc_table_x3.md; rm -rf $out/pmcx3
+for i in 1 2; do for f in "" "--no-profile"; do timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-matched-recall --no-secondary $f 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('bench.py $f:', round(d['value'], 1), 'frames/s', round(d['ms_per_step'], 2), 'ms per step')"; done; done > $out/no_profile_ab.txt 2>&1
+timeout 400 python tools/caption_streams_sweep.py 2>&1 | grep -v amdgpu.ids > $out/caption_streams_sweep.txt
+hipcc --offload-arch=gfx950 -O2 -w -o /tmp/gbp tools/probes/grid_barrier_probe.hip && timeout 120 /tmp/gbp > $out/grid_barrier_probe.txt 2>&1
+timeout 300 python tools/c3_run.py --videos 512 --rank-blocks 8 --out $out/c3_512_rank_blocks.json > /dev/null 2>&1
 date +%s > $out/collected_at
