@@ -96,7 +96,7 @@ def matched_recall(model, dev):
         from hirest_amd import _lib as _l
         lib = _l.load()
         model.set_precision("bf16x3")
-        retrieval.encode_videos(model, frames[:16])                   # warm-up: weight split (once), workspace
+        retrieval.encode_videos(model, frames)                        # warm-up at full size: weight split (once), the 17-GB workspace
         torch.cuda.synchronize()
         lib.hirest_profile_enable(1)
         t0 = time.perf_counter()
