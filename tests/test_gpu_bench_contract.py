@@ -45,6 +45,13 @@ def test_bench_line_contract():
     # the reference-precision towers (precision='fp32') reproduce the reference's ranks; their speed is a separate figure
     p32 = mr["precision_fp32"]
     assert p32["top1_flips"] == 0 and p32["matched_R@1"] == 100.0 and p32["max_abs_score_error"] < 2e-5 and p32["frames_per_s"] > 10
+    # precision='bf16x3': the reference's ranks from split-operand products, with its own roofline line (peak / 3: three MFMAs per product)
+    x3 = mr["precision_bf16x3"]
+    assert x3["top1_flips"] == 0 and x3["matched_R@1"] == 100.0 and x3["max_abs_score_error"] < 5e-6 and x3["top10_lists_identical"] >= 540
+    assert x3["frames_per_s"] > 2 * p32["frames_per_s"]
+    assert abs(x3["roofline"]["peak"] - 2500.0 / 3) < 1e-6 and 0.2 < x3["roofline"]["frac"] < 1.0
+    assert abs(x3["roofline"]["frac"] - x3["roofline"]["achieved"] / x3["roofline"]["peak"]) < 1e-12
+    assert rf["traffic_missing"] == (rf["traffic"] is None)
     # executed vs unpruned work (the last block serves x[:, 0] only): the tower fraction is priced on executed FLOPs
     assert rf["executed_gflop_per_frame"] < rf["unpruned_gflop_per_frame"] == 534.06
     assert abs(rf["whole_tower_frac"] - d["value"] * rf["executed_gflop_per_frame"] / 1e3 / 2500.0) < 1e-9
@@ -63,6 +70,9 @@ def test_bench_line_contract():
     assert sec["step_captioning_beam5"]["token_ids_equal_cpu_oracle_on_sample"]
     for beams in (3, 5):           # all five captions of the timed batch equal the REAL reference's (caption_predictions.json c3 / c5)
         assert sec[f"step_captioning_beam{beams}"]["token_ids_equal_real_reference"] == "5 of 5 captions"
+        pl = sec[f"step_captioning_beam{beams}_pipelined"]            # the same batch with four loader batches in flight
+        assert pl["unit"] == "captions/s" and pl["batches_in_flight"] == 4 and pl["token_ids_equal_real_reference"] == "60 of 60 captions"
+        assert pl["value"] > 0.9 * sec[f"step_captioning_beam{beams}"]["value"]
     assert sec["moment_retrieval"]["value"] > 38 and sec["moment_segmentation"]["value"] > 8 and sec["step_captioning_beam3"]["value"] > 48
 
 
