@@ -132,7 +132,7 @@ def evaluate_video_retrieval(gt_data, pred_data, prompt_to_cat: Optional[Dict[st
         _, idx = ops.topk(scores.contiguous(), kmax, retrieval.tie_rank_from_names(vids, device))
         idx = idx.cpu().tolist()
         for p, row in zip(members, idx):
-            gt_videos = set(gt[p].keys())
+            gt_videos = set(gt[p].keys()) if isinstance(gt[p], dict) else set(gt[p])     # (the split files hold {video: annotation} dicts)
             buckets = ["all"] + ([cat_of[p]] if prompt_to_cat is not None else [])
             for c in buckets:
                 total[c] += 1
