@@ -121,6 +121,10 @@ _SIGNATURES = {
     "hirest_gemm_dispatch_name": (C.c_int, [C.POINTER(GemmArgs), C.c_char_p, C.c_int32]),
     "hirest_attention_select_kernel": (C.c_int, [C.c_int32]),
     "hirest_attention_set_skew": (C.c_int, [C.c_int32]),
+    "hirest_attention_set_mapping": (C.c_int, [C.c_int32]),
+    "hirest_attention_set_pace": (C.c_int, [C.c_int32]),
+    "hirest_attention_set_stagger": (C.c_int, [C.c_int32]),
+    "hirest_attention_debug_trace_read": (C.c_int, [C.c_void_p, C.c_int32]),
     "hirest_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                    C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_attention_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -290,6 +294,8 @@ def load():
     if lib.hirest_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libhirest_hip.so ABI version {lib.hirest_abi_version()} != binding {ABI_VERSION}: rebuild with "
                            "`python -m hirest_amd.build --force`")
+    if os.environ.get("HIREST_ATTENTION_KERNEL"):      # A/B timing of the bf16 attention forms without touching the caller
+        check(lib.hirest_attention_select_kernel(int(os.environ["HIREST_ATTENTION_KERNEL"])), "HIREST_ATTENTION_KERNEL")
     _lib = lib
     return lib
 

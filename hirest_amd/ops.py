@@ -89,8 +89,16 @@ def gemm_select_kernel(which: int):
     _lib.check(_lib.load().hirest_gemm_select_kernel(int(which)), "hirest_gemm_select_kernel")
 
 
+ATTENTION_DEFAULT_KERNEL = 7     # persistent kernel + producer wave (include/hirest_hip.h: hirest_attention_select_kernel)
+
+
 def attention_select_kernel(which: int):
     _lib.check(_lib.load().hirest_attention_select_kernel(int(which)), "hirest_attention_select_kernel")
+
+
+def attention_set_mapping(by_head: bool):
+    """Persistent attention kernel: one head per workgroup over frames (True, default) or one frame per workgroup (False)."""
+    _lib.check(_lib.load().hirest_attention_set_mapping(int(bool(by_head))), "hirest_attention_set_mapping")
 
 
 @on_tensor_device

@@ -151,15 +151,34 @@ int hirest_attention_bf16_rows(const hirest_bf16* qkv, hirest_bf16* out,
                                int32_t B, int32_t N, int32_t H, int32_t dh,
                                float scale, int32_t causal, int32_t q_rows, void* stream);
 /* 1 = register-staged kernel with a transposed V image, 2 = LDS-DMA staging + hardware transpose reads, one workgroup
- * per (frame, head), 3 (default) = 2's arithmetic in one persistent workgroup per frame (used for 80 < N <= 272 tokens
- * and >= 64 frames; other shapes fall back to 2).  For tests / A-B timing. */
+ * per (frame, head), 3 = 2's arithmetic in one persistent workgroup per frame (nine waves; used for 80 < N <= 272 tokens
+ * and >= 64 frames; other shapes fall back to 2), 4 = 3 with twelve waves, 7 (default) = 3 with a tenth wave that issues all
+ * LDS-DMA (same bits as 3), 5 = 3 with the softmax on fewer VALU instructions (row sums taken from the P.V product through a
+ * column of ones in V's pad; last-bit differences from 3), 6 = 5 + the producer wave.  For tests / A-B timing. */
 int hirest_attention_select_kernel(int32_t which);
+/* Persistent kernel, which (frame, head) pairs a workgroup walks: 0 = one frame per workgroup, its heads in order; 1 (default) =
+ * one head per workgroup over frames b0, b0 + 16, ..., the 16 heads of two frames running on the 32 CUs of one XCD at the same time
+ * so that the 128-B lines two neighbouring heads' 176-B row slices share are L2 hits instead of second fetches (used when 32 % H
+ * == 0 and the batch is large enough; anything else takes mapping 0).  Per (frame, head) the arithmetic is the same: results are
+ * bit-identical. */
+int hirest_attention_set_mapping(int32_t by_head);
+/* Persistent kernel with a producer wave: ~64 * units cycles between two K pieces of the next step's K image (0 = one burst).
+ * Results are unchanged. */
+int hirest_attention_set_pace(int32_t units);
+/* Persistent kernel: the first workgroup of CU c starts ~64 * units * (c mod 16) cycles late, so that the CUs' per-step memory bursts
+ * do not coincide.  0 = off.  Results are unchanged. */
+int hirest_attention_set_stagger(int32_t units);
 /* Persistent kernel: park waves 4-7 (the second wave of each SIMD) for ~64 * units cycles after the per-head barrier, so that
  * their MFMA phases fall under the first wave's softmax (VALU) phase and vice versa.  0 = off.  Results are unchanged. */
 int hirest_attention_set_skew(int32_t units);
 /* TIMING EXPERIMENTS ONLY (results become wrong), persistent kernel: bit0 skip the S^T MFMAs, bit1 skip the softmax
- * exponentials, bit2 skip P.V, bit3 skip the K/V LDS-DMA.  0 restores normal operation. */
+ * exponentials, bit2 skip P.V, bit3 skip the K/V LDS-DMA, bit4 skip the output stores, bit5 skip the Q loads, bit6 / bit7 skip
+ * the per-head barriers B / A.  0 restores normal operation. */
 int hirest_attention_debug_mode(int32_t bits);
+/* Debug instantiation with bit8 of the mode set: workgroup 0 stamps the shader clock at 11 points of every step
+ * ([step < 64][wave < 12][slot < 12] int64; slots: 10 top of the step, 0 after barrier A, 1 / 5 tile start, 2 / 6 S^T issued, 3 / 7 softmax
+ * done, 4 / 8 V ready, 9 tiles done).  Copies the first n stamps to host memory (tools/attn_trace.py prints the phase table). */
+int hirest_attention_debug_trace_read(int64_t* dst, int32_t n);
 
 /* ------------------------------------------------------------------------------------
  * Patch extraction (im2col for Conv2d with kernel == stride == P, vit_model.py:198,205):

@@ -195,7 +195,7 @@ def _attention_ref(qkv, B, N, H, dh, causal):
                                                     (1, 257, 8, 88, False, 6.0), (2, 50, 12, 64, False, 1.0),
                                                     (1, 1, 2, 64, True, 1.0), (1, 272, 2, 64, False, 3.0),
                                                     (70, 257, 16, 88, False, 2.0), (66, 200, 4, 64, True, 1.0)])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["v1", "v2", "v3", "v3w12"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7], ids=["v1", "v2", "v3", "v3w12", "v3lean", "v3leanprod", "v3prod"])
 def test_attention(dev, ops, B, N, H, dh, causal, qscale, variant):
     ops.attention_select_kernel(variant)
     D = H * dh
@@ -205,9 +205,34 @@ def test_attention(dev, ops, B, N, H, dh, causal, qscale, variant):
     ref = _attention_ref(qkv, B, N, H, dh, causal)
     out = torch.full((B * N, D), 9.0, dtype=torch.bfloat16, device=dev)
     ops.attention(qkv.to(torch.bfloat16).to(dev), out, B, N, H, dh, causal)
-    ops.attention_select_kernel(3)
+    ops.attention_select_kernel(ops.ATTENTION_DEFAULT_KERNEL)
     # P is rounded to bf16 before P.V and the output is bf16: 2 roundings of <= 2^-8 relative to max|v|
     assert (out.cpu().double() - ref).abs().max().item() <= 3 * 2 ** -8 * qkv[:, 2 * D:].abs().max().item()
+
+
+@pytest.mark.parametrize("B,N,H,dh,q_rows", [(70, 257, 16, 88, 257), (128, 257, 16, 88, 1), (300, 100, 4, 64, 100), (97, 257, 8, 88, 33)])
+@pytest.mark.parametrize("variant", [3, 5, 6], ids=["v3", "v3lean", "v3prod"])
+def test_attention_by_head_mapping_is_bit_identical(dev, ops, B, N, H, dh, q_rows, variant):
+    """hirest_attention_set_mapping: one head per workgroup over frames == one frame per workgroup over heads (default), for batch
+    sizes that leave some workgroups a step short, and for the leading-rows form."""
+    from hirest_amd import _lib
+    D = H * dh
+    g = torch.Generator(device="cpu"); g.manual_seed(B + N)
+    qkv = torch.randn((B * N, 3 * D), generator=g).to(torch.bfloat16).to(dev)
+    outs = []
+    ops.attention_select_kernel(variant)
+    try:
+        for by_head in (False, True):
+            ops.attention_set_mapping(by_head)
+            out = torch.full((B * N, D), 9.0, dtype=torch.bfloat16, device=dev)
+            _lib.check(_lib.load().hirest_attention_bf16_rows(qkv.data_ptr(), out.data_ptr(), B, N, H, dh, dh ** -0.5, 0, q_rows,
+                                                              torch.cuda.current_stream().cuda_stream), "hirest_attention_bf16_rows")
+            outs.append(out.reshape(B, N, D)[:, :q_rows].clone())
+    finally:
+        ops.attention_select_kernel(ops.ATTENTION_DEFAULT_KERNEL)
+        ops.attention_set_mapping(False)
+    assert torch.equal(outs[0], outs[1])
+    assert bool(torch.isfinite(outs[1].float()).all()) and float(outs[1].float().abs().max()) < 9.0
 
 
 def test_embed_tokens_exact(dev, ops):

@@ -111,6 +111,7 @@ def _corpus_worker(rank, world, port, feat_dir, video_ids, prompts, n_frames, se
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    real_ops = retrieval.ops
     try:
         retrieval.ops = _OracleOps
         src = retrieval.FeatureFileSource(feat_dir, video_ids, videos_per_call=50)
@@ -118,6 +119,7 @@ def _corpus_worker(rank, world, port, feat_dir, video_ids, prompts, n_frames, se
         path = res.save(f"rank{rank}_of_{world}", out_dir)
         assert json.load(open(path)) == dict(res)
     finally:
+        retrieval.ops = real_ops        # (the 1-rank reference run is in this process: later GPU tests need the real kernels)
         if world > 1:
             dist.destroy_process_group()
 
