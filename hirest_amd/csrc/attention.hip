@@ -491,7 +491,9 @@ __global__ __launch_bounds__((NW + (PROD ? 1 : 0)) * 64) void attention_kernel_v
         }
         auto issue_k = [&](int st, char* dst, int pace_units) {
             const bf16_t* src = sbase(st) + D;
-            for (int it = 0; it < C::NK_INSTR / PER; ++it) {
+            for (int it0 = 0; it0 < C::NK_INSTR / PER; ++it0) {
+                // (head-per-workgroup mapping: the 16 workgroups of a frame would otherwise walk the same rows at the same time)
+                const int it = map ? (it0 + h0) % (C::NK_INSTR / PER) : it0;
 #pragma unroll
                 for (int j = 0; j < PER; ++j) {
                     const int row = prow[j] + 16 * it, r = row < N ? row : N - 1;
@@ -504,7 +506,8 @@ __global__ __launch_bounds__((NW + (PROD ? 1 : 0)) * 64) void attention_kernel_v
         };
         auto issue_v = [&](int st) {
             const bf16_t* src = sbase(st) + 2 * D;
-            for (int it = 0; it < C::NV_INSTR / PER; ++it) {
+            for (int it0 = 0; it0 < C::NV_INSTR / PER; ++it0) {
+                const int it = map ? (it0 + h0) % (C::NV_INSTR / PER) : it0;
 #pragma unroll
                 for (int j = 0; j < PER; ++j) {
                     const int row = prow[j] + 16 * it, r = row < N ? row : N - 1;
