@@ -56,8 +56,14 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, int m, int n, f32
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) {
+// X3 (split operands, see the ping-pong kernel's header): a 64-deep step holds [hi | lo] of 32 real k, and each of its two 16-deep
+// MFMA chunks issues W_hi A_lo, W_lo A_hi, W_hi A_hi on fragments read once.  This is the split-operand kernel for problems
+// too small to fill the chip with 256 x 256 tiles: the joint model's training GEMMs (1 500 rows, 768 - 3 072 wide).
+// NST = LDS ring slots (32 KiB each).  2: double buffer, two workgroups per CU cover each other's load latency (the bf16 problems this
+// kernel serves have thousands of tiles).  4 (the split-operand form): the training GEMMs have 72 - 288 tiles, at most one workgroup
+// per CU, and a 64-deep step is ~800 cycles of MFMA against ~2 us of load latency — three steps stay in flight (counted vmcnt).
+template <int EPI, bool X3, int NST = 2>
+__device__ __forceinline__ void t128_body(const GemmP& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -115,13 +121,47 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) {
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
     const int nk = p.K / BK;
-    stage(0, 0);
+    if constexpr (NST == 2) stage(0, 0);
+    else {
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i) if (i < nk) stage(i, i);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* As = smem + (kt & 1) * STAGE_BYTES;
+        if constexpr (NST == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        } else {
+            // steps kt + 1 .. kt + NST - 2 may stay in flight (8 LDS-DMA instructions per wave and step); near the end fewer were issued
+            const int ahead = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // step kt landed everywhere; everyone is done reading step kt - 1
+            if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
+        }
+        const char* As = smem + (kt % NST) * STAGE_BYTES;
         const char* Ws = As + BM * BK * 2;
+        if constexpr (X3) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[2][2], wf[2][2];                      // [row tile][0 hi, 1 lo]
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        af[i][h] = *reinterpret_cast<const bf16x8*>(As + a_row_off + i * 32 * BK * 2 + koff[kk + 2 * h]);
+                        wf[i][h] = *reinterpret_cast<const bf16x8*>(Ws + w_row_off + i * 32 * BK * 2 + koff[kk + 2 * h]);
+                    }
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3)                  // (W half, A half): (hi, lo), (lo, hi), (hi, hi)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jn][g3 == 1 ? 1 : 0], af[i][g3 == 0 ? 1 : 0], acc[i][jn], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 af[2], wf[2];
@@ -136,9 +176,141 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) {
                 for (int jn = 0; jn < 2; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jn], af[i], acc[i][jn], 0, 0, 0);
         }
+        }
     }
 
     // ---- epilogue: D row (n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (m) = lane&31
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = M0 + wm * 64 + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = N0 + wn * 64 + jn * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= p.N) continue;
+                f32x4 v = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                epilogue_store<EPI>(p, m, n, v);
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) { t128_body<EPI, false>(p); }
+
+// Split-operand ("bf16x3") kernel for problems of a few hundred 128 x 128 tiles at most — the joint model's training GEMMs (1 500 rows,
+// 768 - 3 072 wide, K = 768 - 3 072): one workgroup per tile and CU, so what matters is how fast ONE tile goes.  Eight waves = the 2 x 2
+// wave grid of t128 twice: group kg = wave >> 2 multiplies the kg-th 16-deep chunk of every 64-column step ([hi | lo] of 32 real k: chunk 0
+// = k 0..15, chunk 1 = k 16..31, each with its hi and lo columns), i.e. the two groups split K inside the step and read the same 32-KiB
+// stage.  Two waves per SIMD cover each other's fragment reads; a 4-slot ring keeps three steps of LDS-DMA in flight (counted vmcnt: a
+// step is 4 instructions per wave); one barrier per step.  At the end group 1 hands its partial tile to group 0 through the (drained) ring:
+// out = (sum over chunk-0 terms) + (sum over chunk-1 terms), a fixed order.
+// KB: operands stored K-step-blocked (HIREST_GEMM_KBLOCKED: element (row, k) at (k / 64) * ld + row * 64 + k % 64) — the eight 128-B
+// row segments one LDS-DMA instruction fetches are then 1 KiB of consecutive bytes instead of eight segments a row stride apart.  The
+// L2 -> LDS path of a CU delivers ~47 GB/s in the strided form and 100 - 125 in the consecutive one (tools/probes), and a
+// 128 x 128 tile needs 32 KiB per 64-deep step: strided, the tile is bound by that path (786 KB for K = 768: 17 us), not by its MFMAs.
+template <int EPI, bool KB>
+__global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NST = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave >> 2, w4 = wave & 3;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int p_lo = xcd * p.ppx;
+    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+    if (np <= 0 || j >= np * p.nbn) return;
+    const int grp = j / (GROUP_M * p.nbn);
+    const int r = j - grp * GROUP_M * p.nbn;
+    int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
+    const int nt = r / gcount, mt = p_lo + grp * GROUP_M + (r - nt * gcount);
+    const int M0 = mt * BM, N0 = nt * BN;
+
+    // staging: waves 0-3 bring the 16 A pieces (8 rows x 128 B each), waves 4-7 the 16 W pieces
+    const bf16_t* src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (w4 * 4 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        if (kg == 0) { int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1; src[q] = p.A + (int64_t)gm * (KB ? BK : p.lda) + chunk * 8; }
+        else { int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1; src[q] = p.W + (int64_t)gn * (KB ? BK : p.ldw) + chunk * 8; }
+    }
+    const int64_t kstep = KB ? (kg == 0 ? p.lda : p.ldw) : BK;
+    auto stage = [&](int slot, int kt) {
+        char* dst = smem + slot * STAGE_BYTES + (kg ? BM * BK * 2 : 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(src[q] + (int64_t)kt * kstep, dst + (w4 * 4 + q) * 1024);
+    };
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int frow = lane & 31, fsw = (frow >> 1) & 7, khalf = lane >> 5;
+    const int koff_hi = ((kg * 2 + khalf) ^ fsw) << 4, koff_lo = (((kg + 2) * 2 + khalf) ^ fsw) << 4;
+    const int a_row_off = (wm * 64 + frow) * (BK * 2);
+    const int w_row_off = (wn * 64 + frow) * (BK * 2);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) if (i < nk) stage(i, i);
+    // One barrier per step; both groups read their fragments, then multiply.  (A ping-pong form — two barriers per step, group 1 half a
+    // step behind, one group reading while the other multiplies — was measured 20 % SLOWER: with every load, read and MFMA knocked out the
+    // loop still costs ~0.2 us per barrier here, which is most of a step)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // step kt landed everywhere; everyone is done reading step kt - 1
+        if (kt + NST - 1 < nk && !(p.dbg & 1)) stage((kt + NST - 1) % NST, kt + NST - 1);
+        const char* As = smem + (kt % NST) * STAGE_BYTES;
+        const char* Ws = As + BM * BK * 2;
+        bf16x8 af[2][2], wf[2][2];                             // [tile][0 hi, 1 lo]
+        if (!(p.dbg & 8)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i][0] = *reinterpret_cast<const bf16x8*>(As + a_row_off + i * 32 * BK * 2 + koff_hi);
+                af[i][1] = *reinterpret_cast<const bf16x8*>(As + a_row_off + i * 32 * BK * 2 + koff_lo);
+                wf[i][0] = *reinterpret_cast<const bf16x8*>(Ws + w_row_off + i * 32 * BK * 2 + koff_hi);
+                wf[i][1] = *reinterpret_cast<const bf16x8*>(Ws + w_row_off + i * 32 * BK * 2 + koff_lo);
+            }
+        }
+        if (!(p.dbg & 4)) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int g3 = 0; g3 < 3; ++g3)                      // (W half, A half): (hi, lo), (lo, hi), (hi, hi)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jn][g3 == 1 ? 1 : 0], af[i][g3 == 0 ? 1 : 0], acc[i][jn], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    // ---- group 1 -> group 0 through LDS: [w4][tile][reg][lane] fp32 = 64 KiB
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + w4 * (4 * 16 * 64);
+    if (kg == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[((i * 2 + jn) * 16 + e) * 64 + lane] = acc[i][jn][e];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] += red[((i * 2 + jn) * 16 + e) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = M0 + wm * 64 + i * 32 + (lane & 31);
@@ -1381,6 +1553,15 @@ int launch256(GemmP p, hipStream_t s) {
 int g_gemm_dbg = 0;
 namespace {
 
+template <int EPI, bool KB>
+int launch_t128x3(const GemmP& p, hipStream_t s) {
+    static HirestDevCfg cfg;
+    auto kern = gemm_t128x3<EPI, KB>;
+    if (int e = hirest_configure(kern, 4 * STAGE_BYTES, cfg)) return e;
+    hipLaunchKernelGGL(kern, dim3(8 * p.ppx * p.nbn), dim3(512), 4 * STAGE_BYTES, s, p);
+    return hirest_launch_status();
+}
+static inline bool x3_small(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) < 256; }
 int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
 
 // LN-fold epilogues exist in the persistent kernels only
@@ -1440,6 +1621,10 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (epi < 0 || epi > HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
     if (a->flags & HIREST_GEMM_X3) {
         if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32 && epi != HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
+        if (x3_small(a->M, a->N) && epi != HIREST_EPI_BIAS_GELU_SPLIT2) {
+            snprintf(out, out_len, "gemm_t128x3<%d, %s>", epi, (a->flags & HIREST_GEMM_KBLOCKED) ? "true" : "false");
+            return 0;
+        }
         snprintf(out, out_len, g_force_kernel == 9 ? "gemm_pq256x3<%d>" : "gemm_pp256x3<%d>", epi);
         return 0;
     }
@@ -1484,6 +1669,13 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HirestProfScope prof(HIREST_PROF_GEMM, a->epilogue, a->M, a->N, a->K, s);
     if (a->flags & HIREST_GEMM_X3) {                  // split-operand products: the ping-pong kernel's X3 form, fp32 outputs only
+        // fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (2 workgroups per CU)
+        const bool small = x3_small(a->M, a->N), kb = (a->flags & HIREST_GEMM_KBLOCKED) != 0;
+        if (kb && (!small || a->epilogue == HIREST_EPI_BIAS_GELU_SPLIT2)) return HIREST_E_SHAPE;   // the blocked layout exists for the small kernel only
+        if (kb && (a->lda < (int64_t)a->M * 64 || a->ldw < (int64_t)a->N * 64)) return HIREST_E_BADARG;
+        if (small && a->epilogue == HIREST_EPI_BIAS_F32) return kb ? launch_t128x3<HIREST_EPI_BIAS_F32, true>(p, s) : launch_t128x3<HIREST_EPI_BIAS_F32, false>(p, s);
+        if (small && a->epilogue == HIREST_EPI_BIAS_RESID_F32)
+            return kb ? launch_t128x3<HIREST_EPI_BIAS_RESID_F32, true>(p, s) : launch_t128x3<HIREST_EPI_BIAS_RESID_F32, false>(p, s);
         switch (a->epilogue) {
             case HIREST_EPI_BIAS_F32:
                 return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_F32, 1, true, 1>(p, s) : launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);

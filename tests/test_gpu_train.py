@@ -43,8 +43,18 @@ def _setup(golden_dir, case, dev):
     return model, batch, seg_batch, cap_batch, np.load(os.path.join(golden_dir, f"train_{case}.npz"))
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def gemm_precision(request):
+    """train.GEMM_PRECISION: the exact-fp32 products (default) and the opt-in split-operand products, against the same goldens and bars."""
+    from hirest_amd import train
+    old = train.GEMM_PRECISION
+    train.GEMM_PRECISION = request.param
+    yield request.param
+    train.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("case", ["a", "b"])
-def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
+def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case, gemm_precision):
     model, batch, seg_batch, cap_batch, g = _setup(golden_dir, case, dev)
     model.eval()                                   # dropout off: the arithmetic the goldens pin
     worst = 0.0
