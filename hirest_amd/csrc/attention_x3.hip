@@ -20,7 +20,7 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
 }
 
 template <int DHP, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
+__global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
                                                                  const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
                                                                  bf16_t* __restrict__ out2, int Tq, int T, int H, int dh, float scale) {
     constexpr int KLD = DHP + 8, VLD = 36, NO = DHP / 32, NS = DHP / 16;     // NS: 16-deep steps of the score product
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* _
     const float* vbase = vp + (int64_t)b * T * ldkv + h * dh;
     const int q = qb * QB + wave * 32 + l31;
     const bool qvalid = q < Tq;
+    const bool wave_active = qb * QB + wave * 32 < Tq;               // a wave without queries only helps staging the tiles (wave-uniform)
     // Q^T fragments (B operand of S^T): lane (query, half) holds d = 16 s + 8 half .. + 7 for s = 0 .. NS - 1, as bf16 hi and lo
     bf16x8 qh[NS], ql[NS];
     {
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* _
         if (k0 + 64 < T) fetch_kv(k0 + 64);
         const bf16_t* Khb = Kh + buf * KSZ; const bf16_t* Klb = Kl + buf * KSZ;
         const bf16_t* Vhb = Vh + buf * VSZ; const bf16_t* Vlb = Vl + buf * VSZ;
+        if (!wave_active) continue;
         // ---- S^T = K Q^T: A = K[key = l31][d = 16 s + 8 half ..], B = Q^T; small terms first
         f32x16 st;
 #pragma unroll
@@ -216,8 +218,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x3_kernel(const float* _
 template <int DHP, class... Args>
 void launch_x3(int nw, dim3 grid, hipStream_t s, Args... args) {
     if (nw == 3) hipLaunchKernelGGL((attention_x3_kernel<DHP, 3>), grid, dim3(192), 0, s, args...);
+    else if (nw == 8) hipLaunchKernelGGL((attention_x3_kernel<DHP, 8>), grid, dim3(512), 0, s, args...);
+    else if (nw == 9) hipLaunchKernelGGL((attention_x3_kernel<DHP, 9>), grid, dim3(576), 0, s, args...);
     else hipLaunchKernelGGL((attention_x3_kernel<DHP, 4>), grid, dim3(256), 0, s, args...);
 }
+int g_x3_waves = 0;      // 0 automatic; 3 / 4 / 8 / 9 force (hirest_attention_x3_select_waves)
 
 }  // namespace
 
@@ -229,13 +234,23 @@ static int attention_x3(const float* q, int64_t ldq, const float* k, const float
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15)   // (out may be NULL)
         return HIREST_E_SHAPE;
     const int waves = (Tq + 31) / 32;
-    const int nw = (waves + 2) / 3 * 3 < (waves + 3) / 4 * 4 ? 3 : 4;         // three-wave blocks when they waste fewer waves (257 queries: 9)
+    int nw = (waves + 2) / 3 * 3 < (waves + 3) / 4 * 4 ? 3 : 4;               // three-wave blocks when they waste fewer waves (257 queries: 9)
+    // exactly nine waves of queries (the ViT's 257 tokens): one workgroup per (frame, head) stages every K / V tile once instead of three
+    // times (5.5 -> 2.2 GB read per 512-frame launch; 3.21 -> 3.07 ms at 1024 frames: the kernel is bound by instruction issue, not by bytes)
+    if (waves == 9 && B * H >= 512) nw = 9;
+    if (g_x3_waves) nw = g_x3_waves;
     const dim3 grid((unsigned)((int64_t)B * H * ((waves + nw - 1) / nw)));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dh <= 32) launch_x3<32>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
     else if (dh <= 64) launch_x3<64>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
     else launch_x3<96>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
     return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_x3_select_waves(int32_t waves) {
+    if (waves != 0 && waves != 3 && waves != 4 && waves != 8 && waves != 9) return HIREST_E_BADARG;
+    g_x3_waves = waves;
+    return 0;
 }
 
 extern "C" int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int32_t B,

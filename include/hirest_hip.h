@@ -411,6 +411,9 @@ int hirest_attention_x3_qkv(const float* q, int64_t ldq, const float* k, const f
 /* the same with the output stored as the split operand [B * Tq, 2 * H * dh] bf16 of the GEMM that follows ((H * dh) % 32 == 0) */
 int hirest_attention_x3_qkv_split2(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, hirest_bf16* out2, int32_t B,
                                    int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float scale, void* stream);
+/* Waves (32 queries each) per workgroup of the split-operand attention: 0 = automatic, 3 / 4 / 8 / 9 force.  Every workgroup stages all
+ * K / V tiles of its (frame, head), so fewer, larger workgroups read K / V fewer times.  Results are unchanged (per-query arithmetic). */
+int hirest_attention_x3_select_waves(int32_t waves);
 /* A/B and tests: bit 0 = the tower's attention is the exact-fp32 hirest_attention_f32_qkv instead of hirest_attention_x3_qkv; bit 1 = fc1 writes fp32
  * and GELU + split run as a separate pass (hirest_split2_bf16) instead of in its epilogue (HIREST_EPI_BIAS_GELU_SPLIT2).  Default 0. */
 int hirest_vision_x3_select_attention(int32_t which);

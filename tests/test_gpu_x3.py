@@ -191,6 +191,15 @@ def test_attention_x3_against_fp64(dev, B, T, H, dh):
         _lib.check(lib.hirest_attention_x3_qkv_split2(qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, out2.data_ptr(), B, T,
                                                       T, H, dh, scale, ops.stream_ptr()), "hirest_attention_x3_qkv_split2")
         assert torch.equal(out2.view(torch.int16), ops.split2(out).view(torch.int16))
+    for waves in (3, 4, 8, 9):                                        # workgroup size changes who stages the tiles, not a query's arithmetic
+        _lib.check(lib.hirest_attention_x3_select_waves(waves), "select_waves")
+        try:
+            o2 = torch.full((B * T, D), 7.0, dtype=torch.float32, device=dev)
+            _lib.check(lib.hirest_attention_x3_qkv(qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, o2.data_ptr(), B, T, T,
+                                                   H, dh, scale, ops.stream_ptr()), "hirest_attention_x3_qkv")
+        finally:
+            lib.hirest_attention_x3_select_waves(0)
+        assert torch.equal(o2, out), waves
 
 
 def test_x3_tower_attention_ab(dev, golden_dir):

@@ -12,11 +12,13 @@ ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--precision", default="bf16x3")
 ap.add_argument("--chunk", type=int, default=0)
+ap.add_argument("--attn-waves", type=int, default=0, help="hirest_attention_x3_select_waves (0 auto, 3 / 4 / 8 / 9)")
 ap.add_argument("--gemm-kernel", type=int, default=0, help="hirest_gemm_select_kernel (9 = the two-phase ping-pong kernel)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.hirest_gemm_select_kernel(a.gemm_kernel)
+lib.hirest_attention_x3_select_waves(a.attn_waves)
 model = hirest_amd.EVA_CLIP(**synth.EVA_CLIP_G_14).to(dev).eval()
 model.init_random_(seed=1234)
 model.set_precision(a.precision)
