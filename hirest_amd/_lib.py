@@ -125,6 +125,7 @@ _SIGNATURES = {
     "hirest_attention_set_mapping": (C.c_int, [C.c_int32]),
     "hirest_attention_set_pace": (C.c_int, [C.c_int32]),
     "hirest_attention_x3_select_waves": (C.c_int, [C.c_int32]),
+    "hirest_attention_x3_debug_trace": (C.c_int, [C.c_void_p]),
     "hirest_attention_set_stagger": (C.c_int, [C.c_int32]),
     "hirest_attention_debug_trace_read": (C.c_int, [C.c_void_p, C.c_int32]),
     "hirest_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,

@@ -22,7 +22,8 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
 template <int DHP, int NW>
 __global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(const float* __restrict__ qp, int64_t ldq, const float* __restrict__ kp,
                                                                  const float* __restrict__ vp, int64_t ldkv, float* __restrict__ out,
-                                                                 bf16_t* __restrict__ out2, int Tq, int T, int H, int dh, float scale) {
+                                                                 bf16_t* __restrict__ out2, int Tq, int T, int H, int dh, float scale,
+                                                                 long long* __restrict__ trace) {
     constexpr int KLD = DHP + 8, VLD = 36, NO = DHP / 32, NS = DHP / 16;     // NS: 16-deep steps of the score product
     constexpr int KSZ = 32 * KLD, VSZ = DHP * VLD;
     __shared__ __attribute__((aligned(16))) bf16_t Kh[2 * KSZ];             // two tiles: tile t + 1 is stored while tile t is multiplied
@@ -126,12 +127,22 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(
     store_kv(0, 0);
     if (32 < T) fetch_kv(32);
     int buf = 0;
+    // timing tool (tools/attn_x3_trace.py): workgroup 0 stamps the shader clock at the phase boundaries of every tile: [tile][wave][6]
+    auto stamp = [&](int k0, int slot) {
+        if (trace && blockIdx.x == 0) {
+            const long long t = __builtin_readcyclecounter();
+            if (lane == 0) trace[((k0 >> 5) * 16 + wave) * 6 + slot] = t;
+        }
+    };
     for (int k0 = 0; k0 < T; k0 += 32, buf ^= 1) {
+        stamp(k0, 0);
         // one barrier per tile: it publishes this tile's images (stored during the previous iteration) and tells every wave that the
         // other buffer — read during the previous iteration — is free for the next tile
         __syncthreads();
+        stamp(k0, 1);
         if (k0 + 32 < T) store_kv(k0 + 32, buf ^ 1);
         if (k0 + 64 < T) fetch_kv(k0 + 64);
+        stamp(k0, 2);
         const bf16_t* Khb = Kh + buf * KSZ; const bf16_t* Klb = Kl + buf * KSZ;
         const bf16_t* Vhb = Vh + buf * VSZ; const bf16_t* Vlb = Vl + buf * VSZ;
         if (!wave_active) continue;
@@ -147,6 +158,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
         }
+        stamp(k0, 3);
         // ---- online softmax (fp32): st[r] = score of key k0 + (r & 3) + 8 (r >> 2) + 4 half for query l31
         float tmax = -3.0e38f;
 #pragma unroll
@@ -176,6 +188,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(
         for (int j = 0; j < NO; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+        stamp(k0, 4);
         // ---- O^T += V^T P^T: A = V^T[d = l31 + 32 j][key slots of this half], k-slot i <-> key 16 s2 + 4 half + (i & 3) + 8 (i >> 2)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(
                 o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.v, ph[s2], o[j], 0, 0, 0);
             }
         }
+        stamp(k0, 5);
     }
     if (!qvalid) return;
     const float inv = 1.0f / lrun;
@@ -222,6 +236,7 @@ void launch_x3(int nw, dim3 grid, hipStream_t s, Args... args) {
     else if (nw == 9) hipLaunchKernelGGL((attention_x3_kernel<DHP, 9>), grid, dim3(576), 0, s, args...);
     else hipLaunchKernelGGL((attention_x3_kernel<DHP, 4>), grid, dim3(256), 0, s, args...);
 }
+long long* g_x3_trace = nullptr;   // device buffer for the phase stamps (hirest_attention_x3_debug_trace; timing tool only)
 int g_x3_waves = 0;      // 0 automatic; 3 / 4 / 8 / 9 force (hirest_attention_x3_select_waves)
 
 }  // namespace
@@ -241,10 +256,15 @@ static int attention_x3(const float* q, int64_t ldq, const float* k, const float
     if (g_x3_waves) nw = g_x3_waves;
     const dim3 grid((unsigned)((int64_t)B * H * ((waves + nw - 1) / nw)));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dh <= 32) launch_x3<32>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
-    else if (dh <= 64) launch_x3<64>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
-    else launch_x3<96>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale);
+    if (dh <= 32) launch_x3<32>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale, g_x3_trace);
+    else if (dh <= 64) launch_x3<64>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale, g_x3_trace);
+    else launch_x3<96>(nw, grid, s, q, ldq, k, v, ldkv, out, out2, (int)Tq, (int)Tk, (int)H, (int)dh, scale, g_x3_trace);
     return hirest_launch_status();
+}
+
+extern "C" int hirest_attention_x3_debug_trace(int64_t* device_buffer) {   // [tiles <= 16][waves <= 16][6] int64 on the device, or NULL (off)
+    g_x3_trace = reinterpret_cast<long long*>(device_buffer);
+    return 0;
 }
 
 extern "C" int hirest_attention_x3_select_waves(int32_t waves) {
