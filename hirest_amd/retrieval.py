@@ -263,13 +263,18 @@ def encode_prompts(model, prompts: Sequence[str], device, batch_size: int = 1024
     """inference_video_retrieval.py:203-214: tokenise + encode_text + L2 in batches -> [Q, E] fp32."""
     if tokenizer is None:
         from .tokenizer import tokenize as tokenizer
+    if len(prompts) == 0:
+        return torch.zeros((0, int(getattr(model, "embed_dim", 0) or 0)), dtype=torch.float32, device=device)
     rows = [encode_texts(model, tokenizer(list(prompts[s:s + batch_size])).to(device)) for s in range(0, len(prompts), batch_size)]
     return torch.cat(rows) if len(rows) != 1 else rows[0]
 
 
 def score_corpus(text_rows: torch.Tensor, video_rows: torch.Tensor, video_ids: Sequence[str], prompts: Sequence[str]) -> RetrievalResult:
     """``text_to_video_scores = T @ V.T`` (:334) and the output dict (:337-346)."""
-    scores = ops.similarity(text_rows.contiguous(), video_rows.contiguous())
+    if text_rows.shape[0] == 0 or video_rows.shape[0] == 0:           # no prompts / an empty corpus: the script's loops simply do not run
+        scores = torch.zeros((text_rows.shape[0], video_rows.shape[0]), dtype=torch.float32, device=text_rows.device)
+    else:
+        scores = ops.similarity(text_rows.contiguous(), video_rows.contiguous())
     host = scores.cpu().tolist()                                  # ONE device -> host copy for the whole matrix
     ids = list(video_ids)
     res = RetrievalResult((p, {"videos": ids, "scores": host[i]}) for i, p in enumerate(prompts))

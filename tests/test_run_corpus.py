@@ -288,3 +288,12 @@ def test_gpu_two_rank_driver_on_one_gpu_equals_one_rank(tmp_path):
     assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["backend"] == "gloo" and two["all_ranks_hold_the_same_rows_and_ranking"]
     assert (two["pooled_sha256"], two["top10_sha256"]) == (one["pooled_sha256"], one["top10_sha256"])
     assert two["result_dict"] == one["result_dict"] and two["result_dict"]["videos_per_prompt"] == 64
+
+
+def test_score_corpus_without_prompts_or_videos():
+    """No prompts / an empty corpus: the script's loops do not run (inference_video_retrieval.py:337-346) — an empty dict, no kernel call."""
+    empty = retrieval.score_corpus(torch.zeros((0, 8)), torch.randn(5, 8), [f"v{i}.mp4" for i in range(5)], [])
+    assert dict(empty) == {} and tuple(empty.scores.shape) == (0, 5)
+    novid = retrieval.score_corpus(torch.randn(2, 8), torch.zeros((0, 8)), [], ["a", "b"])
+    assert dict(novid) == {"a": {"videos": [], "scores": []}, "b": {"videos": [], "scores": []}}
+    assert retrieval.encode_prompts(object(), [], "cpu").shape[0] == 0
