@@ -348,7 +348,8 @@ def main():
                 traffic = None
         if dom:
             epi = {0: "bias", 1: "bias+gelu", 2: "bias+quickgelu", 3: "bias+residual", 4: "bias->f32", 5: "patch+pos",
-                   6: "bias+residual+ln-stats", 7: "ln-fold+bias", 8: "ln-fold+bias+gelu"}
+                   6: "bias+residual+ln-stats", 7: "ln-fold+bias", 8: "ln-fold+bias+gelu",
+                   10: "bias+residual(hi+lo)+ln-stats"}
             roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_missing": traffic is None,      # loud: no committed profile matches the kernels this run dispatched
@@ -374,7 +375,9 @@ def main():
                                       "(BASELINE configs[1]) as 32 videos x 32 frames -> mean-pool+L2 -> all-gather "
                                       "[V,1024] rows -> 546-query cosine top-10; random-init weights",
                           "frames_per_gpu_per_step": args.frames, "global_batch": args.frames * world,
-                          "micro_batch": args.chunk, "parallelism": f"dp{world}"},
+                          "micro_batch": args.chunk, "parallelism": f"dp{world}",
+                          "arithmetic": "bf16 MFMA products, fp32 accumulation / LayerNorm statistics / softmax / pooling / scoring; residual "
+                                        "stream between the blocks held as bf16 hi + bf16 lo (16 significand bits; HIREST_F32_RESIDUAL=1: fp32 array)"},
                "roofline": roofline}
         if args.no_profile:
             out["profile"] = "off (--no-profile: no per-launch event pairs in the timed region, hence no roofline in this line)"

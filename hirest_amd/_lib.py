@@ -13,10 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
 
 (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_POS_F32,
- EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16, EPI_BIAS_GELU_SPLIT2) = range(10)
+ EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16, EPI_BIAS_GELU_SPLIT2, EPI_BIAS_RESID2_LNSTATS) = range(11)
 
 TOWER_NO_LNFOLD = 1
 TOWER_NO_PRUNE = 2
+TOWER_F32_RESIDUAL = 4
 GEMM_REVERSE = 1
 GEMM_X3 = 2
 GEMM_KBLOCKED = 4
@@ -139,6 +140,9 @@ _SIGNATURES = {
     "hirest_patchify": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_void_p]),
     "hirest_rowstats_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hirest_rowstats_split_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p,
+                                             C.c_void_p]),
+    "hirest_combine_hi_lo_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_ln_stats_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "hirest_write_cls_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_void_p]),

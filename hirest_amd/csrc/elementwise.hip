@@ -126,7 +126,7 @@ __device__ __forceinline__ void guard_max(float* guard, float v) {
 template <int NV>
 __global__ __launch_bounds__(256) void rowstats_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ xb,
                                                             float* __restrict__ stats, float eps, int rows, int D,
-                                                            float* __restrict__ guard) {
+                                                            float* __restrict__ guard, bf16_t* __restrict__ xlo) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     float worst = 0.f;
@@ -142,6 +142,12 @@ __global__ __launch_bounds__(256) void rowstats_bf16_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v[e]; const float f = (float)o[e]; s += f; q = fmaf(f, f, q); }
                 *reinterpret_cast<bf16x4*>(xb + (int64_t)row * D + 4 * c) = o;
+                if (xlo) {                                            // the two-array residual stream: lo = bf16(x - hi)
+                    bf16x4 l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = (bf16_t)(v[e] - (float)o[e]);
+                    *reinterpret_cast<bf16x4*>(xlo + (int64_t)row * D + 4 * c) = l;
+                }
             }
         }
         const double S = (double)wave_sum(s), Q = (double)wave_sum(q);
@@ -348,15 +354,47 @@ extern "C" int hirest_layernorm(const float* x, int64_t ldx, const int32_t* row_
     return launch_ln<false>(x, ldx, row_index, gamma, beta, eps, out, ldo, rows, D, s);
 }
 
+// x = hi + lo in fp32 for the rows row_stride apart (the two-array residual stream back to fp32: all rows after a tower's last block, or its
+// CLS rows only); one thread per 4 columns
+__global__ __launch_bounds__(256) void combine_hi_lo_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int64_t ld_in,
+                                                            float* __restrict__ out, int64_t ldo, int rows, int D) {
+    const int nv = D >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * nv; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nv;
+        const int c = (int)(i - r * nv) * 4;
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(hi + r * ld_in + c), b = *reinterpret_cast<const bf16x4*>(lo + r * ld_in + c);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)a[e] + (float)b[e];
+        *reinterpret_cast<f32x4*>(out + r * ldo + c) = v;
+    }
+}
+
+extern "C" int hirest_combine_hi_lo_f32(const hirest_bf16* hi, const hirest_bf16* lo, int64_t ld_in, float* out, int64_t ldo, int32_t rows,
+                                        int32_t D, void* stream) {
+    if (!hi || !lo || !out || rows <= 0 || D <= 0) return HIREST_E_BADARG;
+    if (D % 4 != 0 || ld_in % 4 != 0 || ldo % 4 != 0) return HIREST_E_SHAPE;
+    int64_t blocks = ((int64_t)rows * (D / 4) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(combine_hi_lo_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(hi), reinterpret_cast<const bf16_t*>(lo), ld_in, out, ldo, rows, D);
+    return hirest_launch_status();
+}
+
 extern "C" int hirest_rowstats_bf16(const float* x, int64_t ldx, hirest_bf16* xb, float* stats, float eps, int32_t rows, int32_t D,
                                     float* guard, void* stream) {
+    return hirest_rowstats_split_bf16(x, ldx, xb, nullptr, stats, eps, rows, D, guard, stream);
+}
+
+extern "C" int hirest_rowstats_split_bf16(const float* x, int64_t ldx, hirest_bf16* xb, hirest_bf16* xlo, float* stats, float eps, int32_t rows,
+                                          int32_t D, float* guard, void* stream) {
     if (!x || !xb || !stats || rows <= 0) return HIREST_E_BADARG;
     if (D <= 0 || D % 4 != 0 || D > 6 * 256 || ldx % 4 != 0) return HIREST_E_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     bf16_t* o = reinterpret_cast<bf16_t*>(xb);
     const int nv = (D / 4 + 63) / 64;
     const int grid = rows / 4 + 1 < 256 * 16 ? rows / 4 + 1 : 256 * 16;
-#define RS_CASE(NVV) case NVV: hipLaunchKernelGGL((rowstats_bf16_kernel<NVV>), dim3(grid), dim3(256), 0, s, x, ldx, o, stats, eps, rows, D, guard); break;
+#define RS_CASE(NVV) case NVV: hipLaunchKernelGGL((rowstats_bf16_kernel<NVV>), dim3(grid), dim3(256), 0, s, x, ldx, o, stats, eps, rows, D, guard, reinterpret_cast<bf16_t*>(xlo)); break;
     switch (nv) { RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) default: return HIREST_E_SHAPE; }
 #undef RS_CASE
     return hirest_launch_status();

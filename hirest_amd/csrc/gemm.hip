@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) { pp256_body<EPI, RD,
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp256x3(GemmP p) { pp256_body<EPI, 1, true>(p); }
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, 1, false, 1>(p); }      // two-phase schedule (PH2)
+__global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS ? 2 : 1), false, 1>(p); }      // two-phase schedule (PH2); the two-array residual epilogue decodes its loads a pass late: look-ahead 2 (1.258 -> 1.206 ms on proj; 3: 1.27-1.30)      // two-phase schedule (PH2)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pq256x3(GemmP p) { pp256_body<EPI, 1, true, 1>(p); }
 
@@ -1570,7 +1570,8 @@ int launch_fused(const GemmP& p, hipStream_t s) {
     // (the persistent kernels take any M, N: a small problem just leaves CUs idle — the CLS-row GEMMs of a tower's last block)
     const bool big = p.M >= 64 && p.N >= 256;
     if (!big || !p.aux0 || !p.aux1) return !big ? HIREST_E_SHAPE : HIREST_E_BADARG;
-    if (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
+    if ((EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 || EPI == HIREST_EPI_BIAS_RESID2_LNSTATS) && p.N % 8 != 0) return HIREST_E_SHAPE;   // 16-B stores of the bf16 copy
+    if (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS && p.ldo % 8 != 0) return HIREST_E_SHAPE;
     GemmP q = p; q.dbg = 0;
     // default since round 4: the two-phase ping-pong kernel (pq256) on every shape — 1-3.3 % faster than p256 (K = 1408) / pp256 (K = 6144),
     // same bits; 6 / 8 select those for A/B
@@ -1618,7 +1619,7 @@ extern "C" int hirest_gemm_select_kernel(int32_t which) {
 extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, int32_t out_len) {
     if (!a || a->struct_size != sizeof(hirest_gemm_args) || !out || out_len < 48) return HIREST_E_BADARG;
     const int epi = a->epilogue, f = g_force_kernel;
-    if (epi < 0 || epi > HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
+    if (epi < 0 || epi > HIREST_EPI_BIAS_RESID2_LNSTATS) return HIREST_E_BADARG;
     if (a->flags & HIREST_GEMM_X3) {
         if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32 && epi != HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
         if (x3_small(a->M, a->N) && epi != HIREST_EPI_BIAS_GELU_SPLIT2) {
@@ -1629,7 +1630,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
         return 0;
     }
     if (epi == HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;      // exists in the X3 form only
-    const bool fused = epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32;
+    const bool fused = (epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32 && epi <= HIREST_EPI_LNFOLD_GELU_BF16) || epi == HIREST_EPI_BIAS_RESID2_LNSTATS;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
     const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x10000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
@@ -1699,6 +1700,7 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
             if (!a->pos || a->patches_per_frame <= 0) return HIREST_E_BADARG;
             return launch<HIREST_EPI_PATCH_POS_F32>(p, s);
         case HIREST_EPI_BIAS_RESID_LNSTATS_F32: return launch_fused<HIREST_EPI_BIAS_RESID_LNSTATS_F32>(p, s);
+        case HIREST_EPI_BIAS_RESID2_LNSTATS: return launch_fused<HIREST_EPI_BIAS_RESID2_LNSTATS>(p, s);
         case HIREST_EPI_LNFOLD_BF16: return launch_fused<HIREST_EPI_LNFOLD_BF16>(p, s);
         case HIREST_EPI_LNFOLD_GELU_BF16: return launch_fused<HIREST_EPI_LNFOLD_GELU_BF16>(p, s);
         default: return HIREST_E_BADARG;     // (HIREST_EPI_BIAS_GELU_SPLIT2 without HIREST_GEMM_X3 included)

@@ -74,7 +74,10 @@ __device__ __forceinline__ float sum8(float v) {   // over the 8 lanes lane & ~7
 // NM = 16-row tiles of the block that hold results (8; 4 for the 64-row blocks of w4's edge tiles).
 // RD = how many 16-row passes ahead the residual rows (fp32, HBM) are requested: every pass needs 4 x 16 B per lane, the
 // fragment registers of the K loop are dead here, and with one pass of look-ahead the epilogue was bound by the HBM round trip.
-template <int NI, int NM, int RD>
+// S2 (HIREST_EPI_BIAS_RESID2_LNSTATS): the residual stream is kept as TWO bf16 arrays, hi = bf16(x) — which is the copy the next GEMM streams
+// anyway — and lo = bf16(x - hi) (16 significand bits; p.out = lo [M, ldo], p.aux0 = hi [M, N], both in / out).  The epilogue reads 2 + 2
+// bytes per element and writes 2 + 2 instead of reading 4 and writing 4 + 2: a fifth less traffic on the byte-bound residual GEMMs.
+template <int NI, int NM, int RD, bool S2 = false>
 __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8][NI], int jc, char* stg, int Mw, int Nw, int lane) {
     const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;
     const int rr = lane >> 3, rc = lane & 7;
@@ -89,10 +92,29 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
         bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int n0 = Nw + rc * 4, n1 = Nw + 32 + rc * 4;               // this lane's columns in the two 32-column halves
+    bf16_t* xlo = reinterpret_cast<bf16_t*>(p.out);                  // S2 only
     auto load_res = [&](int mi, f32x4 (&o)[2][2]) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int m = Mw + mi * 16 + it * 8 + rr;
+            if constexpr (S2) {
+                // 16 B per lane at the columns the stores below use (even lanes: n0 .. n0 + 7, odd lanes: n1 - 4 .. n1 + 3 — a row's 64
+                // columns are one 128-B line per array), then the stores' DPP exchange backwards: an even lane keeps its first half as its
+                // n0 values and takes its n1 values from the odd neighbour's first half; an odd lane keeps its second half (n1) and takes
+                // its n0 values from the even neighbour's second half
+                const int64_t mr = m < p.M ? m : p.M - 1;
+                const int col = (rc & 1) ? n1 - 4 : n0;
+                union { bf16x8 v; bf16x4 h[2]; float f[4]; } hv, lv;
+                hv.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; lv.v = hv.v;
+                if (col + 8 <= p.N && !(p.epi_dbg & 1)) {
+                    hv.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xb + mr * p.N + col));
+                    lv.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xlo + mr * p.ldo + col));
+                }
+                // (raw bits into the ring: decoding here would wait for the loads and undo the look-ahead — decode_s2 runs when the pass is due)
+                o[0][it] = __builtin_bit_cast(f32x4, hv.v);
+                o[1][it] = __builtin_bit_cast(f32x4, lv.v);
+                continue;
+            }
             const float* row = outp + (int64_t)(m < p.M ? m : p.M - 1) * p.ldo;
             o[0][it] = (n0 < p.N && !(p.epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n0)) : f32x4{0.f, 0.f, 0.f, 0.f};
             o[1][it] = (n1 < p.N && !(p.epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -105,6 +127,22 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
     for (int mi = 0; mi < NM; ++mi) {
         if (mi + RD < NM) load_res(mi + RD, ring[(mi + RD) % (RD + 1)]);
         f32x4 (&oc)[2][2] = ring[mi % (RD + 1)];
+        if constexpr (S2) {                                          // ring slot: [0][it] = 8 hi values, [1][it] = 8 lo values of this lane's 16-B loads
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                union { bf16x8 v; bf16x4 h[2]; float f[4]; } hv, lv;
+                hv.v = __builtin_bit_cast(bf16x8, oc[0][it]); lv.v = __builtin_bit_cast(bf16x8, oc[1][it]);
+                union { bf16x4 v; float f[2]; } hs, hr, ls, lr;
+                hs.v = (rc & 1) ? hv.h[0] : hv.h[1];
+                ls.v = (rc & 1) ? lv.h[0] : lv.h[1];
+                hr.f[0] = dpp_xor1(hs.f[0]); hr.f[1] = dpp_xor1(hs.f[1]);
+                lr.f[0] = dpp_xor1(ls.f[0]); lr.f[1] = dpp_xor1(ls.f[1]);
+                const bf16x4 h0 = (rc & 1) ? hr.v : hv.h[0], h1 = (rc & 1) ? hv.h[1] : hr.v;
+                const bf16x4 l0 = (rc & 1) ? lr.v : lv.h[0], l1 = (rc & 1) ? lv.h[1] : lr.v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { oc[0][it][e] = (float)h0[e] + (float)l0[e]; oc[1][it][e] = (float)h1[e] + (float)l1[e]; }
+            }
+        }
         f32x4 wv[2][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -123,8 +161,10 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
         for (int it = 0; it < 2; ++it) {
             const int m = Mw + mi * 16 + it * 8 + rr;
             const bool okm = m < p.M, ok0 = okm && n0 < p.N, ok1 = okm && n1 < p.N;
-            if (ok0 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
-            if (ok1 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
+            if constexpr (!S2) {
+                if (ok0 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
+                if (ok1 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
+            }
             union { bf16x4 v; float f[2]; } b0, b1, snd, rcv;
             float ps = 0.f, pq = 0.f;
 #pragma unroll
@@ -140,6 +180,20 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
             if (rc & 1) { w8.f[0] = rcv.f[0]; w8.f[1] = rcv.f[1]; w8.f[2] = b1.f[0]; w8.f[3] = b1.f[1]; col = n1 - 4; }
             else        { w8.f[0] = b0.f[0]; w8.f[1] = b0.f[1]; w8.f[2] = rcv.f[0]; w8.f[3] = rcv.f[1]; col = n0; }
             if (okm && col + 8 <= p.N && !(p.epi_dbg & 4)) __builtin_nontemporal_store(w8.v, reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col));
+            if constexpr (S2) {                                      // lo = bf16(x - hi), regrouped like hi: 16 B per lane, whole lines per row
+                union { bf16x4 v; float f[2]; } l0, l1, ls, lr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    l0.v[e] = (bf16_t)(wv[0][it][e] - (float)b0.v[e]);
+                    l1.v[e] = (bf16_t)(wv[1][it][e] - (float)b1.v[e]);
+                }
+                ls.v = (rc & 1) ? l0.v : l1.v;
+                lr.f[0] = dpp_xor1(ls.f[0]); lr.f[1] = dpp_xor1(ls.f[1]);
+                union { bf16x8 v; float f[4]; } q8;
+                if (rc & 1) { q8.f[0] = lr.f[0]; q8.f[1] = lr.f[1]; q8.f[2] = l1.f[0]; q8.f[3] = l1.f[1]; }
+                else        { q8.f[0] = l0.f[0]; q8.f[1] = l0.f[1]; q8.f[2] = lr.f[0]; q8.f[3] = lr.f[1]; }
+                if (okm && col + 8 <= p.N && !(p.epi_dbg & 2)) __builtin_nontemporal_store(q8.v, reinterpret_cast<bf16x8*>(xlo + (int64_t)m * p.ldo + col));
+            }
             ps = sum8(ps); pq = sum8(pq);
             if (rc == 0 && okm && Nw < p.N && !(p.epi_dbg & 8)) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
         }
@@ -160,10 +214,10 @@ __device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane
 // straight from global memory (L2-resident, written by hirest_ln_stats_finalize) into registers at the start of the epilogue.
 template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1, bool SREG = false>   // PRE: the caller has already brought the row statistics into LDS
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
-    if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32) {
+    if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 || EPI == HIREST_EPI_BIAS_RESID2_LNSTATS) {
 #pragma unroll
         for (int jc = 0; jc < NI; jc += 4)                            // one 64-column group at a time
-            if (Nw + jc * 16 < p.N) epilogue_lnstats<NI, NM, RD>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
+            if (Nw + jc * 16 < p.N) epilogue_lnstats<NI, NM, RD, EPI == HIREST_EPI_BIAS_RESID2_LNSTATS>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
         return;
     }
     constexpr bool FOLD = epi_is_lnfold(EPI);

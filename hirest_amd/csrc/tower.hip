@@ -16,11 +16,13 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Regions {
-    size_t x, h, big, eot, xb, part, stats, guard, total;
+    size_t x, h, big, eot, xb, xl, cls, part, stats, guard, total;
 };
 
 // lnfold: also the folded-LayerNorm buffers (vision): xb bf16 [M,D] = rounded copy of the residual stream (A operand of
-// qkv / fc1), part f32 [M, ceil(D/64), 2] row sums per 64-column group, stats f32 [M,2] (mean, rstd)
+// qkv / fc1) and, since round 4, its HIGH part: between the first and the last block the stream lives as xb + xl (bf16 hi + bf16 lo,
+// 16 significand bits; HIREST_EPI_BIAS_RESID2_LNSTATS) instead of in x — 8 instead of 10 bytes of epilogue traffic per element on the
+// two byte-bound residual GEMMs of a block; HIREST_TOWER_F32_RESIDUAL keeps the fp32 array; part f32 [M, ceil(D/64), 2] row sums per 64-column group, stats f32 [M,2] (mean, rstd)
 Regions plan(int64_t M, int D, int wide, int B, bool lnfold = false) {
     Regions r;
     size_t off = 0;
@@ -28,9 +30,11 @@ Regions plan(int64_t M, int D, int wide, int B, bool lnfold = false) {
     r.h = off; off += align256((size_t)M * D * 2);
     r.big = off; off += align256((size_t)M * wide * 2);
     r.eot = off; off += align256((size_t)B * 4);
-    r.xb = r.part = r.stats = r.guard = off;
+    r.xb = r.xl = r.cls = r.part = r.stats = r.guard = off;
     if (lnfold) {
         r.xb = off; off += align256((size_t)M * D * 2);
+        r.xl = off; off += align256((size_t)M * D * 2);   // low part of the two-array residual stream (hi = xb)
+        r.cls = off; off += 2 * align256((size_t)B * D * 2);   // the CLS rows' hi | lo, compact, for the pruned last block
         r.part = off; off += align256((size_t)M * ((D + 63) / 64) * 8);
         r.stats = off; off += align256((size_t)M * 8);
         r.guard = off; off += 256;                      // one float: max |mean| / sigma over all rows and layers of the call
@@ -86,21 +90,24 @@ int run_block(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf
 
 // the same block with both LayerNorms folded into the GEMMs around them (include/hirest_hip.h, HIREST_EPI_LNFOLD_*):
 // on entry xb / stats describe x; proj and fc2 refresh them in their epilogues
+// xl != nullptr: the residual stream is xb + xl (see plan()); x is not touched
 int run_block_lnfold(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf16* big, hirest_bf16* xb, float* part,
-                     float* stats, float* guard, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream) {
+                     float* stats, float* guard, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream,
+                     hirest_bf16* xl = nullptr) {
     const int M = B * T, G = (D + 63) / 64;
+    void* res = xl ? static_cast<void*>(xl) : static_cast<void*>(x);
+    const int epi_res = xl ? HIREST_EPI_BIAS_RESID2_LNSTATS : HIREST_EPI_BIAS_RESID_LNSTATS_F32;
     CHECK(gemm(xb, D, w.qkv_wf, D, w.qkv_bf, big, 3 * D, M, 3 * D, D, HIREST_EPI_LNFOLD_BF16, stream, nullptr, 0, stats,
                const_cast<float*>(w.qkv_s)));
     CHECK(hirest_attention_bf16(big, h, B, T, heads, dh, 1.0f / sqrtf((float)dh), 0, stream));
-    CHECK(gemm(h, D, w.proj_w, D, w.proj_b, x, D, M, D, D, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
+    CHECK(gemm(h, D, w.proj_w, D, w.proj_b, res, D, M, D, D, epi_res, stream, nullptr, 0, xb, part));
     CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, guard, stream));
     CHECK(gemm(xb, D, w.fc1_wf, D, w.fc1_bf, big, Dm, M, Dm, D, HIREST_EPI_LNFOLD_GELU_BF16, stream, nullptr, 0, stats,
                const_cast<float*>(w.fc1_s)));
     // fc2 walks its rows backwards: it starts on the part of the hidden activation fc1 wrote last, and the next block's qkv
     // (forwards) starts on the rows of xb fc2 wrote last — both still in the 256-MB Infinity Cache.  (Alternating every
     // kernel of the chain, attention included, measured less: the grouped tile order of qkv / fc1 runs slower backwards.)
-    CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, x, D, M, D, Dm, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part,
-               HIREST_GEMM_REVERSE));
+    CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, res, D, M, D, Dm, epi_res, stream, nullptr, 0, xb, part, HIREST_GEMM_REVERSE));
     CHECK(hirest_ln_stats_finalize(part, G, stats, eps, M, D, guard, stream));
     return 0;
 }
@@ -112,12 +119,27 @@ int run_block_lnfold(const hirest_block_weights& w, float* x, hirest_bf16* h, hi
 // compactly, row b = frame b — nothing reads their all-token contents after the qkv GEMM.  Every surviving row goes through
 // the same kernels and epilogues as in run_block_lnfold, so the CLS rows of x are bit-identical to the unpruned block's.
 int run_block_lnfold_cls(const hirest_block_weights& w, float* x, hirest_bf16* h, hirest_bf16* big, hirest_bf16* xb, float* part,
-                         float* stats, float* guard, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream) {
+                         float* stats, float* guard, int B, int T, int D, int heads, int dh, int Dm, float eps, void* stream,
+                         hirest_bf16* xl = nullptr, hirest_bf16* cls_hi = nullptr, hirest_bf16* cls_lo = nullptr) {
     const int M = B * T, G = (D + 63) / 64;
     const int64_t TD = (int64_t)T * D;
     CHECK(gemm(xb, D, w.qkv_wf, D, w.qkv_bf, big, 3 * D, M, 3 * D, D, HIREST_EPI_LNFOLD_BF16, stream, nullptr, 0, stats,
                const_cast<float*>(w.qkv_s)));
     CHECK(hirest_attention_bf16_rows(big, h, B, T, heads, dh, 1.0f / sqrtf((float)dh), 0, 1, stream));
+    if (xl) {
+        // two-array residual stream: the CLS rows' hi / lo move into compact [B, D] arrays (the epilogue indexes its hi array by output
+        // row), and the block updates those — the same arithmetic per row as run_block_lnfold's, so the result equals the unpruned block's
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        if (hipMemcpy2DAsync(cls_hi, (size_t)D * 2, xb, (size_t)TD * 2, (size_t)D * 2, B, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpy2DAsync(cls_lo, (size_t)D * 2, xl, (size_t)TD * 2, (size_t)D * 2, B, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return hirest_launch_status();
+        CHECK(gemm(h, TD, w.proj_w, D, w.proj_b, cls_lo, D, B, D, D, HIREST_EPI_BIAS_RESID2_LNSTATS, stream, nullptr, 0, cls_hi, part));
+        CHECK(hirest_ln_stats_finalize(part, G, stats, eps, B, D, guard, stream));
+        CHECK(gemm(cls_hi, D, w.fc1_wf, D, w.fc1_bf, big, Dm, B, Dm, D, HIREST_EPI_LNFOLD_GELU_BF16, stream, nullptr, 0, stats,
+                   const_cast<float*>(w.fc1_s)));
+        CHECK(gemm(big, Dm, w.fc2_w, Dm, w.fc2_b, cls_lo, D, B, D, Dm, HIREST_EPI_BIAS_RESID2_LNSTATS, stream, nullptr, 0, cls_hi, part));
+        return 0;
+    }
     CHECK(gemm(h, TD, w.proj_w, D, w.proj_b, x, TD, B, D, D, HIREST_EPI_BIAS_RESID_LNSTATS_F32, stream, nullptr, 0, xb, part));
     CHECK(hirest_ln_stats_finalize(part, G, stats, eps, B, D, guard, stream));
     CHECK(gemm(xb, D, w.fc1_wf, D, w.fc1_bf, big, Dm, B, Dm, D, HIREST_EPI_LNFOLD_GELU_BF16, stream, nullptr, 0, stats,
@@ -167,21 +189,32 @@ extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* f
     CHECK(hirest_write_cls_rows(x, D, t->cls, t->pos, B, T, D, stream));
     if (t->ln_pre_g)   // model.py:261 ln_pre, in place on the fp32 stream (row-local, so in place is safe)
         CHECK(hirest_layernorm(x, D, nullptr, t->ln_pre_g, t->ln_pre_b, t->ln_eps, x, D, 1, B * T, D, stream));
+    int64_t cls_ldx = (int64_t)T * D;                         // row stride of the CLS rows the head reads
     if (lnfold) {
         hirest_bf16* xb = reinterpret_cast<hirest_bf16*>(ws + r.xb);
         float* part = reinterpret_cast<float*>(ws + r.part);
         float* stats = reinterpret_cast<float*>(ws + r.stats);
         float* guard = reinterpret_cast<float*>(ws + r.guard);
         if (hipMemsetAsync(guard, 0, 256, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return hirest_launch_status();
-        CHECK(hirest_rowstats_bf16(x, D, xb, stats, t->ln_eps, B * T, D, guard, stream));
         const bool prune = !t->out_all_tokens && !(flags & HIREST_TOWER_NO_PRUNE);
+        // the two-array residual stream between the first and the last block (a one-block tower with pruning never leaves x)
+        hirest_bf16* xl = ((flags & HIREST_TOWER_F32_RESIDUAL) || (prune && t->layers == 1)) ? nullptr : reinterpret_cast<hirest_bf16*>(ws + r.xl);
+        hirest_bf16* cls_hi = reinterpret_cast<hirest_bf16*>(ws + r.cls);
+        hirest_bf16* cls_lo = reinterpret_cast<hirest_bf16*>(ws + r.cls + align256((size_t)B * D * 2));
+        CHECK(hirest_rowstats_split_bf16(x, D, xb, xl, stats, t->ln_eps, B * T, D, guard, stream));
         for (int l = 0; l < t->layers; ++l) {
-            if (prune && l == t->layers - 1)
+            if (prune && l == t->layers - 1) {
                 CHECK(run_block_lnfold_cls(t->blocks[l], x, h, big, xb, part, stats, guard, B, T, D, t->heads, t->head_dim, t->mlp_dim,
-                                           t->ln_eps, stream));
-            else
+                                           t->ln_eps, stream, xl, cls_hi, cls_lo));
+            } else {
                 CHECK(run_block_lnfold(t->blocks[l], x, h, big, xb, part, stats, guard, B, T, D, t->heads, t->head_dim, t->mlp_dim,
-                                       t->ln_eps, stream));
+                                       t->ln_eps, stream, xl));
+            }
+        }
+        if (xl && !prune) CHECK(hirest_combine_hi_lo_f32(xb, xl, D, x, D, B * T, D, stream));
+        if (xl && prune) {                                     // the CLS rows back to fp32, compact [B, D] at the start of x
+            CHECK(hirest_combine_hi_lo_f32(cls_hi, cls_lo, D, x, D, B, D, stream));
+            cls_ldx = D;
         }
     } else {
         for (int l = 0; l < t->layers; ++l)
@@ -193,7 +226,7 @@ extern "C" int hirest_vision_forward(const hirest_vision_tower* t, const void* f
         return 0;
     }
     // norm on the CLS rows only (LayerNorm is per-row, so norm(x)[:,0] == norm(x[:,0])), then head
-    CHECK(hirest_layernorm(x, (int64_t)T * D, nullptr, t->norm_g, t->norm_b, t->ln_eps, h, D, 0, B, D, stream));
+    CHECK(hirest_layernorm(x, cls_ldx, nullptr, t->norm_g, t->norm_b, t->ln_eps, h, D, 0, B, D, stream));
     CHECK(gemm(h, D, t->head_w, D, t->head_b, out, t->embed_dim, B, t->embed_dim, D, HIREST_EPI_BIAS_F32, stream));
     return 0;
 }

@@ -156,6 +156,9 @@ class VisionTower(_Tower):
         self.last_fold_ratio = 0.0       # (None: never check).  Largest |mean| / sigma seen by the last forward()
         self.fold_fallbacks = 0          # calls redone so far
         self.prune_last_block = True     # the last block computes only what x[:, 0] needs (bit-identical CLS rows; False: A/B)
+        # bf16 tower, folded calls: the residual stream between the blocks as bf16 hi + bf16 lo (16 significand bits) instead of an fp32
+        # array: a fifth less epilogue traffic on proj / fc2.  True (or HIREST_F32_RESIDUAL=1) keeps the fp32 array of rounds 1-3.
+        self.f32_residual = os.environ.get("HIREST_F32_RESIDUAL", "0") == "1"
 
     def _prepare(self, device):
         if self._prepared is not None and self._prepared["device"] == device and not self._prepared.get("f32"):
@@ -329,7 +332,7 @@ class VisionTower(_Tower):
         ws = self._ws(nbytes, image.device)
         code = ops._IN_DTYPES[image.dtype]
         self.last_fold_ratio = 0.0
-        flags = 0 if self.prune_last_block else _lib.TOWER_NO_PRUNE
+        flags = (0 if self.prune_last_block else _lib.TOWER_NO_PRUNE) | (_lib.TOWER_F32_RESIDUAL if self.f32_residual else 0)
         goff = lib.hirest_vision_guard_offset(C.byref(prep["desc"]), step) if self.fold_guard_ratio is not None else _NO_GUARD
         starts = list(range(0, B, step))
         # Guard of the folded LayerNorm (include/hirest_hip.h): every call reports the largest |mean| / sigma any token row had

@@ -74,7 +74,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     if w.shape[1] != K:
         raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
     out_dtype = torch.bfloat16 if epilogue in (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, _lib.EPI_LNFOLD_BF16,
-                                              _lib.EPI_LNFOLD_GELU_BF16) else torch.float32
+                                              _lib.EPI_LNFOLD_GELU_BF16, _lib.EPI_BIAS_RESID2_LNSTATS) else torch.float32
     args = _lib.GemmArgs.make(_dev(a, torch.bfloat16, "gemm.a"), K, _dev(w, torch.bfloat16, "gemm.w"), K,
                          _opt(bias, torch.float32, "gemm.bias"), _dev(out, out_dtype, "gemm.out"), out.shape[-1],
                          M, N, K, epilogue, _opt(pos, torch.float32, "gemm.pos"), patches_per_frame,

@@ -68,9 +68,14 @@ enum hirest_epilogue {
                                         must be readable up to an EVEN number of rows, i.e. M + 1 rows when M is odd),
                                         aux1 = s [N];  out bf16 = rstd * (acc - mean * s) + b' */
     HIREST_EPI_LNFOLD_GELU_BF16 = 8, /* same, then gelu_erf */
-    HIREST_EPI_BIAS_GELU_SPLIT2 = 9  /* HIREST_GEMM_X3 only: out bf16 [M, 2N] = nn.GELU()(acc + bias) (erf form, fp32) in the split operand format
+    HIREST_EPI_BIAS_GELU_SPLIT2 = 9, /* HIREST_GEMM_X3 only: out bf16 [M, 2N] = nn.GELU()(acc + bias) (erf form, fp32) in the split operand format
                                         of hirest_split2_bf16 (per 64 columns: hi of 32 outputs | their lo): fc1 of the bf16x3 tower feeding fc2
                                         without an fp32 round trip.  N % 32 == 0, ldo >= 2N. */
+    HIREST_EPI_BIAS_RESID2_LNSTATS = 10 /* producer like HIREST_EPI_BIAS_RESID_LNSTATS_F32 with the residual stream kept as two bf16 arrays:
+                                        aux0 = hi [M, N] = bf16(x) (in / out; the next GEMM's A operand), out = lo [M, ldo] = bf16(x - hi)
+                                        (in / out): x' = hi + lo + acc + bias in fp32, hi' = bf16(x'), lo' = bf16(x' - hi'); aux1 = row
+                                        partials of hi' as before.  16 significand bits per residual value, 8 instead of 10 bytes of
+                                        epilogue traffic per element (the bf16 vision tower's blocks, calls of >= 64 frames). */
 };
 
 typedef struct hirest_gemm_args {
@@ -214,6 +219,12 @@ int hirest_write_cls_rows(float* x, int64_t ldx, const float* cls, const float* 
  * about r times the rounding noise of the LayerNorm pass; callers zero it before a tower call and compare afterwards. */
 int hirest_rowstats_bf16(const float* x, int64_t ldx, hirest_bf16* xb, float* stats, float eps, int32_t rows, int32_t D,
                          float* guard, void* stream);
+/* The same with the residual's low part as well: xlo [rows, D] = bf16(x - xb) (the two-array residual stream of
+ * HIREST_EPI_BIAS_RESID2_LNSTATS); hirest_combine_hi_lo_f32 turns rows of it back into fp32 (out = hi + lo). */
+int hirest_rowstats_split_bf16(const float* x, int64_t ldx, hirest_bf16* xb, hirest_bf16* xlo, float* stats, float eps, int32_t rows,
+                               int32_t D, float* guard, void* stream);
+int hirest_combine_hi_lo_f32(const hirest_bf16* hi, const hirest_bf16* lo, int64_t ld_in, float* out, int64_t ldo, int32_t rows,
+                             int32_t D, void* stream);
 int hirest_ln_stats_finalize(const float* partials, int32_t groups, float* stats, float eps, int32_t rows, int32_t D,
                              float* guard, void* stream);
 
@@ -297,7 +308,11 @@ size_t hirest_vision_workspace_bytes(const hirest_vision_tower* t, int32_t B);
  * not fold.  The host layer re-runs a call with HIREST_TOWER_NO_LNFOLD when that value exceeds its threshold. */
 enum { HIREST_TOWER_NO_LNFOLD = 1,
        /* run the last block on every token (A/B timing and the bit-identity test of the pruned form) */
-       HIREST_TOWER_NO_PRUNE = 2 };
+       HIREST_TOWER_NO_PRUNE = 2,
+       /* folded calls: keep the residual stream in the fp32 array x between the blocks (rounds 1-3) instead of as two bf16 arrays hi + lo
+        * (16 significand bits, HIREST_EPI_BIAS_RESID2_LNSTATS: a fifth less epilogue traffic on proj / fc2) — A/B timing and the numerics
+        * test of the two-array form */
+       HIREST_TOWER_F32_RESIDUAL = 4 };
 int hirest_vision_forward(const hirest_vision_tower* t, const void* frames, int32_t in_dtype,
                           int32_t B, float* out, void* workspace, size_t workspace_bytes,
                           int32_t flags, void* stream);

@@ -194,14 +194,16 @@ def test_profiled_kernels_are_the_dispatched_ones(lib):
     lib.hirest_gemm_select_kernel(0)
     lib.hirest_gemm_debug_mode(0)
     Mv, Mp, Mt = 1024 * 257, 1024 * 256, 546 * 77
-    problems = [(Mv, 4224, 1408, _lib.EPI_LNFOLD_BF16), (Mv, 1408, 1408, _lib.EPI_BIAS_RESID_LNSTATS_F32),
-                (Mv, 6144, 1408, _lib.EPI_LNFOLD_GELU_BF16), (Mv, 1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32),
+    problems = [(Mv, 4224, 1408, _lib.EPI_LNFOLD_BF16), (Mv, 1408, 1408, _lib.EPI_BIAS_RESID2_LNSTATS),
+                (Mv, 6144, 1408, _lib.EPI_LNFOLD_GELU_BF16), (Mv, 1408, 6144, _lib.EPI_BIAS_RESID2_LNSTATS),
+                # (HIREST_TOWER_F32_RESIDUAL: the fp32 residual array of rounds 1-3)
+                (Mv, 1408, 1408, _lib.EPI_BIAS_RESID_LNSTATS_F32), (Mv, 1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32),
                 (Mp, 1408, 640, _lib.EPI_PATCH_POS_F32), (1024, 1024, 1408, _lib.EPI_BIAS_F32),
                 # text tower (546 prompts x 77 tokens, width 768): qkv, out_proj, c_fc, c_proj, projection
                 (Mt, 2304, 768, _lib.EPI_BIAS_BF16), (Mt, 768, 768, _lib.EPI_BIAS_RESID_F32), (Mt, 3072, 768, _lib.EPI_BIAS_GELU_BF16),
                 (Mt, 768, 3072, _lib.EPI_BIAS_RESID_F32), (546, 1024, 768, _lib.EPI_BIAS_F32)]
     dispatched = {name(*p) for p in problems}
-    assert {"gemm_pq256<7>", "gemm_pq256<6>", "gemm_pq256<8>", "gemm_pq256<5>"} <= dispatched        # (round 4: the two-phase ping-pong kernel)
+    assert {"gemm_pq256<7>", "gemm_pq256<10>", "gemm_pq256<6>", "gemm_pq256<8>", "gemm_pq256<5>"} <= dispatched        # (round 4: the two-phase ping-pong kernel)
     rounds = sorted(d for d in os.listdir(os.path.join(REPO, "profiles")) if re.fullmatch(r"r\d\d", d))
     # the newest round that holds a traffic profile (a round's directory exists from its first committed measurement on; its
     # counters are collected on the final build)

@@ -38,4 +38,5 @@ d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('bench.py
 timeout 400 python tools/caption_streams_sweep.py 2>&1 | grep -v amdgpu.ids > $out/caption_streams_sweep.txt
 hipcc --offload-arch=gfx950 -O2 -w -o /tmp/gbp tools/probes/grid_barrier_probe.hip && timeout 120 /tmp/gbp > $out/grid_barrier_probe.txt 2>&1
 timeout 300 python tools/c3_run.py --videos 512 --rank-blocks 8 --out $out/c3_512_rank_blocks.json > /dev/null 2>&1
+timeout 400 python tools/c3_run.py --out $out/c3_n1.json > /dev/null 2>&1
 date +%s > $out/collected_at

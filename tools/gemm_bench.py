@@ -16,7 +16,9 @@ SHAPES = {"qkv": (4224, 1408, _lib.EPI_BIAS_BF16), "proj": (1408, 1408, _lib.EPI
           "proj_plain": (1408, 1408, _lib.EPI_BIAS_BF16), "fc2_f32": (1408, 6144, _lib.EPI_BIAS_F32),
           # LayerNorm-fold epilogues (same operands, so the difference to qkv / fc1 / proj / fc2 is the epilogue's cost)
           "qkv_fold": (4224, 1408, _lib.EPI_LNFOLD_BF16), "fc1_fold": (6144, 1408, _lib.EPI_LNFOLD_GELU_BF16),
-          "proj_stats": (1408, 1408, _lib.EPI_BIAS_RESID_LNSTATS_F32), "fc2_stats": (1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32)}
+          "proj_stats": (1408, 1408, _lib.EPI_BIAS_RESID_LNSTATS_F32), "fc2_stats": (1408, 6144, _lib.EPI_BIAS_RESID_LNSTATS_F32),
+          # the same with the residual stream as bf16 hi + bf16 lo (out = lo, aux0 = hi, both in / out)
+          "proj_stats2": (1408, 1408, _lib.EPI_BIAS_RESID2_LNSTATS), "fc2_stats2": (1408, 6144, _lib.EPI_BIAS_RESID2_LNSTATS)}
 
 
 def main():
@@ -59,7 +61,7 @@ def main():
             aux0 = torch.cat([torch.randn((M + 1, 1), device=dev, generator=g) * 0.1, torch.rand((M + 1, 1), device=dev, generator=g) + 0.5], 1)[:M].contiguous()
             aux0 = torch.cat([aux0, aux0[:1]])[:M]
             aux1 = torch.randn((N,), device=dev, generator=g)
-        elif epi == _lib.EPI_BIAS_RESID_LNSTATS_F32:
+        elif epi in (_lib.EPI_BIAS_RESID_LNSTATS_F32, _lib.EPI_BIAS_RESID2_LNSTATS):
             aux0 = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
             aux1 = torch.empty((M, (N + 63) // 64, 2), device=dev)
         import ctypes as C
