@@ -127,11 +127,11 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(
     store_kv(0, 0);
     if (32 < T) fetch_kv(32);
     int buf = 0;
-    // timing tool (tools/attn_x3_trace.py): workgroup 0 stamps the shader clock at the phase boundaries of every tile: [tile][wave][6]
+    // timing tool (tools/attn_x3_trace.py): workgroup 0 stamps the shader clock at the phase boundaries of every tile: [tile][wave][8]
     auto stamp = [&](int k0, int slot) {
         if (trace && blockIdx.x == 0) {
             const long long t = __builtin_readcyclecounter();
-            if (lane == 0) trace[((k0 >> 5) * 16 + wave) * 6 + slot] = t;
+            if (lane == 0) trace[((k0 >> 5) * 16 + wave) * 8 + slot] = t;
         }
     };
     for (int k0 = 0; k0 < T; k0 += 32, buf ^= 1) {
@@ -140,7 +140,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 1 : 2) void attention_x3_kernel(
         // other buffer — read during the previous iteration — is free for the next tile
         __syncthreads();
         stamp(k0, 1);
+        if (trace && blockIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(k0, 6); }   // (tool only: the tile's loads have landed)
         if (k0 + 32 < T) store_kv(k0 + 32, buf ^ 1);
+        stamp(k0, 7);                                                 // (split + LDS stores done: the stamp drains lgkmcnt)
         if (k0 + 64 < T) fetch_kv(k0 + 64);
         stamp(k0, 2);
         const bf16_t* Khb = Kh + buf * KSZ; const bf16_t* Klb = Kl + buf * KSZ;
@@ -262,7 +264,7 @@ static int attention_x3(const float* q, int64_t ldq, const float* k, const float
     return hirest_launch_status();
 }
 
-extern "C" int hirest_attention_x3_debug_trace(int64_t* device_buffer) {   // [tiles <= 16][waves <= 16][6] int64 on the device, or NULL (off)
+extern "C" int hirest_attention_x3_debug_trace(int64_t* device_buffer) {   // [tiles <= 16][waves <= 16][8] int64 on the device, or NULL (off)
     g_x3_trace = reinterpret_cast<long long*>(device_buffer);
     return 0;
 }

@@ -430,8 +430,8 @@ int hirest_attention_x3_qkv_split2(const float* q, int64_t ldq, const float* k, 
  * K / V tiles of its (frame, head), so fewer, larger workgroups read K / V fewer times.  Results are unchanged (per-query arithmetic). */
 int hirest_attention_x3_select_waves(int32_t waves);
 /* Timing tool: workgroup 0 of every following launch stamps the shader clock at six points of every 32-key tile into device_buffer
- * ([tile < 16][wave < 16][6] int64: 0 top, 1 after the barrier, 2 tile staged / next fetch issued, 3 scores issued, 4 softmax done, 5 P.V
- * issued); NULL switches it off (default).  tools/attn_x3_trace.py. */
+ * ([tile < 16][wave < 16][8] int64: 0 top, 1 after the barrier, 6 the next tile's loads landed, 7 split + LDS stores done, 2 next fetch issued,
+ * 3 scores issued, 4 softmax done, 5 P.V issued); NULL switches it off (default).  tools/attn_x3_trace.py. */
 int hirest_attention_x3_debug_trace(int64_t* device_buffer);
 /* A/B and tests: bit 0 = the tower's attention is the exact-fp32 hirest_attention_f32_qkv instead of hirest_attention_x3_qkv; bit 1 = fc1 writes fp32
  * and GELU + split run as a separate pass (hirest_split2_bf16) instead of in its epilogue (HIREST_EPI_BIAS_GELU_SPLIT2).  Default 0. */

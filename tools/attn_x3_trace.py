@@ -17,7 +17,7 @@ qkv = torch.randn((B * T, 3 * D), device=dev, generator=g)
 out = torch.empty((B * T, D), device=dev)
 lib = _lib.load()
 lib.hirest_attention_x3_select_waves(a.waves)
-trace = torch.zeros((16, 16, 6), dtype=torch.int64, device=dev)
+trace = torch.zeros((16, 16, 8), dtype=torch.int64, device=dev)
 
 
 def run():
@@ -43,4 +43,7 @@ names = ["wait at barrier (0->1)", "store tile t+1 to LDS, fetch t+2 (1->2)", "S
 print(f"{'phase':46s}" + "".join(f"  wave{w:2d}" for w in range(nw)))
 for i, name in enumerate(names[:5]):
     print(f"{name:46s}" + "".join(f"{(t[1:8, w, i + 1] - t[1:8, w, i]).mean():8.0f}" for w in range(nw)))
+    if i == 1:   # the staging step in three parts: loads of tile t+1 land (1->6), split + LDS stores (6->7), fetch of t+2 issued (7->2)
+        for sub, (a0, a1) in (("   of which: waiting for the tile's loads", (1, 6)), ("             split + LDS stores", (6, 7)), ("             issuing the next fetch", (7, 2))):
+            print(f"{sub:46s}" + "".join(f"{(t[1:8, w, a1] - t[1:8, w, a0]).mean():8.0f}" for w in range(nw)))
 print(f"{names[5]:46s}" + "".join(f"{(t[2:9, w, 0] - t[1:8, w, 0]).mean():8.0f}" for w in range(nw)))
