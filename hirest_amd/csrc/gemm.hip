@@ -1632,7 +1632,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (epi == HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;      // exists in the X3 form only
     const bool fused = (epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32 && epi <= HIREST_EPI_LNFOLD_GELU_BF16) || epi == HIREST_EPI_BIAS_RESID2_LNSTATS;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
-    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x10000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
+    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x30000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
     if (f == 9 || (fused && f != 6 && f != 8) || (!fused && f == 0 && big && !dbg_inst)) snprintf(out, out_len, "gemm_pq256<%d>", epi);
     else if (fused) {
@@ -1661,8 +1661,8 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.pos = a->pos; p.P = a->patches_per_frame;
     p.aux0 = a->aux0; p.aux1 = a->aux1;
     p.rev = ((a->flags & HIREST_GEMM_REVERSE) && !(g_gemm_dbg & 512)) ? 1 : 0;   // debug bit 9: ignore the direction flags (A/B)
-    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x10000);
-    p.sched = (g_gemm_dbg >> 16) & 1;
+    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x30000);
+    p.sched = (g_gemm_dbg >> 16) & 3;     // bit 16: uneven XCD split; bit 17: the two-array residual epilogue loads hi / lo cached instead of streaming (A/B)
     p.stagger = (g_gemm_dbg >> 10) & 3;
     p.epi_dbg = (g_gemm_dbg >> 12) & 15;   // A/B experiment: start the CUs of an XCD 0..3 quarter tiles apart (bits 10-11 = mode)
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;

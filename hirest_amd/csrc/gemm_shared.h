@@ -107,8 +107,13 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
                 union { bf16x8 v; bf16x4 h[2]; float f[4]; } hv, lv;
                 hv.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; lv.v = hv.v;
                 if (col + 8 <= p.N && !(p.epi_dbg & 1)) {
-                    hv.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xb + mr * p.N + col));
-                    lv.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xlo + mr * p.ldo + col));
+                    if (p.sched & 2) {                               // A/B (hirest_gemm_debug_mode bit 17): cached instead of streaming loads
+                        hv.v = *reinterpret_cast<const bf16x8*>(xb + mr * p.N + col);
+                        lv.v = *reinterpret_cast<const bf16x8*>(xlo + mr * p.ldo + col);
+                    } else {
+                        hv.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xb + mr * p.N + col));
+                        lv.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xlo + mr * p.ldo + col));
+                    }
                 }
                 // (raw bits into the ring: decoding here would wait for the loads and undo the look-ahead — decode_s2 runs when the pass is due)
                 o[0][it] = __builtin_bit_cast(f32x4, hv.v);
