@@ -294,8 +294,10 @@ def main():
         _, val, idx = retrieval.retrieve(text_n, allv, min(TOPK, V_total))
         return idx
 
+    tinfo = {}
     elapsed, idx = launch.timed_steps(step, args.warmup, args.steps, torch.cuda.synchronize,
-                                      on_timed_start=(None if args.no_profile else (lambda: lib.hirest_profile_enable(1))), reduce_device=dev)
+                                      on_timed_start=(None if args.no_profile else (lambda: lib.hirest_profile_enable(1))), reduce_device=dev,
+                                      info=tinfo)
     # per-launch records of the timed steps (this rank)
     recs = (_lib.ProfRecord * 200000)()
     nrec = lib.hirest_profile_collect(recs, len(recs))
@@ -369,7 +371,11 @@ def main():
                         "breakdown": breakdown[:12]}
         out = {"metric": "encoded frames/sec (EVA-CLIP-g/14 224^2)", "value": value, "unit": "frames/s",
                "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": elapsed / args.steps * 1e3,
+               # every rank's own time per step up to its own device sync, before the closing barrier (ms_per_step is their MAX + the barrier):
+               # the first real N-GPU run shows skew between ranks, not just a sum
+               "ms_per_step_by_rank": [t / args.steps * 1e3 for t in tinfo.get("per_rank_s", [])],
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "EVA-CLIP-g/14 frame encoder, 1024-frame synthetic batch bf16 per GPU per step "
                                       "(BASELINE configs[1]) as 32 videos x 32 frames -> mean-pool+L2 -> all-gather "

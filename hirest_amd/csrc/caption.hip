@@ -329,7 +329,7 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
 
     // (the LM head's LayerNorm-prologue form exists as the streaming kernel for D = 768 only: hirest_gemm_f32_ln rejects N >= 8192
     //  with another depth, so such a decoder takes the separate-kernel path instead of failing the step)
-    const bool fused_ln = g_caption_mode == 0 && R <= 32 && D % 256 == 0 && D <= 1024 && (d->vocab_padded < 8192 || D == 768);
+    const bool fused_ln = g_caption_mode == 0 && R <= 256 && D % 256 == 0 && D <= 1024 && (d->vocab_padded < 8192 || D == 768);
     if (fused_ln) {
         // every LayerNorm (and the token + position embedding) is the prologue of the GEMM that consumes it (hirest_gemm_f32_ln):
         // a = the pre-LayerNorm sum of the previous sub-layer, x / b = the normalised rows (written by the GEMM, residual of the next)
@@ -361,7 +361,17 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
                               D, 1, stream));
         // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU); for the
         // one-call beam step it also leaves the maxima of its 16-column tiles for the tail
-        if (tile_max_out && d->vocab_padded >= 8192 && D == 768) {
+        if (R > 32 && d->vocab_padded >= 8192) {
+            // more rows than the streaming LM head holds (a merged search: 60 - 160 beam rows): LayerNorm, then the plain product
+            CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
+            if (tile_max_out && D == 768) {                  // the row-group streaming LM head, which also leaves the tile maxima for the tail
+                float* tm = reinterpret_cast<float*>(base + w.tm);
+                CK(hirest_gemm_f32_rows_colmax(b, D, d->lm_w, D, d->lm_b, logits, d->vocab_padded, tm, R, d->vocab_padded, D, stream));
+                *tile_max_out = tm;
+            } else {
+                CK(hirest_gemm_f32(b, D, d->lm_w, D, d->lm_b, nullptr, 0, nullptr, 0, logits, d->vocab_padded, R, d->vocab_padded, D, 0, stream));
+            }
+        } else if (tile_max_out && d->vocab_padded >= 8192 && D == 768) {
             float* tm = reinterpret_cast<float*>(base + w.tm);
             CK(hirest_gemm_f32_ln_colmax(x, D, d->tr_ln_g, d->tr_ln_b, eps, d->lm_w, D, d->lm_b, logits, d->vocab_padded, tm, R, d->vocab_padded, D,
                                          stream));

@@ -823,6 +823,207 @@ int launch_m16ln_stream(const GemmLN& q, hipStream_t s, int lds_max) {
     return hirest_launch_status();
 }
 
+// The LM head of a MERGED beam search (33 .. 256 rows: 20 - 32 videos x 3 - 5 beams; round 5).  Too many rows for one block's registers,
+// and by now a compute problem, not a weight stream: 160 x 30 528 x 768 is 7.5 GFLOP = 48 us of v_mfma_f32_16x16x4_f32 on 256 CUs,
+// while the 94 MB of W take 12 us of HBM.  So: NG row groups of 16 MT rows; a block owns one row group and one of the column-tile
+// streams, its four waves = the four K quarters of the shared summation order, each keeping the A fragments of its quarter in
+// registers for good (MT x 48 floats, read once from the already-normalised rows) and streaming W through a private LDS-DMA ring that
+// never drains: the tile loop has ONE bare barrier per tile (s_waitcnt lgkmcnt(0) + s_barrier — __syncthreads() also waits for vmcnt(0),
+// i.e. empties the ring at every tile), the four partial tiles meet in a double-buffered LDS buffer, and the wave that adds them,
+// applies the bias (pre-loaded into LDS: no vector load inside the loop, so no compiler-placed vmcnt(0) either) and stores rotates
+// with the tile number, so no wave is the one the others wait for.  Fragments of slab s + 1 are read while slab s multiplies.
+// The NG blocks that stream the same tiles sit on the same XCD (blockIdx % 8) next to each other and run in step, so W is pulled
+// from memory once and served to the other row groups by that XCD's L2.
+template <int NS, int MT, int DEPTH>
+__global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmF p, float* __restrict__ colmax, int ng, int max_mine) {
+    static_assert(NS % 2 == 0, "the fragment double buffer alternates by slab parity");
+    constexpr int SLAB = 2048, L = 2, GA = MT * NS;          // the first GA slabs of a wave's stream are its A tiles, then W
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x DEPTH slabs | red[2][4][MT][64] f32x4 | bias of this block's tiles
+    const int tid = threadIdx.x, lane = tid & 63, kq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15, slot = lane >> 4;
+    const bool odd = slot >> 1;
+    char* ring = smem + kq * DEPTH * SLAB;
+    f32x4 (*red)[4][MT][64] = reinterpret_cast<f32x4 (*)[4][MT][64]>(smem + 4 * DEPTH * SLAB);
+    float* bias_lds = reinterpret_cast<float*>(smem + 4 * DEPTH * SLAB + 2 * 4 * MT * 1024);
+    auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
+    // block -> (XCD, row group, column stream): the ng row groups of a stream are consecutive slots of one XCD
+    const int xcd = (int)blockIdx.x & 7, xslot = (int)blockIdx.x >> 3;
+    const int rg = xslot % ng, cs = xslot / ng;
+    const int ncs = (((int)gridDim.x >> 3) / ng) * 8;       // launcher: gridDim.x = 8 ng k
+    const int stream = cs * 8 + xcd;
+    const int ntile = (p.N + 15) / 16;
+    const int mine = stream < ntile ? (ntile - 1 - stream) / ncs + 1 : 0;      // tiles stream, stream + ncs, ...
+    if (mine == 0) return;                                   // (block-uniform)
+    const int M0 = rg * 16 * MT;
+    const int first = kq * NS;
+    const int items = mine * NS, total = GA + items;         // this wave's stream: A (tile t, slab sl), then W (tile i, slab sl)
+    // The bias of this block's tiles -> LDS (tile i at floats 16 i .. + 15), by LDS-DMA from wave 0 BEFORE its ring starts: the
+    // oldest vector-memory operation of the wave, so every later counted wait implies it, and the only vector loads of the kernel
+    // stay the ring's (a plain load anywhere in the loop makes the compiler wait for vmcnt(0) = empty the ring).
+    if (kq == 0 && p.bias) {
+        for (int r = 0; r < max_mine; r += 16) {
+            const int i = r + (lane >> 2);
+            int n = (stream + (i < mine ? i : mine - 1) * ncs) * 16 + 4 * (lane & 3);
+            n = n + 4 <= p.N ? n : p.N - 4;
+            glds16(p.bias + n, bias_lds + 16 * r);
+        }
+    }
+    const int trow0 = lane >> 3, chunk_lane = lane & 7;
+    const char* wrow[L];
+    auto a_rows = [&](int t) {                               // A tile t as a "column tile": its 16 rows x this wave's K quarter
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int trow = 8 * j + trow0;
+            int gm = M0 + 16 * t + trow; gm = gm < p.M ? gm : p.M - 1;
+            wrow[j] = reinterpret_cast<const char*>(p.A + (int64_t)gm * p.lda) + 16 * (chunk_lane ^ swz(trow)) + (int64_t)first * (FK * 4);
+        }
+    };
+    auto w_rows = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int trow = 8 * j + trow0;
+            int gn = (stream + i * ncs) * 16 + trow; gn = gn < p.N ? gn : p.N - 1;
+            wrow[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * (chunk_lane ^ swz(trow)) + (int64_t)first * (FK * 4);
+        }
+    };
+    int psl = 0, pi = -MT, prs = 0, issued = 0;              // producer: slab psl of tile pi (pi < 0: A tile pi + MT)
+    a_rows(0);
+    auto dma = [&]() {
+        char* dst = ring + prs * SLAB;
+#pragma unroll
+        for (int j = 0; j < L; ++j) glds16(wrow[j] + psl * (FK * 4), dst + j * 1024);
+        ++issued;
+        prs = prs + 1 == DEPTH ? 0 : prs + 1;
+        if (++psl == NS) {
+            psl = 0; ++pi;
+            if (pi < 0) a_rows(pi + MT); else w_rows(pi);    // (rows past the last tile are clamped: never requested)
+        }
+    };
+#pragma unroll 1
+    for (int u = 0; u < DEPTH; ++u)
+        if (issued < total) dma();
+    // fragment of instruction 2 c + e: element 2 e + odd of chunk 4 (slot & 1) + c -> two dwords 8 B apart (one ds_read2_b32)
+    int fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fo[c] = idx * 128 + (((4 * (slot & 1) + c) ^ swz(idx)) << 4) + (odd ? 4 : 0);
+    auto read_frags = [&](int rs, float (&w)[4][2]) {
+        const char* wb = ring + rs * SLAB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* wp = reinterpret_cast<const float*>(wb + fo[c]);
+            w[c][0] = wp[0]; w[c][1] = wp[2];
+        }
+    };
+    // slabs g .. issued - 1 are in flight, in order: slab g has landed once at most DEPTH - 1 slabs are pending (or, near the end of
+    // the stream, once nothing is)
+    auto landed = [&](int g) {
+        if (total - g >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // this wave's A fragments for good: row tile t, slab sl, instruction 2 c + e -> the lane's k slot
+    float af[MT][NS][4][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            constexpr int D_ = DEPTH;
+            const int g = t * NS + sl;                       // (compile-time after unrolling)
+            landed(g);
+            read_frags(g % D_, af[t][sl]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's reads have returned before it is refilled
+            if (issued < total) dma();
+        }
+    float wq[2][4][2];
+    landed(GA);
+    read_frags(GA % DEPTH, wq[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (issued < total) dma();
+    f32x4 acc[MT];
+    int it = 0, rs = (GA + 1) % DEPTH;                       // rs: ring slot of W slab it + 1
+#pragma unroll 1
+    for (int i = 0; i < mine; ++i) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl, ++it) {
+            const bool more = it + 1 < items;
+            if (more) {                                      // fragments of slab it + 1 are read while slab it multiplies
+                landed(GA + it + 1);
+                read_frags(rs, wq[(sl + 1) & 1]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[sl & 1][c][e], af[t][sl][c][e], acc[t], 0, 0, 0);
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                rs = rs + 1 == DEPTH ? 0 : rs + 1;
+                if (issued < total) dma();
+            }
+        }
+        // the four K quarters of tile i meet in red[i & 1]; wave i % 4 adds them in the shared order and stores
+        const int buf = i & 1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[buf][kq][t][lane] = acc[t];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kq == (i & 3)) {
+            const int tile = stream + i * ncs, n = tile * 16 + 4 * slot;
+            Epi4 ep;
+            ep.resid = f32x4{0.f, 0.f, 0.f, 0.f}; ep.periodic = ep.resid;
+            ep.bias = p.bias ? *reinterpret_cast<const f32x4*>(bias_lds + 16 * i + 4 * slot) : ep.resid;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int m = M0 + 16 * t + idx;
+                const bool in = n < p.N && m < p.M;
+                const f32x4 sum = ((red[buf][0][t][lane] + red[buf][1][t][lane]) + red[buf][2][t][lane]) + red[buf][3][t][lane];
+                const f32x4 v = epilogue_apply4(p, sum, ep, m, n, in);
+                if (colmax) {                                // (uniform) the tile's maximum per row: the beam tail's row max without a row scan
+                    float mx = in ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
+                    { float pa = mx, pb = mx; lane_swap16(pa, pb); mx = fmaxf(pa, pb); pa = mx; pb = mx; lane_swap32(pa, pb); mx = fmaxf(pa, pb); }
+                    if (slot == 0 && m < p.M) colmax[(int64_t)m * ntile + tile] = mx;
+                }
+            }
+        }
+    }
+}
+
+template <int NS, int MT, int DEPTH>
+int launch_rows_stream(const GemmF& p, float* colmax, int ng, hipStream_t s) {
+    static HirestDevCfg cfg;
+    int cus = 0;
+    auto kern = gemm_f32_rows_stream_kernel<NS, MT, DEPTH>;
+    constexpr int FIXED = 4 * DEPTH * 2048 + 2 * 4 * MT * 1024;
+    static_assert(FIXED + 4096 <= 160 * 1024, "does not fit the LDS");
+    if (int e = hirest_configure(kern, 160 * 1024, cfg, &cus)) return e;
+    const int ntile = (p.N + 15) / 16;
+    int per_xcd = cus / 8 < 1 ? 1 : cus / 8;                // one block per CU; blockIdx % 8 = XCD
+    int k = per_xcd / ng; if (k < 1) k = 1;                 // column streams per XCD
+    const int ncs = 8 * k;
+    const int max_mine = (ntile + ncs - 1) / ncs;
+    const int lds = FIXED + max_mine * 64;
+    if (lds > 160 * 1024) return HIREST_E_SHAPE;
+    hipLaunchKernelGGL(kern, dim3(8 * ng * k), dim3(256), lds, s, p, colmax, ng, max_mine);
+    return hirest_launch_status();
+}
+
+// M rows as ng groups of mt 16-row tiles (mt <= 5: MT x 48 fragment registers per wave), least padding first, then fewer groups
+static int rows_stream(const GemmF& p, float* colmax, hipStream_t s) {
+    const int tiles = (p.M + 15) / 16;
+    int mt = 5, ng = (tiles + 4) / 5;
+    for (int m = 4; m >= 2; --m) {
+        const int g = (tiles + m - 1) / m;
+        if (g * m < ng * mt || (g * m == ng * mt && g < ng)) { mt = m; ng = g; }
+    }
+    switch (mt) {
+        case 2: return launch_rows_stream<6, 2, 14>(p, colmax, ng, s);
+        case 3: return launch_rows_stream<6, 3, 14>(p, colmax, ng, s);
+        case 4: return launch_rows_stream<6, 4, 14>(p, colmax, ng, s);
+        default: return launch_rows_stream<6, 5, 14>(p, colmax, ng, s);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 flash attention, head dim 64, full (unmasked) attention over T keys with the reference's uniform
 // additive constant: s = fl(fl(q.k * scale) + add_const) (module_visual.py:164-176 with the all-zeros mask
@@ -1332,6 +1533,15 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     // blockIdx.y — whole-line operand traffic beats the split-K kernel's lane = row loads (ASR encoder 108 -> 117 k sentences/s)
     if (M > 32 && M <= 256 && K % FK == 0 && g_f32_kernel == 0 && N < 8192)
         return launch_m16<2, 1, 6>(p, reinterpret_cast<hipStream_t>(stream));
+    // a merged beam search's LM head (60 - 160 rows x 30 522 columns): A fragments in registers, W streamed once per row group
+    if (M > 32 && M <= 256 && N >= 8192 && K == 768 && !resid && !periodic && g_f32_kernel == 0)
+        return rows_stream(p, nullptr, reinterpret_cast<hipStream_t>(stream));
+    // other wide problems of 48 - 256 rows: the 64x64 kernel beats the split-K kernel's lane = row loads from 60 rows on (LM head: 63 vs 97 us at
+    // 96 rows, 93 vs 150 at 160)
+    if (M >= 48 && M <= 256 && N >= 8192 && g_f32_kernel == 0) {
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+        return hirest_launch_status();
+    }
     if (M <= 32 && K % FK == 0 && g_f32_kernel == 0) {
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         // one row tile per block for the decoder's layers (2 x N / 16 blocks share the operand traffic; 8 slabs in flight per wave,
@@ -1381,7 +1591,10 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
                                   int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M,
                                   int32_t N, int32_t K, int32_t act, void* stream) {
     if ((!X && !(ids && table && pos_row)) || !gamma || !beta || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
-    if (M > 32 || K % 256 != 0 || K > 1024 || N % 4 != 0 || ldw % 4 != 0 || (X && ldx % 4 != 0) || (ln_out && ldl % 4 != 0)) return HIREST_E_SHAPE;
+    // the 16-row blocks of the layer form tile any number of rows across blockIdx.y (a merged beam search: 60 - 160 rows per word);
+    // the LM-head stream keeps all its rows in one block's registers: 32 at most
+    if (M > 256 || K % 256 != 0 || K > 1024 || N % 4 != 0 || ldw % 4 != 0 || (X && ldx % 4 != 0) || (ln_out && ldl % 4 != 0)) return HIREST_E_SHAPE;
+    if (M > 32 && N >= 8192) return HIREST_E_SHAPE;
     GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act, nullptr}, X, ldx, ids, table, pos_row, gamma, beta, eps,
              ln_out, ldl, g_ln_colmax};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1419,6 +1632,16 @@ extern "C" int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const floa
     const int e = hirest_gemm_f32_ln(X, ldx, nullptr, nullptr, nullptr, gamma, beta, eps, nullptr, 0, W, ldw, bias, nullptr, 0, out, ldo, M, N, K, 0, stream);
     g_ln_colmax = nullptr;
     return e;
+}
+
+// out = A @ W^T + bias for the rows of a merged beam search (K = 768, N >= 16) through the row-group streaming kernel, which
+// also reports colmax[M, ceil(N / 16)]: per row, the maximum of each 16-column tile of `out` (NULL: not wanted).
+extern "C" int hirest_gemm_f32_rows_colmax(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
+                                           float* colmax, int32_t M, int32_t N, int32_t K, void* stream) {
+    if (!A || !W || !out || M <= 0 || N <= 0) return HIREST_E_BADARG;
+    if (K != 768 || M > 1280 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || ldo % 4 != 0) return HIREST_E_SHAPE;
+    GemmF p{A, lda, W, ldw, bias, nullptr, 0, nullptr, 0, out, ldo, M, N, K, 0, nullptr};
+    return rows_stream(p, colmax, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int hirest_gemm_f32_layouts(const float* A, int64_t lda, int32_t a_kmajor, const float* W, int64_t ldw, int32_t w_kmajor,

@@ -85,9 +85,12 @@ def init_ranks(n_expected: int, backend: str = "nccl", device=None) -> Tuple[int
 
 
 def timed_steps(step: Callable[[], object], warmup: int, steps: int, sync: Callable[[], None],
-                on_timed_start: Optional[Callable[[], None]] = None, reduce_device=None) -> Tuple[float, object]:
+                on_timed_start: Optional[Callable[[], None]] = None, reduce_device=None,
+                info: Optional[dict] = None) -> Tuple[float, object]:
     """The bench contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier and a device sync
-    on both sides; returns (elapsed seconds = MAX over ranks, last step's result)."""
+    on both sides; returns (elapsed seconds = MAX over ranks, last step's result).  `info` (a dict), when given, receives
+    ``per_rank_s``: every rank's own time from the common start to its own device sync, BEFORE the closing barrier — the skew
+    between ranks that the MAX hides (a slow GPU, a late gather)."""
     import torch
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -104,11 +107,20 @@ def timed_steps(step: Callable[[], object], warmup: int, steps: int, sync: Calla
     for _ in range(steps):
         out = step()
     sync()
+    own = time.perf_counter() - t0
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device if reduce_device is not None else "cpu")
+        rd = reduce_device if reduce_device is not None else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rd)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if info is not None:
+            mine = torch.tensor([own], dtype=torch.float64, device=rd)
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            info["per_rank_s"] = [float(e.item()) for e in every]
+    elif info is not None:
+        info["per_rank_s"] = [own]
     return elapsed, out

@@ -783,10 +783,41 @@ class MomentModel(nn.Module):
                 break
         return self._caption_result(beams, return_ids)
 
+    CAPTION_ROWS_IN_FLIGHT = 160      # beam rows of one merged search (caption_batches): 32 videos x 5 beams, the reference's default eval batch
+
+    def _caption_merge(self, group, dev):
+        """Several loader batches as ONE step-captioning batch: each batch is trimmed on its own (its T and its moment mask), the
+        [B_i, max_frames, D] results are concatenated and the merged batch carries an all-ones moment mask — trim_feats of exactly
+        max_frames selected rows is the identity, and rows a short moment left at zero stay zero.  Every kernel downstream is
+        batch-invariant, so a video's caption does not depend on what it is merged with."""
+        max_frames = int(getattr(self.args, "max_frames_step_captioning", 20)) if self.args is not None else 20
+        vs, as_, ts = [], [], []
+        for b in group:
+            vis = b["vis_feats"].to(dev).float()
+            rows = self._trim_rows(b["moment_mask"], max_frames, dev)
+            vs.append(self._trim(vis, None, max_frames, idx=rows))
+            if self.use_asr:
+                as_.append(self._trim(b["asr_feats"].to(dev).float(), None, max_frames, idx=rows))
+            ts.append(self._text_feat(b, dev))
+        v = torch.cat(vs, 0)
+        merged = {"tasks": ["step_captioning"], "vis_feats": v, "moment_mask": torch.ones((v.shape[0], max_frames), dtype=torch.long),
+                  "text_feat": torch.cat(ts, 0)}
+        if self.use_asr:
+            merged["asr_feats"] = torch.cat(as_, 0)
+        return merged
+
     @torch.no_grad()
-    def caption_batches(self, batches, num_beams=5, streams=4, return_ids=False, graphs=True):
+    def caption_batches(self, batches, num_beams=5, streams=2, return_ids=False, graphs=True, merge=True, rows_in_flight=None):
         """Step captioning over a LIST of loader batches (the evaluation loop of run.py:328-336 / modeling.py:556-632 calls
-        test_step once per batch) with up to `streams` batches in flight, each on its own HIP stream and host thread.
+        test_step once per batch).
+
+        merge=True (default): consecutive batches are captioned by ONE beam search over the union of their beam rows, up to
+        `rows_in_flight` rows (default CAPTION_ROWS_IN_FLIGHT = 160 = the reference's default --eval_batch_size 32 at beam 5,
+        args.py:27) — a word's 162 MB of decoder weights are then streamed once for all of them instead of once per batch; each
+        sample keeps its own done flag and the search ends when all have emitted [SEP].  The merged groups (if more than one) then go
+        through the machinery below, up to `streams` in flight.  merge=False: every loader batch is its own search (round 4).
+
+        Up to `streams` searches in flight, each on its own HIP stream and host thread.
 
         Why: one batch of 5 videos x 5 beams is 25 rows — a word step is ~20 dependent kernels of a few microseconds each, bound by
         launch and memory latency, not by the 162 MB of weights it streams: the GPU is mostly idle.  Independent batches
@@ -795,6 +826,29 @@ class MomentModel(nn.Module):
         exactly what ``test_step`` returns for it alone.  Returns the per-batch result dicts in order."""
         import threading
         batches = list(batches)
+        if merge and len(batches) > 1:
+            dev0 = self._w()["dev"]
+            cap = max(1, int(rows_in_flight or self.CAPTION_ROWS_IN_FLIGHT) // max(1, num_beams))      # videos per merged search
+            groups, cur, cnt = [], [], 0
+            for b in batches:
+                nb = int(b["vis_feats"].shape[0])
+                if cur and cnt + nb > cap:
+                    groups.append(cur); cur, cnt = [], 0
+                cur.append(b); cnt += nb
+            if cur:
+                groups.append(cur)
+            if any(len(g) > 1 for g in groups):
+                with torch.cuda.device(dev0):
+                    merged = [self._caption_merge(g, dev0) if len(g) > 1 else g[0] for g in groups]
+                res = self.caption_batches(merged, num_beams=num_beams, streams=streams, return_ids=return_ids, graphs=graphs, merge=False)
+                out = []
+                for g, r in zip(groups, res):           # hand each loader batch its own slice of the merged result
+                    lo = 0
+                    for b in g:
+                        nb = int(b["vis_feats"].shape[0])
+                        out.append({k: v[lo:lo + nb] for k, v in r.items()})
+                        lo += nb
+                return out
         n = max(1, min(int(streams), len(batches)))
         c = self._w()                                       # weight cache built (and the kernels' per-device setup done) before the threads
         dev = c["dev"]

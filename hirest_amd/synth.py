@@ -398,7 +398,11 @@ def joint_inputs(name, B, T, seed):
 TRAIN_CASES = {"a": (3, 64), "b": (2, 300)}
 # step-captioning goldens (tests/golden/caption_predictions.json): case -> (B, T, beams, moment lengths)
 CAPTION_CASES = {"a": (3, 64, 3, [7, 20, 37]), "b": (2, 300, 5, [7, 20]),
-                 "c3": (5, 300, 3, [15] * 5), "c5": (5, 300, 5, [15] * 5)}
+                 "c3": (5, 300, 3, [15] * 5), "c5": (5, 300, 5, [15] * 5),
+                 # the reference's default evaluation batch (args.py:27 --eval_batch_size 32): 96 / 160 beam rows per word, moments
+                 # shorter than, equal to and longer than max_frames mixed in one batch
+                 "d3": (32, 300, 3, [[15, 7, 20, 37, 12, 25, 3, 18][b % 8] for b in range(32)]),
+                 "d5": (32, 300, 5, [[15, 7, 20, 37, 12, 25, 3, 18][b % 8] for b in range(32)])}
 
 
 def train_targets(name, B, T, seed, bounds):

@@ -57,7 +57,7 @@ _SIDE = {}
 class _K:
     """Thin tensor-level wrappers over the training entry points (device fp32 contiguous in, fresh tensors out)."""
 
-    _memo = None     # split operands of the current backward: (data_ptr, shape, stride) -> [normal, transposed]
+    _memo = None     # split operands of the current backward: (data_ptr, shape, stride) -> [normal, transposed, the source tensor]
 
     @staticmethod
     def _x3(M=1, N=1):
@@ -71,8 +71,8 @@ class _K:
         key = (x.data_ptr(), tuple(x.shape), x.stride(0))
         ent = _K._memo.get(key) if _K._memo is not None else None
         if ent is None:
-            ent = [None, None]
-            if _K._memo is not None:
+            ent = [None, None, x]          # x itself is held: a freed dY's address is readily reused by the next [R, 768] gradient of the
+            if _K._memo is not None:       # same backward, and the key (pointer, shape, stride) would then return the stale split
                 _K._memo[key] = ent
         need_n, need_t = normal and ent[0] is None, transposed and ent[1] is None
         if need_n or need_t:

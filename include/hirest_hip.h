@@ -471,7 +471,8 @@ int hirest_gemm_f32_layouts(const float* A, int64_t lda, int32_t a_kmajor, const
  * share K, operands by LDS-DMA; other M <= 256: the split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the
  * 64x64 kernel, 2 = automatic without the 16-column kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */
 int hirest_gemm_f32_select_kernel(int32_t which);
-/* out = act(LayerNorm(X; gamma, beta, eps) @ W^T + bias) (+ resid) for M <= 32 rows, K % 256 == 0, K <= 1024: the rows are
+/* out = act(LayerNorm(X; gamma, beta, eps) @ W^T + bias) (+ resid) for M <= 256 rows (N < 8192; the LM-head form N >= 8192, K = 768
+ * takes M <= 32), K % 256 == 0, K <= 1024: the rows are
  * normalised inside the GEMM with hirest_layernorm's own arithmetic (same bits as the two calls), and written to ln_out as well
  * when it is not NULL.  With ids != NULL, X[r] = table[ids[r]] + pos_row (table rows of K floats): a decoding step's token +
  * position embedding (module_decoder.py embeddings + LayerNorm).  Replaces hirest_layernorm + hirest_gemm_f32 (and
@@ -485,6 +486,13 @@ int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* ids, const fl
  * instead of scanning the rows for their maximum). */
 int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const float* gamma, const float* beta, float eps, const float* W, int64_t ldw,
                               const float* bias, float* out, int64_t ldo, float* colmax, int32_t M, int32_t N, int32_t K, void* stream);
+/* out = A @ W^T + bias for the beam rows of a MERGED search (K = 768; any M, meant for 33 .. 256): row groups of 32 - 80 rows, each wave's A
+ * fragments in registers, W streamed once per row group through LDS-DMA rings (the groups of a column stream share an XCD's L2); the
+ * shared fp32 summation order, so bit-identical to hirest_gemm_f32.  colmax (may be NULL) [M, ceil(N / 16)]: per row, the maximum of
+ * each 16-column tile of `out`.  The LM head of clip4caption's decoder (module_decoder.py:247-277) at the reference's default
+ * --eval_batch_size 32 (args.py:27). */
+int hirest_gemm_f32_rows_colmax(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
+                                float* colmax, int32_t M, int32_t N, int32_t K, void* stream);
 /* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*dh]; no key masking (the
  * reference passes an all-zeros mask, i.e. add_const = -10000 on every score: SURVEY hazard H3).  dh: any multiple of 4 up to 96
  * (instantiations for 32, 64 and 96 columns; a head gives the same bits in each one that holds it); blocks of one wave (sequences of

@@ -166,7 +166,8 @@ def _case(golden_dir, case):
     return shapes, pred, g, joint_inputs(f"joint.{case}", pred["B"], pred["T"], 41)
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c120", "c571", "c1855"])     # c*: SURVEY 8d C4 sizes (B = 5), real-reference goldens
+# c*: SURVEY 8d C4 sizes (B = 5; c300 = the notebook's own operating point), d300: args.py:27's default eval batch of 32; real-reference goldens
+@pytest.mark.parametrize("case", ["a", "b", "c120", "c300", "c571", "c1855", "d300"])
 def test_moment_model_vs_reference(dev, golden_dir, case):
     import hirest_amd
     shapes, pred, g, (vis, asr, text, vis_mask, moment_mask, bounds) = _case(golden_dir, case)
@@ -200,7 +201,9 @@ def test_moment_model_vs_reference(dev, golden_dir, case):
         model.test_step({"tasks": ["something_else"]})
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c3", "c5"])    # c3 / c5: BASELINE configs[4]'s own operating point (B = 5, beam 3 / 5)
+# c3 / c5: BASELINE configs[4]'s own operating point (B = 5, beam 3 / 5); d3 / d5: the reference's default evaluation batch
+# (args.py:27 --eval_batch_size 32: 96 / 160 beam rows per word, all three trim branches in one batch)
+@pytest.mark.parametrize("case", ["a", "b", "c3", "c5", "d3", "d5"])
 def test_step_captioning_vs_reference(dev, golden_dir, case):
     """BASELINE configs[4] in miniature: trim_feats + encoder + beam-searched decoder; token ids exact vs the
     REAL reference MomentModel.test_step (tests/golden/caption_predictions.json)."""
@@ -241,7 +244,7 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
     model.caption_kv_cache = False
     assert model.test_step(batch, num_beams=pred["beams"], return_ids=True)["token_ids"] == res["token_ids"]
     # greedy decoding (one beam) and a wider beam through both paths
-    for nb in (1, 7):
+    for nb in (1, 7) if B <= 5 else (2,):
         model.caption_kv_cache = False
         ref = model.test_step(batch, num_beams=nb, return_ids=True)["token_ids"]
         model.caption_kv_cache = True
@@ -266,6 +269,39 @@ def test_lm_head_tile_maxima(dev, M):
                                              cm.data_ptr(), M, N, K, st), "gemm_ln_colmax")
     assert torch.equal(out, ref)
     assert torch.equal(cm, ref.reshape(M, N // 16, 16).max(-1).values)
+
+
+@pytest.mark.parametrize("M,N", [(160, 30528), (96, 30528), (100, 30528), (60, 30528), (33, 30528), (256, 30528), (17, 8200), (130, 8200),
+                                 (75, 1000), (330, 30528), (160, 16)])
+def test_lm_head_row_groups_equal_the_64x64_kernel(dev, M, N):
+    """hirest_gemm_f32_rows_colmax (a merged beam search's LM head: row groups of 32 - 80 rows, A fragments in registers, W streamed
+    through LDS-DMA rings, rotating reducer wave) against the 64x64 kernel: same summation order -> bit for bit, every row-tile /
+    row-group split (mt 2..5, ng 1..5), a last tile cut by N, and the 16-column tile maxima; hirest_gemm_f32's automatic dispatch
+    takes it for 33 .. 256 rows."""
+    from hirest_amd import _lib, ops
+    from hirest_amd.moment_model import MomentModel
+    lib, st = _lib.load(), ops.stream_ptr()
+    K = 768
+    a = synth.tensor("rs.a", (M, K), 1.0, 3).to(dev)
+    w = synth.tensor("rs.w", (N, K), 0.05, 3).to(dev)
+    b = synth.tensor("rs.b", (N,), 0.3, 3).to(dev)
+    _lib.check(lib.hirest_gemm_f32_select_kernel(1), "select")
+    try:
+        ref = MomentModel._gemm(a, w, b)
+        ref0 = MomentModel._gemm(a, w, None)
+    finally:
+        lib.hirest_gemm_f32_select_kernel(0)
+    nt = (N + 15) // 16
+    out = torch.full((M, N), 3.0, device=dev); cm = torch.full((M, nt), 7.0, device=dev)
+    _lib.check(lib.hirest_gemm_f32_rows_colmax(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), out.data_ptr(), N, cm.data_ptr(), M, N, K, st), "rows")
+    assert torch.equal(out, ref)
+    pad = torch.full((M, nt * 16), float("-inf"), device=dev); pad[:, :N] = ref
+    assert torch.equal(cm, pad.reshape(M, nt, 16).max(-1).values)
+    out.fill_(3.0)
+    _lib.check(lib.hirest_gemm_f32_rows_colmax(a.data_ptr(), K, w.data_ptr(), K, None, out.data_ptr(), N, None, M, N, K, st), "rows, no bias")
+    assert torch.equal(out, ref0)
+    assert torch.equal(MomentModel._gemm(a, w, b), ref)               # automatic dispatch
+    assert lib.hirest_gemm_f32_rows_colmax(a.data_ptr(), K, w.data_ptr(), K, None, out.data_ptr(), N, None, M, N, 512, st) == -2
 
 
 def test_round3_fp32_kernels_randomised_bit_equality(dev):
@@ -313,7 +349,10 @@ def test_attention_f32_decode_equals_gather_then_attention(dev, t_hist, newkey, 
 
 
 @pytest.mark.parametrize("M,N,K,act,embed", [(25, 30528, 768, 0, False), (15, 30528, 768, 0, False), (32, 8200, 768, 1, False), (25, 2304, 768, 0, True), (25, 768, 768, 0, False), (15, 3072, 768, 1, False), (7, 100, 256, 2, False),
-                                             (32, 768, 1024, 3, True), (1, 36, 512, 0, False)])
+                                             (32, 768, 1024, 3, True), (1, 36, 512, 0, False),
+                                             # merged beam searches: 60 - 160 rows per word, 16-row blocks across blockIdx.y
+                                             (160, 2304, 768, 0, True), (96, 3072, 768, 1, False), (100, 768, 768, 0, False), (256, 768, 768, 1, False),
+                                             (33, 36, 256, 2, False)])
 def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
     """hirest_gemm_f32_ln (LayerNorm / token + position embedding as the GEMM's prologue) against hirest_embedding_pos_fwd_f32 +
     hirest_layernorm + hirest_gemm_f32: output and the normalised rows bit for bit"""
@@ -347,7 +386,7 @@ def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
     assert not want_ln or torch.equal(ln2, ln)
     assert torch.equal(out, ref)
     assert lib.hirest_gemm_f32_ln(x.data_ptr(), K, None, None, None, g.data_ptr(), be.data_ptr(), 1e-12, None, 0, w.data_ptr(), K, None, None, 0,
-                                  out.data_ptr(), N, 33, N, K, act, st) == -2          # more than 32 rows: HIREST_E_SHAPE
+                                  out.data_ptr(), N, 257, N, K, act, st) == -2         # more than 256 rows: HIREST_E_SHAPE
 
 
 @pytest.mark.parametrize("B,beam,step", [(5, 5, 3), (5, 3, 0), (2, 7, 1), (3, 1, 2)])
@@ -481,8 +520,15 @@ def test_caption_batches_with_three_in_flight_equal_sequential_calls(dev, golden
     batches.append(small)
     want.append(model.test_step(small, num_beams=beams, return_ids=True))
     for streams, graphs in ((3, True), (2, True), (8, False), (3, False)):      # word steps replayed from hipGraphs / issued eagerly
-        got = model.caption_batches(batches, num_beams=beams, streams=streams, return_ids=True, graphs=graphs)
+        got = model.caption_batches(batches, num_beams=beams, streams=streams, return_ids=True, graphs=graphs, merge=False)
         assert [g["token_ids"] for g in got] == [w["token_ids"] for w in want], (streams, graphs)
+        assert [g["prediction"] for g in got] == [w["prediction"] for w in want]
+    # round 5, the default: ONE beam search over the union of consecutive batches' beam rows (up to rows_in_flight; the decoder's
+    # weights are streamed once per word for all of them), each loader batch handed its own slice: 160 rows = 6 + 2 batches,
+    # 50 rows = pairs, 25 rows = nothing to merge, 1000 = all 38 videos (190 rows) in one search
+    for rows, streams, graphs in ((None, 2, True), (50, 3, True), (50, 1, False), (25, 2, True), (1000, 1, True)):
+        got = model.caption_batches(batches, num_beams=beams, streams=streams, return_ids=True, graphs=graphs, rows_in_flight=rows)
+        assert [g["token_ids"] for g in got] == [w["token_ids"] for w in want], (rows, streams, graphs)
         assert [g["prediction"] for g in got] == [w["prediction"] for w in want]
     assert model.caption_batches(batches[:1], num_beams=beams, streams=3, return_ids=True)[0]["token_ids"] == want[0]["token_ids"]
     assert model.caption_batches([], num_beams=beams) == []

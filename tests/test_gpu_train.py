@@ -276,8 +276,9 @@ def test_grouped_column_sums_equal_the_single_calls():
         assert torch.equal(w, o), i
 
 
-def test_weight_gradients_on_the_side_stream_equal_the_single_stream_backward(dev, golden_dir):
-    """The dW GEMMs of a backward run on a second stream behind "dY is ready" events (train.SIDE_STREAM_DW): same kernels on the same
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_backward(dev, golden_dir, gemm_precision):
+    """(With the split-operand products too: their per-backward memo of split dY forms must hold the source tensor, or a recycled
+    address returns a stale split in the single-stream backward — ADVICE r4.)  The dW GEMMs of a backward run on a second stream behind "dY is ready" events (train.SIDE_STREAM_DW): same kernels on the same
     operands, so every gradient must equal the single-stream backward bit for bit — in train mode (same seed, same dropout masks),
     for all three tasks, repeatedly (a missing dependency would show as a race)."""
     from hirest_amd import train

@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
 model.load_state_dict(sd, strict=False)
 model = model.to(dev).eval()
-B, T = 5, 300
+B, T = int(os.environ.get("CAPTION_B", "5")), 300            # CAPTION_B=32: the reference's default evaluation batch (args.py:27)
 vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"jb.{T}", B, T, 43)
 mm15 = torch.zeros_like(moment_mask); mm15[:, 10:25] = 1
 batch = {"tasks": ["step_captioning"], "vis_feats": vis.to(dev), "vis_mask": vis_mask.to(dev), "moment_mask": mm15,
