@@ -362,9 +362,10 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
         // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU); for the
         // one-call beam step it also leaves the maxima of its 16-column tiles for the tail
         if (R > 32 && d->vocab_padded >= 8192) {
-            // more rows than the streaming LM head holds (a merged search: 60 - 160 beam rows): LayerNorm, then the plain product
+            // a merged search (60 - 160 beam rows): by now a compute problem — LayerNorm once, then the row-group streaming product
+            // with five row tiles per wave (its LayerNorm-prologue form holds three), which also leaves the tile maxima for the tail
             CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
-            if (tile_max_out && D == 768) {                  // the row-group streaming LM head, which also leaves the tile maxima for the tail
+            if (tile_max_out && D == 768) {
                 float* tm = reinterpret_cast<float*>(base + w.tm);
                 CK(hirest_gemm_f32_rows_colmax(b, D, d->lm_w, D, d->lm_b, logits, d->vocab_padded, tm, R, d->vocab_padded, D, stream));
                 *tile_max_out = tm;

@@ -834,17 +834,28 @@ int launch_m16ln_stream(const GemmLN& q, hipStream_t s, int lds_max) {
 // with the tile number, so no wave is the one the others wait for.  Fragments of slab s + 1 are read while slab s multiplies.
 // The NG blocks that stream the same tiles sit on the same XCD (blockIdx % 8) next to each other and run in step, so W is pulled
 // from memory once and served to the other row groups by that XCD's L2.
-template <int NS, int MT, int DEPTH>
-__global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmF p, float* __restrict__ colmax, int ng, int max_mine) {
+// With LN, the rows are LayerNorm(X) (X optionally table[ids] + pos_row), as in gemm_f32_m16ln_kernel: each wave first takes the
+// statistics of 4 MT of the block's rows with layernorm_rows' own arithmetic (ln_wave_stats; the column-stream-0 blocks also write the
+// normalised rows to ln_out), and the A phase then normalises the raw fragments it reads from the ring element by element with
+// ln_apply's expression — same bits as hirest_layernorm + the plain product.  A block normalises its rows ONCE for all its column
+// tiles, where the 16-row blocks of gemm_f32_m16ln_kernel do it per column tile and run 1450 blocks (three rounds) for a 160 x 2304
+// layer.
+template <int NS, int MT, int DEPTH, bool LN>
+__global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmLN q, int ng, int max_mine) {
     static_assert(NS % 2 == 0, "the fragment double buffer alternates by slab parity");
+    const GemmF& p = q.g;
     constexpr int SLAB = 2048, L = 2, GA = MT * NS;          // the first GA slabs of a wave's stream are its A tiles, then W
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x DEPTH slabs | red[2][4][MT][64] f32x4 | bias of this block's tiles
+    constexpr int K = NS * 4 * FK;
+    // 4 x DEPTH slabs | red[2][4][MT][64] f32x4 | LN: gamma, beta, pos [K] each, (mean, rstd) of the 16 MT rows | bias of this block's tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, kq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15, slot = lane >> 4;
     const bool odd = slot >> 1;
     char* ring = smem + kq * DEPTH * SLAB;
     f32x4 (*red)[4][MT][64] = reinterpret_cast<f32x4 (*)[4][MT][64]>(smem + 4 * DEPTH * SLAB);
-    float* bias_lds = reinterpret_cast<float*>(smem + 4 * DEPTH * SLAB + 2 * 4 * MT * 1024);
+    float* lnp = reinterpret_cast<float*>(smem + 4 * DEPTH * SLAB + 2 * 4 * MT * 1024);
+    float* stats = lnp + 3 * K;
+    float* bias_lds = LN ? stats + 2 * 16 * MT : lnp;
     auto swz = [](int row) { const int pr = (row >> 1) & 7; return pr ^ ((((pr >> 1) ^ (pr >> 2)) & 1) << 2); };
     // block -> (XCD, row group, column stream): the ng row groups of a stream are consecutive slots of one XCD
     const int xcd = (int)blockIdx.x & 7, xslot = (int)blockIdx.x >> 3;
@@ -858,7 +869,7 @@ __global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmF p, floa
     const int first = kq * NS;
     const int items = mine * NS, total = GA + items;         // this wave's stream: A (tile t, slab sl), then W (tile i, slab sl)
     // The bias of this block's tiles -> LDS (tile i at floats 16 i .. + 15), by LDS-DMA from wave 0 BEFORE its ring starts: the
-    // oldest vector-memory operation of the wave, so every later counted wait implies it, and the only vector loads of the kernel
+    // oldest vector-memory operation of the wave, so every later counted wait implies it, and the only vector loads of the loop
     // stay the ring's (a plain load anywhere in the loop makes the compiler wait for vmcnt(0) = empty the ring).
     if (kq == 0 && p.bias) {
         for (int r = 0; r < max_mine; r += 16) {
@@ -875,7 +886,8 @@ __global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmF p, floa
         for (int j = 0; j < L; ++j) {
             const int trow = 8 * j + trow0;
             int gm = M0 + 16 * t + trow; gm = gm < p.M ? gm : p.M - 1;
-            wrow[j] = reinterpret_cast<const char*>(p.A + (int64_t)gm * p.lda) + 16 * (chunk_lane ^ swz(trow)) + (int64_t)first * (FK * 4);
+            const float* row = !LN ? p.A + (int64_t)gm * p.lda : (q.ids ? q.table + (int64_t)q.ids[gm] * K : q.X + (int64_t)gm * q.ldx);
+            wrow[j] = reinterpret_cast<const char*>(row) + 16 * (chunk_lane ^ swz(trow)) + (int64_t)first * (FK * 4);
         }
     };
     auto w_rows = [&](int i) {
@@ -902,6 +914,55 @@ __global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmF p, floa
 #pragma unroll 1
     for (int u = 0; u < DEPTH; ++u)
         if (issued < total) dma();
+    if (LN) {
+        // gamma | beta | pos_row -> LDS in natural order (the A phase reads the lane's k positions from there)
+        constexpr int NV = K / 256;
+        if (tid < K / 4) {
+            reinterpret_cast<f32x4*>(lnp)[tid] = *reinterpret_cast<const f32x4*>(q.gamma + 4 * tid);
+            reinterpret_cast<f32x4*>(lnp + K)[tid] = *reinterpret_cast<const f32x4*>(q.beta + 4 * tid);
+            reinterpret_cast<f32x4*>(lnp + 2 * K)[tid] = q.ids ? *reinterpret_cast<const f32x4*>(q.pos_row + 4 * tid) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // statistics of rows M0 + 4 (4 j + kq) + rr, j < MT, by this wave (lane owns float4 number lane + 64 i of a row), four rows at
+        // a time; all loads unconditional (rows past M re-read row M - 1) and issued before the first reduction
+        const bool writes = q.ln_out && cs == 0 && xcd == 0;
+        f32x4 gam[NV], bet[NV], pe[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            gam[i] = *reinterpret_cast<const f32x4*>(q.gamma + 4 * (lane + 64 * i));
+            bet[i] = *reinterpret_cast<const f32x4*>(q.beta + 4 * (lane + 64 * i));
+            pe[i] = q.ids ? *reinterpret_cast<const f32x4*>(q.pos_row + 4 * (lane + 64 * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int j = 0; j < MT; ++j) {
+            f32x4 v[4][NV];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int m = M0 + 4 * (4 * j + kq) + rr; m = m < p.M ? m : p.M - 1;
+                const float* row = q.ids ? q.table + (int64_t)q.ids[m] * K : q.X + (int64_t)m * q.ldx;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(row + 4 * (lane + 64 * i));
+            }
+            if (q.ids) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) v[rr][i] += pe[i];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int rl = 4 * (4 * j + kq) + rr;
+                float mean, rstd;
+                ln_wave_stats<NV>(v[rr], K >> 2, K, q.eps, lane, mean, rstd);
+                if (lane == 0) { stats[2 * rl] = mean; stats[2 * rl + 1] = rstd; }
+                if (writes && M0 + rl < p.M) {               // (wave-uniform)
+#pragma unroll
+                    for (int i = 0; i < NV; ++i)
+                        *reinterpret_cast<f32x4*>(q.ln_out + (int64_t)(M0 + rl) * q.ldl + 4 * (lane + 64 * i)) = ln_apply(v[rr][i], mean, rstd, gam[i], bet[i]);
+                }
+            }
+        }
+        __syncthreads();                                     // statistics and parameters complete (the only full barrier: it also lands the ring's first slabs)
+    }
     // fragment of instruction 2 c + e: element 2 e + odd of chunk 4 (slot & 1) + c -> two dwords 8 B apart (one ds_read2_b32)
     int fo[4];
 #pragma unroll
@@ -923,16 +984,30 @@ __global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmF p, floa
     // this wave's A fragments for good: row tile t, slab sl, instruction 2 c + e -> the lane's k slot
     float af[MT][NS][4][2];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < MT; ++t) {
+        float mean = 0.f, rstd = 0.f;
+        if (LN) { mean = stats[2 * (16 * t + idx)]; rstd = stats[2 * (16 * t + idx) + 1]; }
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            constexpr int D_ = DEPTH;
             const int g = t * NS + sl;                       // (compile-time after unrolling)
             landed(g);
-            read_frags(g % D_, af[t][sl]);
+            read_frags(g % DEPTH, af[t][sl]);
+            if (LN) {
+                const int k0 = (first + sl) * FK + 16 * (slot & 1) + (odd ? 1 : 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = k0 + 4 * c + 2 * e;
+                        float v = af[t][sl][c][e];
+                        if (q.ids) v += lnp[2 * K + k];      // (uniform) token + position embedding
+                        af[t][sl][c][e] = __builtin_fmaf((v - mean) * rstd, lnp[k], lnp[K + k]);       // ln_apply's expression
+                    }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's reads have returned before it is refilled
             if (issued < total) dma();
         }
+    }
     float wq[2][4][2];
     landed(GA);
     read_frags(GA % DEPTH, wq[0]);
@@ -963,65 +1038,85 @@ __global__ __launch_bounds__(256) void gemm_f32_rows_stream_kernel(GemmF p, floa
                 if (issued < total) dma();
             }
         }
-        // the four K quarters of tile i meet in red[i & 1]; wave i % 4 adds them in the shared order and stores
+        // The four K quarters of tile i meet in red[i & 1], and EVERY wave reduces its share of the row tiles — t with (t + i) % 4 = kq —
+        // in the shared order and stores them.  (One reducing wave per tile, rotating or not, puts its whole epilogue on the critical
+        // path: the reducer of tile i + 1 waits for the quarter of the wave that was busy storing tile i — profiles/r05/lm_head_rows_forms.txt.)
         const int buf = i & 1;
 #pragma unroll
         for (int t = 0; t < MT; ++t) red[buf][kq][t][lane] = acc[t];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kq == (i & 3)) {
+        {
             const int tile = stream + i * ncs, n = tile * 16 + 4 * slot;
-            Epi4 ep;
-            ep.resid = f32x4{0.f, 0.f, 0.f, 0.f}; ep.periodic = ep.resid;
-            ep.bias = p.bias ? *reinterpret_cast<const f32x4*>(bias_lds + 16 * i + 4 * slot) : ep.resid;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 bias4 = p.bias ? *reinterpret_cast<const f32x4*>(bias_lds + 16 * i + 4 * slot) : zero;
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
+                if (((t + i) & 3) != kq) continue;           // (wave-uniform)
                 const int m = M0 + 16 * t + idx;
                 const bool in = n < p.N && m < p.M;
+                Epi4 ep;                                     // (no residual / periodic operand here: the launcher sends those elsewhere)
+                ep.bias = bias4; ep.periodic = zero; ep.resid = zero;
                 const f32x4 sum = ((red[buf][0][t][lane] + red[buf][1][t][lane]) + red[buf][2][t][lane]) + red[buf][3][t][lane];
                 const f32x4 v = epilogue_apply4(p, sum, ep, m, n, in);
-                if (colmax) {                                // (uniform) the tile's maximum per row: the beam tail's row max without a row scan
+                if (q.colmax) {                              // (uniform) the tile's maximum per row: the beam tail's row max without a row scan
                     float mx = in ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
                     { float pa = mx, pb = mx; lane_swap16(pa, pb); mx = fmaxf(pa, pb); pa = mx; pb = mx; lane_swap32(pa, pb); mx = fmaxf(pa, pb); }
-                    if (slot == 0 && m < p.M) colmax[(int64_t)m * ntile + tile] = mx;
+                    if (slot == 0 && m < p.M) q.colmax[(int64_t)m * ntile + tile] = mx;
                 }
             }
         }
     }
 }
 
-template <int NS, int MT, int DEPTH>
-int launch_rows_stream(const GemmF& p, float* colmax, int ng, hipStream_t s) {
+template <int NS, int MT, int DEPTH, bool LN>
+int launch_rows_stream(const GemmLN& q, int ng, int k, hipStream_t s) {
     static HirestDevCfg cfg;
     int cus = 0;
-    auto kern = gemm_f32_rows_stream_kernel<NS, MT, DEPTH>;
-    constexpr int FIXED = 4 * DEPTH * 2048 + 2 * 4 * MT * 1024;
+    auto kern = gemm_f32_rows_stream_kernel<NS, MT, DEPTH, LN>;
+    constexpr int K = NS * 4 * FK;
+    constexpr int FIXED = 4 * DEPTH * 2048 + 2 * 4 * MT * 1024 + (LN ? 3 * K * 4 + 2 * 16 * MT * 4 : 0);
     static_assert(FIXED + 4096 <= 160 * 1024, "does not fit the LDS");
     if (int e = hirest_configure(kern, 160 * 1024, cfg, &cus)) return e;
-    const int ntile = (p.N + 15) / 16;
-    int per_xcd = cus / 8 < 1 ? 1 : cus / 8;                // one block per CU; blockIdx % 8 = XCD
-    int k = per_xcd / ng; if (k < 1) k = 1;                 // column streams per XCD
-    const int ncs = 8 * k;
+    if (q.g.resid || q.g.periodic) return HIREST_E_SHAPE;
+    const int ntile = (q.g.N + 15) / 16, ncs = 8 * k;
     const int max_mine = (ntile + ncs - 1) / ncs;
     const int lds = FIXED + max_mine * 64;
     if (lds > 160 * 1024) return HIREST_E_SHAPE;
-    hipLaunchKernelGGL(kern, dim3(8 * ng * k), dim3(256), lds, s, p, colmax, ng, max_mine);
+    hipLaunchKernelGGL(kern, dim3(8 * ng * k), dim3(256), lds, s, q, ng, max_mine);
     return hirest_launch_status();
 }
 
-// M rows as ng groups of mt 16-row tiles (mt <= 5: MT x 48 fragment registers per wave), least padding first, then fewer groups
-static int rows_stream(const GemmF& p, float* colmax, hipStream_t s) {
-    const int tiles = (p.M + 15) / 16;
-    int mt = 5, ng = (tiles + 4) / 5;
-    for (int m = 4; m >= 2; --m) {
-        const int g = (tiles + m - 1) / m;
-        if (g * m < ng * mt || (g * m == ng * mt && g < ng)) { mt = m; ng = g; }
+// M rows as ng groups of mt 16-row tiles (mt <= 5: MT x 48 fragment registers per wave) x 8 k column streams, one block per CU: the
+// split with the shortest block — tiles per stream x (MFMA time of a tile + its reduction) + the prologue (statistics, A phase)
+template <bool LN>
+static int rows_stream(const GemmLN& q, hipStream_t s) {
+    static HirestDevCfg cfg;
+    int cus = 0;
+    if (int e = hirest_configure(gemm_f32_rows_stream_kernel<6, 1, 12, LN>, 160 * 1024, cfg, &cus)) return e;
+    const int per_xcd = cus / 8 < 1 ? 1 : cus / 8;          // blockIdx % 8 = XCD
+    const int tiles = (q.g.M + 15) / 16, ntile = (q.g.N + 15) / 16;
+    int best_mt = 0, best_ng = 0, best_k = 0;
+    int64_t best = 0;
+    for (int mt = 1; mt <= (LN ? 3 : 5); ++mt) {             // (the LayerNorm form of 4 / 5 row tiles does not fit the registers)
+        const int ng = (tiles + mt - 1) / mt;
+        int k = per_xcd / ng; if (k < 1) k = 1;
+        if (8 * k > ntile) k = (ntile + 7) / 8;
+        const int per_stream = (ntile + 8 * k - 1) / (8 * k);
+        const int64_t cost = (int64_t)per_stream * (mt * 6 * 8 * 42 + 800) + (int64_t)mt * (LN ? 2500 : 1500);
+        if (best_mt == 0 || cost < best) { best = cost; best_mt = mt; best_ng = ng; best_k = k; }
     }
-    switch (mt) {
-        case 2: return launch_rows_stream<6, 2, 14>(p, colmax, ng, s);
-        case 3: return launch_rows_stream<6, 3, 14>(p, colmax, ng, s);
-        case 4: return launch_rows_stream<6, 4, 14>(p, colmax, ng, s);
-        default: return launch_rows_stream<6, 5, 14>(p, colmax, ng, s);
+    switch (best_mt) {
+        case 1: return launch_rows_stream<6, 1, 12, LN>(q, best_ng, best_k, s);
+        case 2: return launch_rows_stream<6, 2, 12, LN>(q, best_ng, best_k, s);
+        case 3: return launch_rows_stream<6, 3, 12, LN>(q, best_ng, best_k, s);
+        case 4: return launch_rows_stream<6, 4, 12, false>(q, best_ng, best_k, s);
+        default: return launch_rows_stream<6, 5, 12, false>(q, best_ng, best_k, s);
     }
+}
+static int rows_stream_plain(const GemmF& p, float* colmax, hipStream_t s) {
+    if (p.resid || p.periodic) return HIREST_E_SHAPE;
+    GemmLN q{p, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, colmax};
+    return rows_stream<false>(q, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1531,11 +1626,12 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     GemmF p{A, lda, W, ldw, bias, resid, ldr, periodic, period, out, ldo, M, N, K, act, nullptr};
     // 33 .. 256 rows (the sentence encoder's batches, the captioning task's training rows): the same kernel, 32-row tiles across
     // blockIdx.y — whole-line operand traffic beats the split-K kernel's lane = row loads (ASR encoder 108 -> 117 k sentences/s)
+    // (a 3072-deep product is a chain of 192 dependent MFMAs per K quarter: one row tile per wave, i.e. twice the blocks, halves it)
     if (M > 32 && M <= 256 && K % FK == 0 && g_f32_kernel == 0 && N < 8192)
-        return launch_m16<2, 1, 6>(p, reinterpret_cast<hipStream_t>(stream));
+        return K >= 2048 ? launch_m16<1, 1, 4>(p, reinterpret_cast<hipStream_t>(stream)) : launch_m16<2, 1, 6>(p, reinterpret_cast<hipStream_t>(stream));
     // a merged beam search's LM head (60 - 160 rows x 30 522 columns): A fragments in registers, W streamed once per row group
     if (M > 32 && M <= 256 && N >= 8192 && K == 768 && !resid && !periodic && g_f32_kernel == 0)
-        return rows_stream(p, nullptr, reinterpret_cast<hipStream_t>(stream));
+        return rows_stream_plain(p, nullptr, reinterpret_cast<hipStream_t>(stream));
     // other wide problems of 48 - 256 rows: the 64x64 kernel beats the split-K kernel's lane = row loads from 60 rows on (LM head: 63 vs 97 us at
     // 96 rows, 93 vs 150 at 160)
     if (M >= 48 && M <= 256 && N >= 8192 && g_f32_kernel == 0) {
@@ -1593,7 +1689,13 @@ extern "C" int hirest_gemm_f32_ln(const float* X, int64_t ldx, const int32_t* id
     if ((!X && !(ids && table && pos_row)) || !gamma || !beta || !W || !out || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return HIREST_E_BADARG;
     // the 16-row blocks of the layer form tile any number of rows across blockIdx.y (a merged beam search: 60 - 160 rows per word);
     // the LM-head stream keeps all its rows in one block's registers: 32 at most
-    if (M > 256 || K % 256 != 0 || K > 1024 || N % 4 != 0 || ldw % 4 != 0 || (X && ldx % 4 != 0) || (ln_out && ldl % 4 != 0)) return HIREST_E_SHAPE;
+    if ((M > 256 && !(K == 768 && !resid)) || K % 256 != 0 || K > 1024 || N % 4 != 0 || ldw % 4 != 0 || (X && ldx % 4 != 0) || (ln_out && ldl % 4 != 0)) return HIREST_E_SHAPE;
+    // (narrow layers stay with the 16-row blocks below: 10 vs 12 us at 160 x 768; above 256 rows this is the only form)
+    if (M > 32 && K == 768 && !resid && (N >= 2048 || M > 256)) {   // a merged search's rows: row groups x column streams, rows normalised once per block
+        GemmLN qs{GemmF{nullptr, 0, W, ldw, bias, nullptr, 0, nullptr, 0, out, ldo, M, N, K, act, nullptr}, X, ldx, ids, table, pos_row, gamma, beta, eps,
+                  ln_out, ldl, g_ln_colmax};
+        return rows_stream<true>(qs, reinterpret_cast<hipStream_t>(stream));
+    }
     if (M > 32 && N >= 8192) return HIREST_E_SHAPE;
     GemmLN q{GemmF{nullptr, 0, W, ldw, bias, resid, ldr, nullptr, 0, out, ldo, M, N, K, act, nullptr}, X, ldx, ids, table, pos_row, gamma, beta, eps,
              ln_out, ldl, g_ln_colmax};
@@ -1641,7 +1743,7 @@ extern "C" int hirest_gemm_f32_rows_colmax(const float* A, int64_t lda, const fl
     if (!A || !W || !out || M <= 0 || N <= 0) return HIREST_E_BADARG;
     if (K != 768 || M > 1280 || N % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || ldo % 4 != 0) return HIREST_E_SHAPE;
     GemmF p{A, lda, W, ldw, bias, nullptr, 0, nullptr, 0, out, ldo, M, N, K, 0, nullptr};
-    return rows_stream(p, colmax, reinterpret_cast<hipStream_t>(stream));
+    return rows_stream_plain(p, colmax, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int hirest_gemm_f32_layouts(const float* A, int64_t lda, int32_t a_kmajor, const float* W, int64_t ldw, int32_t w_kmajor,

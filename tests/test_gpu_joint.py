@@ -272,7 +272,7 @@ def test_lm_head_tile_maxima(dev, M):
 
 
 @pytest.mark.parametrize("M,N", [(160, 30528), (96, 30528), (100, 30528), (60, 30528), (33, 30528), (256, 30528), (17, 8200), (130, 8200),
-                                 (75, 1000), (330, 30528), (160, 16)])
+                                 (75, 1000), (330, 30528), (160, 16), (64, 8216)])
 def test_lm_head_row_groups_equal_the_64x64_kernel(dev, M, N):
     """hirest_gemm_f32_rows_colmax (a merged beam search's LM head: row groups of 32 - 80 rows, A fragments in registers, W streamed
     through LDS-DMA rings, rotating reducer wave) against the 64x64 kernel: same summation order -> bit for bit, every row-tile /
@@ -352,7 +352,8 @@ def test_attention_f32_decode_equals_gather_then_attention(dev, t_hist, newkey, 
                                              (32, 768, 1024, 3, True), (1, 36, 512, 0, False),
                                              # merged beam searches: 60 - 160 rows per word, 16-row blocks across blockIdx.y
                                              (160, 2304, 768, 0, True), (96, 3072, 768, 1, False), (100, 768, 768, 0, False), (256, 768, 768, 1, False),
-                                             (33, 36, 256, 2, False)])
+                                             (33, 36, 256, 2, False), (160, 30528, 768, 0, False), (96, 8200, 768, 1, False), (300, 768, 768, 1, True),
+                                             (40, 64, 768, 0, False), (129, 3072, 768, 1, False)])
 def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
     """hirest_gemm_f32_ln (LayerNorm / token + position embedding as the GEMM's prologue) against hirest_embedding_pos_fwd_f32 +
     hirest_layernorm + hirest_gemm_f32: output and the normalised rows bit for bit"""
@@ -375,18 +376,24 @@ def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
         x = synth.tensor("gl.x", (M, K), 2.0, 3).to(dev)
     ln = torch.empty((M, K), device=dev)
     _lib.check(lib.hirest_layernorm(x.data_ptr(), K, None, g.data_ptr(), be.data_ptr(), 1e-12, ln.data_ptr(), K, 1, M, K, st), "ln")
-    ref = MomentModel._gemm(ln, w, bias, resid=resid, act=act)
-    out = torch.empty((M, N), device=dev)
-    ln2 = torch.empty((M, K), device=dev)
-    want_ln = N < 8192                                          # the LM-head form (persistent blocks) is taken without ln_out
-    _lib.check(lib.hirest_gemm_f32_ln(None if embed else x.data_ptr(), K, ids.data_ptr() if embed else None,
-                                      table.data_ptr() if embed else None, pos[9].data_ptr() if embed else None, g.data_ptr(), be.data_ptr(),
-                                      1e-12, ln2.data_ptr() if want_ln else None, K, w.data_ptr(), K, bias.data_ptr(), resid.data_ptr(), N,
-                                      out.data_ptr(), N, M, N, K, act, st), "gemm_ln")
-    assert not want_ln or torch.equal(ln2, ln)
-    assert torch.equal(out, ref)
-    assert lib.hirest_gemm_f32_ln(x.data_ptr(), K, None, None, None, g.data_ptr(), be.data_ptr(), 1e-12, None, 0, w.data_ptr(), K, None, None, 0,
-                                  out.data_ptr(), N, 257, N, K, act, st) == -2         # more than 256 rows: HIREST_E_SHAPE
+    want_ln = N < 8192 or M > 32                                # the LM-head form for <= 32 rows (persistent blocks) is taken without ln_out
+    for use_resid in (True, False):
+        # with a residual: the 16-row blocks (up to 256 rows, layer widths); without one, above 32 rows and K = 768: the row-group
+        # streaming kernel (any number of rows, any width)
+        if use_resid and (M > 256 or (M > 32 and N >= 8192)):
+            continue
+        ref = MomentModel._gemm(ln, w, bias, resid=resid if use_resid else None, act=act)
+        out = torch.full((M, N), 5.0, device=dev)
+        ln2 = torch.full((M, K), 5.0, device=dev)
+        _lib.check(lib.hirest_gemm_f32_ln(None if embed else x.data_ptr(), K, ids.data_ptr() if embed else None,
+                                          table.data_ptr() if embed else None, pos[9].data_ptr() if embed else None, g.data_ptr(), be.data_ptr(),
+                                          1e-12, ln2.data_ptr() if want_ln else None, K, w.data_ptr(), K, bias.data_ptr(),
+                                          resid.data_ptr() if use_resid else None, N, out.data_ptr(), N, M, N, K, act, st), "gemm_ln")
+        assert not want_ln or torch.equal(ln2, ln), use_resid
+        assert torch.equal(out, ref), use_resid
+    if K != 768:                                                # (K = 768 takes the row-group streaming kernel for any number of rows above 32)
+        assert lib.hirest_gemm_f32_ln(x.data_ptr(), K, None, None, None, g.data_ptr(), be.data_ptr(), 1e-12, None, 0, w.data_ptr(), K, None, None, 0,
+                                      out.data_ptr(), N, 257, N, K, act, st) == -2     # more than 256 rows: HIREST_E_SHAPE
 
 
 @pytest.mark.parametrize("B,beam,step", [(5, 5, 3), (5, 3, 0), (2, 7, 1), (3, 1, 2)])
