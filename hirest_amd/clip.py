@@ -60,6 +60,10 @@ class OpenAIVisionTower(_Tower):
             b.mlp.c_fc, b.mlp.c_proj = _linear(4 * D, D), _linear(D, 4 * D)
             blocks.append(b)
         self.transformer.resblocks = nn.ModuleList(blocks)
+        # 'bf16' (default: the MFMA towers) | 'fp32' (exact-fp32 kernels of csrc/tower_f32.hip with its QuickGELU epilogue, ln_pre and
+        # all-token head: the reference's own arithmetic, so cosines land within 1e-5 of it and its top-k ids are reproduced);
+        # CLIP.set_precision / clip.load(..., precision=) / HIREST_PRECISION select it
+        self.precision = "bf16"
         self.pip_head = False          # True: return the CLS embedding like the pip `clip` package (clip.load(..., pip_head=True))
         self.ln_post = _norm(D)
         self.proj = nn.Parameter(torch.zeros(D, output_dim))
@@ -102,19 +106,65 @@ class OpenAIVisionTower(_Tower):
         self._prepared = {"device": device, "desc": desc, "blocks": blocks, "keep": keep}
         return self._prepared
 
+    def _prepare_f32(self, device):
+        """The fp32 master parameters as they are (contiguous fp32 views; the zero-padded conv weight and proj^T are copies)."""
+        if self._prepared is not None and self._prepared["device"] == device and self._prepared.get("f32"):
+            return self._prepared
+        if device.type != "cuda":
+            raise RuntimeError("hirest_amd: the CLIP vision tower runs on MI355X only (no CPU fallback)")
+        D, P = self.width, self.patch_size
+        K = 3 * P * P
+        kpad = (K + 63) // 64 * 64
+        keep = []
+
+        def hold(t):
+            t = t.detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        pw = torch.zeros((D, kpad), dtype=torch.float32, device=device)
+        pw[:, :K] = self.conv1.weight.detach().float().reshape(D, K)
+        blocks = (_lib.BlockWeightsF32 * self.layers)()
+        for i, b in enumerate(self.transformer.resblocks):
+            blocks[i] = _lib.BlockWeightsF32(
+                hold(b.ln_1.weight), hold(b.ln_1.bias), hold(b.attn.in_proj_weight), hold(b.attn.in_proj_bias),
+                hold(b.attn.out_proj.weight), hold(b.attn.out_proj.bias), hold(b.ln_2.weight), hold(b.ln_2.bias),
+                hold(b.mlp.c_fc.weight), hold(b.mlp.c_fc.bias), hold(b.mlp.c_proj.weight), hold(b.mlp.c_proj.bias))
+        mean = torch.tensor((0.48145466, 0.4578275, 0.40821073), dtype=torch.float32, device=device)
+        std = torch.tensor((0.26862954, 0.26130258, 0.27577711), dtype=torch.float32, device=device)
+        desc = _lib.VisionTowerF32(
+            self.input_resolution, P, D, self.heads, D // self.heads, 4 * D, self.layers, self.output_dim, kpad,
+            1, 1e-5,                                                  # QuickGELU (model.py:175), nn.LayerNorm default eps
+            hold(pw), None,                                           # conv1 has no bias (model.py:220)
+            hold(self.class_embedding), hold(self.positional_embedding), blocks, hold(self.ln_post.weight), hold(self.ln_post.bias),
+            hold(self.proj.detach().float().t()), None, hold(mean), hold(std),
+            hold(self.ln_pre.weight), hold(self.ln_pre.bias), 1)       # ln_pre; ln_post + proj on every token (model.py:229-273)
+        self._prepared = {"device": device, "desc": desc, "blocks": blocks, "keep": keep, "f32": True}
+        return self._prepared
+
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
             x = x.float()
-        prep = self._prepare(x.device)
+        f32 = self.precision != "bf16"
+        if self._prepared is not None and bool(self._prepared.get("f32")) != f32:
+            self._prepared = None                      # the other kernel set's descriptor
+        prep = self._prepare_f32(x.device) if f32 else self._prepare(x.device)
         lib = _lib.load()
         x = x.contiguous()
         B, T, E = x.shape[0], self.num_tokens, self.output_dim
         out = torch.empty((B, T, E), dtype=torch.float32, device=x.device)
         step = max(1, int(self.max_frames_per_call))
-        ws = self._ws(lib.hirest_vision_workspace_bytes(C.byref(prep["desc"]), min(B, step)), x.device)
+        if B == 0:
+            return out[:, 0, :] if self.pip_head else out[:, 1:, :]
+        wsb = lib.hirest_vision_workspace_bytes_f32 if f32 else lib.hirest_vision_workspace_bytes
+        ws = self._ws(wsb(C.byref(prep["desc"]), min(B, step)), x.device)
         for s in range(0, B, step):
             n = min(step, B - s)
+            if f32:
+                _lib.check(lib.hirest_vision_forward_f32(C.byref(prep["desc"]), x[s:s + n].data_ptr(), ops._IN_DTYPES[x.dtype], n,
+                                                         out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(), ops.stream_ptr()),
+                           "hirest_vision_forward_f32")
+                continue
             _lib.check(lib.hirest_vision_forward(C.byref(prep["desc"]), x[s:s + n].data_ptr(), ops._IN_DTYPES[x.dtype], n,
                                                  out[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(), 0, ops.stream_ptr()),
                        "hirest_vision_forward")
@@ -157,6 +207,17 @@ class CLIP(nn.Module):
     def _load_from_state_dict(self, *a, **k):
         self._text.invalidate()
         return super()._load_from_state_dict(*a, **k)
+
+    def set_precision(self, precision: str):
+        """'bf16' = the bf16 MFMA towers (default); 'fp32' = both towers in exact fp32 (the reference's own arithmetic: model.py runs in
+        fp32 on CPU, clip.py:136-138): cosines within 1e-5 of the reference, its top-k ids reproduced; 'bf16x3' is accepted and runs the
+        fp32 kernels (ViT-B/32 is 4.4 GFLOP per frame: the exact path is cheap, no split-operand variant is built for it)."""
+        if precision not in ("bf16", "fp32", "bf16x3"):
+            raise ValueError(f"precision must be one of ('bf16', 'fp32', 'bf16x3'), got {precision!r}")
+        p = "bf16" if precision == "bf16" else "fp32"
+        self.visual.precision = p
+        self._text.precision = p
+        return self
 
     @property
     def dtype(self):
@@ -201,7 +262,8 @@ def build_model(state_dict: Dict[str, torch.Tensor]) -> CLIP:
     return model.eval()
 
 
-def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False, download_root: str = None, pip_head: bool = False):
+def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False, download_root: str = None, pip_head: bool = False,
+         precision: str = "bf16"):
     """clip.py:94-193 for local checkpoints: a JIT archive or a plain state dict -> (model, preprocess).
 
     ``pip_head=True`` gives the model of the *pip* ``clip`` package (openai/CLIP @ a9b1bf5, requirements.txt:25) that the reference's
@@ -216,5 +278,8 @@ def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False
     except RuntimeError:
         state_dict = torch.load(name, map_location="cpu")
     model = build_model(state_dict).to(device)
+    # precision: this argument, unless HIREST_PRECISION (the opt-in for unmodified reference callers, as in eva_clip.create_model) is set
+    env = os.environ.get("HIREST_PRECISION", "").strip().lower()
+    model.set_precision(env or precision)
     model.visual.pip_head = bool(pip_head)
     return model, image_transform(model.visual.input_resolution)

@@ -458,3 +458,18 @@ def test_openai_clip_b32_config1_vs_reference(dev, golden_dir):
     assert torch.equal(got[safe], torch.from_numpy(g["top5"])[safe])
     print(f"top-5 ids exact on {int(safe.sum())}/{len(safe)} queries with safe margins; "
           f"overall set agreement {np.mean([len(set(a.tolist()) & set(b.tolist())) / 5 for a, b in zip(got, torch.from_numpy(g['top5']))]):.3f}")
+    # precision='fp32' (the reference's own arithmetic on the exact-fp32 kernels): SURVEY 8d C1's bar — ALL 16 top-5 lists equal the
+    # reference's, cosines within 1e-5
+    model.set_precision("fp32")
+    fe32 = model.encode_image(img).mean(dim=1)
+    te32 = model.encode_text(torch.from_numpy(g["tokens"]).to(dev))
+    cos32 = o.similarity(o.pool_l2norm(te32.unsqueeze(1).contiguous()), o.pool_l2norm(fe32.unsqueeze(1).contiguous())).cpu()
+    err32 = (cos32 - ref).abs().max().item()
+    print(f"config 1 at precision fp32: max |cosine diff| {err32:.2e}")
+    assert err32 <= 1e-5
+    assert torch.equal(cos32.topk(5, dim=1).indices, torch.from_numpy(g["top5"]))
+    assert (fe32.cpu() - torch.from_numpy(g["frame_embed"])).abs().max().item() <= 5e-5 * torch.from_numpy(g["frame_embed"]).abs().max().item()
+    model.set_precision("bf16")
+    assert torch.equal(model.encode_image(img).mean(dim=1), fe)                 # switching back rebuilds the bf16 descriptor: same bits
+    with pytest.raises(ValueError):
+        model.set_precision("int8")

@@ -264,7 +264,8 @@ def test_gpu_c3_eight_rank_blocks_equal_the_single_sweep():
 
 
 @pytest.mark.gpu
-def test_gpu_two_rank_driver_on_one_gpu_equals_one_rank(tmp_path):
+@pytest.mark.parametrize("model", ["tiny", "g14"])      # g14: the production kernels (pq256 GEMMs, v3 attention, LN fold) on both ranks, 64 videos
+def test_gpu_two_rank_driver_on_one_gpu_equals_one_rank(tmp_path, model):
     """tools/c3_run.py as TWO PROCESSES (launcher, shard_range blocks, RowGather, replicated text tower + ranking, cross-rank agreement
     check) against the same script as one process: identical SHA-256 of the gathered [V, E] rows and of the top-10 table.  The two ranks
     share the one GPU of a test box and gather through gloo (RCCL refuses two ranks on one device) — the transport is the only part of
@@ -274,14 +275,14 @@ def test_gpu_two_rank_driver_on_one_gpu_equals_one_rank(tmp_path):
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(HERE), "tools", "c3_run.py")
-    common = [sys.executable, tool, "--model", "tiny", "--videos", "64", "--frames", "4", "--block", "16"]   # 64-frame tower calls on every rank
+    common = [sys.executable, tool, "--model", model, "--videos", "64", "--frames", "4", "--block", "16"]   # 64-frame tower calls on every rank
     reports = {}
     for n in (1, 2):
         out = str(tmp_path / f"c3_{n}.json")
         extra = ["--gpus", "2", "--backend", "gloo", "--share-gpu"] if n == 2 else []
         env = dict(os.environ)
         env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-        r = subprocess.run(common + extra + ["--out", out], capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run(common + extra + ["--out", out], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         reports[n] = json.load(open(out))
     one, two = reports[1], reports[2]

@@ -151,23 +151,56 @@ def measure(dev=None, cpu=True, log=lambda m: None):
             ent["cpu_baseline"] = {"value": 1 / tc, "unit": "captions/s", "cores": threads, "kind": "port", "sample": "one caption (video 0)"}
             ent["token_ids_equal_cpu_oracle_on_sample"] = bool(list(c_cpu[0]) == list(r["token_ids"][0]))
         out[f"step_captioning_beam{beams}"] = ent
-        # the same batch as an evaluation loop sees it: several loader batches in flight (MomentModel.caption_batches, one HIP stream +
-        # host thread each).  One batch alone is latency-bound (25 rows, ~20 dependent kernels per word); independent batches fill
-        # the idle CUs and only the HBM-bound LM head serialises.  Same token ids per batch (tests/test_gpu_joint.py).
-        nb, ns = 12, 4
+        # the same batch as an evaluation loop sees it (run.py:328-336: one test_step per loader batch): MomentModel.caption_batches
+        # captions consecutive loader batches with ONE beam search over the union of their beam rows (up to 160 rows: 12 batches of 5
+        # videos = two searches of 30 videos, both in flight on their own streams), so a word's decoder + LM-head weights are
+        # streamed once per SEARCH, not once per batch.  Same token ids per batch (tests/test_gpu_joint.py).
+        nb, ns = 12, 2
         many = [bcp] * nb
-        model.caption_batches(many[:ns], num_beams=beams, streams=ns)                      # warm-up: streams, allocator pools
+        model.caption_batches(many, num_beams=beams, streams=ns)                           # warm-up: streams, allocator pools, graphs
         sync(); t0 = time.perf_counter()
         res = model.caption_batches(many, num_beams=beams, streams=ns, return_ids=True)
         sync(); dtp = (time.perf_counter() - t0) / nb
-        gbs = bytes_per_word * 48 / dtp / 1e9
+        per_search = max(1, model.CAPTION_ROWS_IN_FLIGHT // beams // B)                     # loader batches per merged search
+        searches = -(-nb // per_search)
+        gbs = bytes_per_word * 48 * searches / (dtp * nb) / 1e9
+        rows = per_search * B * beams
+        tfl = 2.0 * (bytes_per_word / 4) * rows * 48 * searches / (dtp * nb) / 1e12
         out[f"step_captioning_beam{beams}_pipelined"] = {
             "value": B / dtp, "unit": "captions/s", "ms_per_batch": dtp * 1e3, "beam": beams, "max_words": 48, "batches": nb,
-            "batches_in_flight": ns, "how": "MomentModel.caption_batches: loader batches of 5 videos captioned concurrently on 4 HIP streams (word steps replayed from hipGraphs)",
+            "merged_searches": searches, "beam_rows_per_search": rows, "searches_in_flight": ns,
+            "how": "MomentModel.caption_batches (default merge=True): loader batches of 5 videos captioned by one beam search per 160 beam rows; "
+                   "the searches replay their word steps from hipGraphs on their own streams",
             "token_ids_equal_real_reference": f"{sum(int(list(a) == b) for r_ in res for a, b in zip(r_['token_ids'], want))} of {nb * len(want)} captions",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_word_step": bytes_per_word,
-                         "note": "each batch in flight streams the decoder + LM-head weights once per word"}}
+                         "note": "the decoder + LM-head weights ONCE per word per merged search (not per loader batch); at 90 - 150 rows the word "
+                                 "is matrix-pipe time, not weight-stream time: see mfma_f32",
+                         "mfma_f32": {"achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MFMA_PEAK_TFLOPS,
+                                      "note": "2 x weights x beam rows per word (attention and the tail not counted), exact-fp32 MFMA"}}}
+        # the reference's DEFAULT evaluation batch (args.py:27 --eval_batch_size 32): one test_step on the inputs of the real-reference
+        # goldens d3 / d5 (make_golden.py: the REAL MomentModel.test_step at B = 32), all 32 captions compared
+        case = f"d{beams}"
+        dB, dT, _, dlens = CAPTION_CASES[case]
+        dvis, dasr, dtext, dvm, _, _ = joint_inputs(f"cap.{case}", dB, dT, 47)
+        dmm = torch.zeros(dB, dT, dtype=torch.long)
+        for b in range(dB):
+            dmm[b, 5 + b:5 + b + dlens[b]] = 1
+        bd = {"tasks": ["step_captioning"], "vis_feats": g(dvis), "vis_mask": g(dvm), "asr_feats": g(dasr), "text_feat": g(dtext), "moment_mask": dmm}
+        dtd, rd = _timeit(lambda: model.test_step(bd, num_beams=beams, return_ids=True), 3, sync)
+        wantd = [[int(t) for t in p.split()] for p in gold[case]["prediction"]]
+        gbs = bytes_per_word * 48 / dtd / 1e9
+        tfl = 2.0 * (bytes_per_word / 4) * dB * beams * 48 / dtd / 1e12
+        out[f"step_captioning_beam{beams}_b32"] = {
+            "value": dB / dtd, "unit": "captions/s", "ms_per_batch": dtd * 1e3, "beam": beams, "max_words": 48, "batch": dB,
+            "beam_rows": dB * beams, "how": "MomentModel.test_step at the reference's default --eval_batch_size 32 (args.py:27)",
+            "token_ids_equal_real_reference": f"{sum(int(list(a) == b) for a, b in zip(rd['token_ids'], wantd))} of {len(wantd)} captions",
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_word_step": bytes_per_word,
+                         "note": "one weight stream per word for all 96 / 160 beam rows (48 word steps: no sample of the golden batch ends early "
+                                 "enough to stop the search); the word is matrix-pipe time at this size: see mfma_f32",
+                         "mfma_f32": {"achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MFMA_PEAK_TFLOPS,
+                                      "note": "2 x weights x beam rows per word (attention and the tail not counted), exact-fp32 MFMA"}}}
     with torch.no_grad():
         sep_bias.copy_(sep_saved)
 
