@@ -1199,12 +1199,34 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
     const bool panel_major = p.nbn <= 8;
     const int nunit = np * p.nbn;
     if (slot >= nunit) return;
+    // Units of this CU slot.  Default: unit j -> slot j % nslot, i.e. slot, slot + nslot, ...  With few column tiles (fc2 / proj: nbn = 6 of
+    // 32 slots) that makes the set of CUs sharing an A panel change every round (32 / 6 is not an integer) and lets them drift apart in
+    // K, so the panel's slabs are pulled through the XCD's 4-MB L2 again and again (fc2: 17.6 GB fetched per launch for 4.7 algorithmic).
+    // TEAM walk (p.sched bit 2 = hirest_gemm_debug_mode bit 18, A/B): the slots form nslot / nbn fixed teams of nbn CUs — team t takes
+    // panels t, t + teams, ... one column tile per member, so the same nbn CUs start every panel together and stay K-aligned — and the
+    // nslot % nbn slots left over each walk whole panels of the tail of the XCD's range on their own, column after column.
+    const bool team_walk = (p.sched & 4) && panel_major && p.nbn <= nslot && nunit >= nslot;
+    const int teams = team_walk ? nslot / p.nbn : 0, tslots = teams * p.nbn, solo = nslot - tslots;
+    const int np_solo = team_walk && solo ? (np * solo + nslot / 2) / nslot : 0, np_team = np - np_solo;
+    int count;
+    if (!team_walk) count = (nunit - slot + nslot - 1) / nslot;
+    else if (slot < tslots) { const int tm = slot / p.nbn; count = tm < np_team ? (np_team - tm + teams - 1) / teams : 0; }
+    else { const int sl_ = slot - tslots; count = sl_ < np_solo ? ((np_solo - sl_ + solo - 1) / solo) * p.nbn : 0; }
+    if (count <= 0) return;
     if (p.stagger) {   // timing experiment: de-synchronise the CUs so that their HBM-heavy epilogues do not coincide
         const int who = p.stagger == 1 ? (slot & 3) : p.stagger == 2 ? (xcd & 3) : ((slot + xcd) & 7);
         const int units = who * (p.stagger == 3 ? (p.K / Q_BK + 15) / 16 : (p.K / Q_BK + 7) / 8);
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    auto tile_origin = [&](int j, int& M0, int& N0) {        // same walk as p256 (see there)
+    auto team_origin = [&](int i, int& M0, int& N0) {        // i-th unit of this slot under the team walk
+        if (p.rev) i = count - 1 - i;
+        int panel, col;
+        if (slot < tslots) { panel = slot / p.nbn + i * teams; col = slot % p.nbn; }
+        else { panel = np_team + (slot - tslots) + (i / p.nbn) * solo; col = i % p.nbn; }
+        M0 = (p_lo + panel) * T_BM; N0 = col * T_BN;
+    };
+    auto tile_origin = [&](int j, int& M0, int& N0) {        // same walk as p256 (see there); j = slot + i nslot
+        if (team_walk) { team_origin((j - slot) / nslot, M0, N0); return; }
         if (p.rev) j = nunit - 1 - j;
         if (panel_major) {
             const int mt_i = j / p.nbn;
@@ -1277,7 +1299,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
         ++dma_g;
         if (dma_live && ++dma_k == nst) {
             dma_j += nslot;
-            if (dma_j < nunit) { int m0, n0; tile_origin(dma_j, m0, n0); set_sources(m0, n0); dma_k = 0; }
+            if (dma_j < slot + count * nslot) { int m0, n0; tile_origin(dma_j, m0, n0); set_sources(m0, n0); dma_k = 0; }
             else { dma_live = false; dma_k = nst - 1; }        // past the end: refetch of the last step, never consumed
         }
     };
@@ -1347,7 +1369,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
 
     char* stg = smem + 2 * Q_STEP + wave * p_stg_bytes(EPI);
     int g = 0;                                        // global step index of the MFMA side: step g lives in ring slot g & 1
-    for (int j = slot; j < nunit; j += nslot) {
+    for (int j = slot; j < slot + count * nslot; j += nslot) {
         int M0, N0;
         tile_origin(j, M0, N0);
         const bool active = (N0 + wc * 64 < p.N) && (M0 + wr * 128 < p.M);
@@ -1632,7 +1654,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (epi == HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;      // exists in the X3 form only
     const bool fused = (epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32 && epi <= HIREST_EPI_LNFOLD_GELU_BF16) || epi == HIREST_EPI_BIAS_RESID2_LNSTATS;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
-    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x30000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
+    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x70000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
     if (f == 9 || (fused && f != 6 && f != 8) || (!fused && f == 0 && big && !dbg_inst)) snprintf(out, out_len, "gemm_pq256<%d>", epi);
     else if (fused) {
@@ -1661,8 +1683,8 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.pos = a->pos; p.P = a->patches_per_frame;
     p.aux0 = a->aux0; p.aux1 = a->aux1;
     p.rev = ((a->flags & HIREST_GEMM_REVERSE) && !(g_gemm_dbg & 512)) ? 1 : 0;   // debug bit 9: ignore the direction flags (A/B)
-    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x30000);
-    p.sched = (g_gemm_dbg >> 16) & 3;     // bit 16: uneven XCD split; bit 17: the two-array residual epilogue loads hi / lo cached instead of streaming (A/B)
+    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x70000);
+    p.sched = (g_gemm_dbg >> 16) & 7;     // bit 18: team walk of the persistent ping-pong kernels (few column tiles); bit 16: uneven XCD split; bit 17: the two-array residual epilogue loads hi / lo cached instead of streaming (A/B)
     p.stagger = (g_gemm_dbg >> 10) & 3;
     p.epi_dbg = (g_gemm_dbg >> 12) & 15;   // A/B experiment: start the CUs of an XCD 0..3 quarter tiles apart (bits 10-11 = mode)
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;

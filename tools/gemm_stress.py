@@ -11,6 +11,7 @@ ap.add_argument("--repeats", type=int, default=5)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--variant", type=int, default=6, help="kernel under test (hirest_gemm_select_kernel)")
 ap.add_argument("--full", action="store_true", help="the four production shapes at M = 263168 instead of random shapes")
+ap.add_argument("--dbg", type=int, default=0, help="hirest_gemm_debug_mode bits for the kernel under test (e.g. 262144 = bit 18: team walk)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(a.seed)
@@ -29,6 +30,7 @@ for c in range(a.cases):
     bias = torch.randn((N,), device=dev, generator=g)
     base = torch.randn((M, N), device=dev, generator=g).to(odt)
     def run(variant):
+        _lib.load().hirest_gemm_debug_mode(a.dbg if variant == a.variant else 0)
         ops.gemm_select_kernel(variant)
         out = base.clone()
         ops.gemm(A, W, bias, out, epi)
@@ -45,5 +47,6 @@ for c in range(a.cases):
     bad += not ok
     if c % 10 == 9: print(f"{c + 1} cases, {bad} bad", flush=True)
 ops.gemm_select_kernel(0)
+_lib.load().hirest_gemm_debug_mode(0)
 print("RESULT:", "clean" if bad == 0 else f"{bad} mismatching cases")
 sys.exit(1 if bad else 0)
