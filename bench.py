@@ -48,6 +48,26 @@ GFLOP_EXECUTED_PER_FRAME = GFLOP_PER_FRAME - GFLOP_PRUNED_PER_FRAME
 PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")  # newest first: where roofline.traffic is looked up
 
 
+def small_calls(model, frames):
+    """frames/s of encode_image at the call sizes the reference's own drivers use (inference_video_retrieval.py:59,270: 10 videos x 32
+    frames = 320 per call; extract_features.py:15: 256) and below (one 32-frame video, 64 frames).  Outside the timed region; the
+    1024-frame headline is the same model and kernels.  Calls of fewer than 64 frames take the unfolded-LayerNorm kernels."""
+    flat = frames.reshape(-1, 3, 224, 224)
+    out = {}
+    for n in (32, 64, 128, 256, 320):
+        x = flat[:n]
+        reps = max(3, 1024 // n)
+        for _ in range(2):
+            model.encode_image(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            model.encode_image(x)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+        out[str(n)] = {"frames_per_s": n / dt, "ms_per_call": dt * 1e3}
+    return {"unit": "frames/s by frames per encode_image call", "by_frames_per_call": out,
+            "note": "tile quantisation: a 64-frame call is 65 row panels = 6.09 rounds of 256 x 256 tiles on 256 CUs for fc1, run as 7"}
+
+
 def matched_recall(model, dev):
     """R@1/5/10 of the GPU path against GT(q) = the real reference's top-1 video on the committed C3 sub-corpus, with the
     margin report that says which disagreements a bf16 encoder is entitled to (evaluate.py:33-81 semantics: ranking by
@@ -407,12 +427,14 @@ def main():
     # ---- the other rows of SURVEY 8 (configs[3], configs[4], f4) at the reference's operating point, outside the timed
     # region, rank 0, N = 1: value + roofline fraction + CPU oracle each (tools/secondary_bench.py)
     if rank == 0 and world == 1 and not args.no_secondary:
+        small = small_calls(model, frames)
         del frames
         model.visual._workspace = None
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import secondary_bench
         out["secondary"] = secondary_bench.measure(dev, cpu=not args.no_cpu_baseline, log=_log)
+        out["secondary"]["tower_small_calls"] = small
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1088,6 +1088,16 @@ int launch_rows_stream(const GemmLN& q, int ng, int k, hipStream_t s) {
 
 // M rows as ng groups of mt 16-row tiles (mt <= 5: MT x 48 fragment registers per wave) x 8 k column streams, one block per CU: the
 // split with the shortest block — tiles per stream x (MFMA time of a tile + its reduction) + the prologue (statistics, A phase)
+// hirest_gemm_f32_rows_ln_mode (A/B): 0 one block per CU, ring depth 12, 1 - 3 row tiles per wave; 1 / 2: one row tile per wave, ring depth 4,
+// one / two blocks per CU.  Default 2: the layer products of a merged search (160 x 2304 / 3072 x 768) are a few microseconds of matrix
+// time behind a LayerNorm prologue, and a second block per CU covers one block's prologue with the other's MFMAs (B = 32, beam 5:
+// 1735 -> 1800 captions/s; mode 1: 1755)
+static int g_rows_ln_mode = 2;
+extern "C" int hirest_gemm_f32_rows_ln_mode(int32_t mode) {
+    if (mode < 0 || mode > 2) return HIREST_E_BADARG;
+    g_rows_ln_mode = mode;
+    return 0;
+}
 template <bool LN>
 static int rows_stream(const GemmLN& q, hipStream_t s) {
     static HirestDevCfg cfg;
@@ -1095,6 +1105,11 @@ static int rows_stream(const GemmLN& q, hipStream_t s) {
     if (int e = hirest_configure(gemm_f32_rows_stream_kernel<6, 1, 12, LN>, 160 * 1024, cfg, &cus)) return e;
     const int per_xcd = cus / 8 < 1 ? 1 : cus / 8;          // blockIdx % 8 = XCD
     const int tiles = (q.g.M + 15) / 16, ntile = (q.g.N + 15) / 16;
+    if (LN && g_rows_ln_mode) {
+        int k = (per_xcd * g_rows_ln_mode) / tiles; if (k < 1) k = 1;
+        if (8 * k > ntile) k = (ntile + 7) / 8;
+        return launch_rows_stream<6, 1, 4, LN>(q, tiles, k, s);
+    }
     int best_mt = 0, best_ng = 0, best_k = 0;
     int64_t best = 0;
     for (int mt = 1; mt <= (LN ? 3 : 5); ++mt) {             // (the LayerNorm form of 4 / 5 row tiles does not fit the registers)

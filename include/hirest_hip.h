@@ -491,6 +491,9 @@ int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const float* gamma, c
  * shared fp32 summation order, so bit-identical to hirest_gemm_f32.  colmax (may be NULL) [M, ceil(N / 16)]: per row, the maximum of
  * each 16-column tile of `out`.  The LM head of clip4caption's decoder (module_decoder.py:247-277) at the reference's default
  * --eval_batch_size 32 (args.py:27). */
+/* A/B switch of hirest_gemm_f32_ln's row-group form (above 32 rows): 0 = one block per CU with a 12-slab ring and 1 - 3 row tiles per wave,
+ * 1 / 2 = one row tile per wave, 4-slab rings, one / two blocks per CU (2 is the default).  Same bits. */
+int hirest_gemm_f32_rows_ln_mode(int32_t mode);
 int hirest_gemm_f32_rows_colmax(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
                                 float* colmax, int32_t M, int32_t N, int32_t K, void* stream);
 /* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*dh]; no key masking (the

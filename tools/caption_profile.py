@@ -18,6 +18,9 @@ mm15 = torch.zeros_like(moment_mask); mm15[:, 10:25] = 1
 batch = {"tasks": ["step_captioning"], "vis_feats": vis.to(dev), "vis_mask": vis_mask.to(dev), "moment_mask": mm15,
          "asr_feats": asr.to(dev), "text_feat": text.to(dev)}
 beams = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if os.environ.get("HIREST_ROWS_LN_MODE"):
+    from hirest_amd import _lib
+    _lib.check(_lib.load().hirest_gemm_f32_rows_ln_mode(int(os.environ["HIREST_ROWS_LN_MODE"])), "mode")
 model.test_step(batch, num_beams=beams)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 reps = int(os.environ.get("CAPTION_REPS", "10"))
