@@ -391,6 +391,18 @@ def test_gemm_f32_ln_equals_layernorm_then_gemm(dev, M, N, K, act, embed):
                                           resid.data_ptr() if use_resid else None, N, out.data_ptr(), N, M, N, K, act, st), "gemm_ln")
         assert not want_ln or torch.equal(ln2, ln), use_resid
         assert torch.equal(out, ref), use_resid
+        if not use_resid and M > 32 and K == 768:               # the row-group form's A/B modes (ring depth / blocks per CU): same bits
+            for mode in (0, 1, 2):
+                _lib.check(lib.hirest_gemm_f32_rows_ln_mode(mode), "mode")
+                out.fill_(5.0)
+                try:
+                    _lib.check(lib.hirest_gemm_f32_ln(None if embed else x.data_ptr(), K, ids.data_ptr() if embed else None,
+                                                      table.data_ptr() if embed else None, pos[9].data_ptr() if embed else None, g.data_ptr(),
+                                                      be.data_ptr(), 1e-12, None, K, w.data_ptr(), K, bias.data_ptr(), None, N, out.data_ptr(), N,
+                                                      M, N, K, act, st), "gemm_ln mode")
+                finally:
+                    lib.hirest_gemm_f32_rows_ln_mode(2)
+                assert torch.equal(out, ref), mode
     if K != 768:                                                # (K = 768 takes the row-group streaming kernel for any number of rows above 32)
         assert lib.hirest_gemm_f32_ln(x.data_ptr(), K, None, None, None, g.data_ptr(), be.data_ptr(), 1e-12, None, 0, w.data_ptr(), K, None, None, 0,
                                       out.data_ptr(), N, 257, N, K, act, st) == -2     # more than 256 rows: HIREST_E_SHAPE
