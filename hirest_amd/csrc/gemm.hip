@@ -1268,7 +1268,10 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
                 a_off[hsel][q] = (uint32_t)(ra * (int)p.lda + ca * 8) * 2u;
                 w_off[hsel][q] = (uint32_t)(rn * (int)p.ldw + cw * 8) * 2u;
             }
-        a_base = reinterpret_cast<const char*>(p.A + (int64_t)M0 * p.lda);
+        // TIMING EXPERIMENT (p.sched bit 3 = hirest_gemm_debug_mode bit 19; results are wrong): the A operand of every tile wraps into the
+        // XCD's first four panels (2.9 MB: L2-resident after the first touch) — what a perfect L2 hit rate on A would be worth
+        const int Ma = (p.sched & 8) ? (p_lo + ((M0 / T_BM - p_lo) & 3)) * T_BM : M0;
+        a_base = reinterpret_cast<const char*>(p.A + (int64_t)Ma * p.lda);
         w_base = reinterpret_cast<const char*>(p.W + (int64_t)N0 * p.ldw);
     };
     // The refill stream is two steps ahead of the step being multiplied; its a1 group is issued one step later than its
@@ -1654,7 +1657,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (epi == HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;      // exists in the X3 form only
     const bool fused = (epi >= HIREST_EPI_BIAS_RESID_LNSTATS_F32 && epi <= HIREST_EPI_LNFOLD_GELU_BF16) || epi == HIREST_EPI_BIAS_RESID2_LNSTATS;
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
-    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x70000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
+    const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0xF0000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
     if (f == 9 || (fused && f != 6 && f != 8) || (!fused && f == 0 && big && !dbg_inst)) snprintf(out, out_len, "gemm_pq256<%d>", epi);
     else if (fused) {
@@ -1683,8 +1686,8 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     p.pos = a->pos; p.P = a->patches_per_frame;
     p.aux0 = a->aux0; p.aux1 = a->aux1;
     p.rev = ((a->flags & HIREST_GEMM_REVERSE) && !(g_gemm_dbg & 512)) ? 1 : 0;   // debug bit 9: ignore the direction flags (A/B)
-    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0x70000);
-    p.sched = (g_gemm_dbg >> 16) & 7;     // bit 18: team walk of the persistent ping-pong kernels (few column tiles); bit 16: uneven XCD split; bit 17: the two-array residual epilogue loads hi / lo cached instead of streaming (A/B)
+    p.dbg = g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0xF0000);
+    p.sched = (g_gemm_dbg >> 16) & 15;     // bit 18: team walk of the persistent ping-pong kernels (few column tiles); bit 16: uneven XCD split; bit 17: the two-array residual epilogue loads hi / lo cached instead of streaming (A/B)
     p.stagger = (g_gemm_dbg >> 10) & 3;
     p.epi_dbg = (g_gemm_dbg >> 12) & 15;   // A/B experiment: start the CUs of an XCD 0..3 quarter tiles apart (bits 10-11 = mode)
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
