@@ -141,7 +141,7 @@ def matched_recall(model, dev):
         if fc:
             ms = sum(r.ms for r in fc) / len(fc)
             tf = 2.0 * fc[0].d0 * fc[0].d1 * (fc[0].d2 // 2) / (ms * 1e-3) / 1e12
-            x3["roofline"] = {"bound": "mfma", "kernel": f"gemm_pp256x3<bias->f32> fc1 M={fc[0].d0} N={fc[0].d1} K={fc[0].d2 // 2} (x2 split columns)",
+            x3["roofline"] = {"bound": "mfma", "kernel": f"gemm_pp256x3<bias+gelu->split hi|lo (HIREST_EPI_BIAS_GELU_SPLIT2)> fc1 M={fc[0].d0} N={fc[0].d1} K={fc[0].d2 // 2} (x2 split columns)",
                               "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS / 3, "unit": "TFLOP/s", "frac": tf / (MFMA_BF16_PEAK_TFLOPS / 3),
                               "avg_launch_ms": ms, "launches": len(fc),
                               "note": "algorithmic flops (2 M N K) over the kernel's live hipEvent time; peak = dense bf16 MFMA peak / 3 "

@@ -342,7 +342,8 @@ __device__ __forceinline__ void sleep_n(int n) {   // ~64 n cycles
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
 template <int NW, int CPR> struct ROWS_PER_PIECE_OK { static constexpr bool value = (NW * 64 % CPR == 0) && ((NW * 64 / CPR) % 8 == 0); };
-// LEAN (the default since round 4): the softmax arithmetic on fewer VALU instructions, same structure.  rocprofv3 counted 590 VALU
+// LEAN (selectable: hirest_attention_select; the default g_attn_variant = 7 is the non-LEAN form + producer wave, v3's bits): the softmax
+// arithmetic on fewer VALU instructions, same structure.  rocprofv3 counted 590 VALU
 // instructions per 16-query tile against 105 MFMAs (profiles/r03/pmc_summary.md), and the ISA showed where they were: every
 // fmaxf operand canonicalised first (v_max_f32 x, x: 68 per tile), 68 scalar v_fma, 68 scalar adds for the row sum.  Now:
 //   row max      v_max3_f32 written out (two values per instruction, no canonicalisation: MFMA results are never signalling NaNs)

@@ -56,13 +56,8 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, int m, int n, f32
     }
 }
 
-// X3 (split operands, see the ping-pong kernel's header): a 64-deep step holds [hi | lo] of 32 real k, and each of its two 16-deep
-// MFMA chunks issues W_hi A_lo, W_lo A_hi, W_hi A_hi on fragments read once.  This is the split-operand kernel for problems
-// too small to fill the chip with 256 x 256 tiles: the joint model's training GEMMs (1 500 rows, 768 - 3 072 wide).
-// NST = LDS ring slots (32 KiB each).  2: double buffer, two workgroups per CU cover each other's load latency (the bf16 problems this
-// kernel serves have thousands of tiles).  4 (the split-operand form): the training GEMMs have 72 - 288 tiles, at most one workgroup
-// per CU, and a 64-deep step is ~800 cycles of MFMA against ~2 us of load latency — three steps stay in flight (counted vmcnt).
-template <int EPI, bool X3, int NST = 2>
+// (The split-operand small-problem kernel is its own kernel further down: gemm_t128x3.)
+template <int EPI>
 __device__ __forceinline__ void t128_body(const GemmP& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,47 +116,13 @@ __device__ __forceinline__ void t128_body(const GemmP& p) {
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
     const int nk = p.K / BK;
-    if constexpr (NST == 2) stage(0, 0);
-    else {
-#pragma unroll
-        for (int i = 0; i < NST - 1; ++i) if (i < nk) stage(i, i);
-    }
+    stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        if constexpr (NST == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        } else {
-            // steps kt + 1 .. kt + NST - 2 may stay in flight (8 LDS-DMA instructions per wave and step); near the end fewer were issued
-            const int ahead = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                   // step kt landed everywhere; everyone is done reading step kt - 1
-            if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
-        }
-        const char* As = smem + (kt % NST) * STAGE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* As = smem + (kt & 1) * STAGE_BYTES;
         const char* Ws = As + BM * BK * 2;
-        if constexpr (X3) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[2][2], wf[2][2];                      // [row tile][0 hi, 1 lo]
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        af[i][h] = *reinterpret_cast<const bf16x8*>(As + a_row_off + i * 32 * BK * 2 + koff[kk + 2 * h]);
-                        wf[i][h] = *reinterpret_cast<const bf16x8*>(Ws + w_row_off + i * 32 * BK * 2 + koff[kk + 2 * h]);
-                    }
-#pragma unroll
-                for (int g3 = 0; g3 < 3; ++g3)                  // (W half, A half): (hi, lo), (lo, hi), (hi, hi)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < 2; ++jn)
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jn][g3 == 1 ? 1 : 0], af[i][g3 == 0 ? 1 : 0], acc[i][jn], 0, 0, 0);
-            }
-        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 af[2], wf[2];
@@ -175,7 +136,6 @@ __device__ __forceinline__ void t128_body(const GemmP& p) {
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jn], af[i], acc[i][jn], 0, 0, 0);
-        }
         }
     }
 
@@ -198,7 +158,7 @@ __device__ __forceinline__ void t128_body(const GemmP& p) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) { t128_body<EPI, false>(p); }
+__global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) { t128_body<EPI>(p); }
 
 // Split-operand ("bf16x3") kernel for problems of a few hundred 128 x 128 tiles at most — the joint model's training GEMMs (1 500 rows,
 // 768 - 3 072 wide, K = 768 - 3 072): one workgroup per tile and CU, so what matters is how fast ONE tile goes.  Eight waves = the 2 x 2

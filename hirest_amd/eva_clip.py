@@ -574,9 +574,14 @@ def create_model(model_name: str, pretrained: str = "", precision: str = "fp32",
     # ``precision`` (run.py / inference_video_retrieval.py / extract_features.py all get the fp32 default): the environment
     # selects the towers without an edit at the call site.  Unset: the argument decides, as in the reference.
     env = os.environ.get("HIREST_PRECISION", "").strip().lower()
+    if env and env not in TOWER_PRECISIONS:
+        raise ValueError(f"HIREST_PRECISION={env!r}: expected one of {TOWER_PRECISIONS}")
+    if env and precision != "fp32" and precision != env:
+        # an explicit non-default argument is the caller's decision; the environment only redirects the fp32 DEFAULT of unmodified callers
+        import warnings
+        warnings.warn(f"hirest_amd: HIREST_PRECISION={env} ignored: create_model was called with precision={precision!r}")
+        env = ""
     if env:
-        if env not in TOWER_PRECISIONS:
-            raise ValueError(f"HIREST_PRECISION={env!r}: expected one of {TOWER_PRECISIONS}")
         model.set_precision(env)
     elif precision == "fp32":
         model.set_precision("fp32")

@@ -39,6 +39,7 @@ def on_tensor_device(fn):
     @functools.wraps(fn)
     def wrapped(*args, **kw):
         for a in list(args) + list(kw.values()):
+            a = getattr(a, "data", a) if isinstance(a, BlockedSplit) else a      # (a blocked split operand: its storage tensor)
             if isinstance(a, torch.Tensor) and a.is_cuda:
                 if a.device.index != torch.cuda.current_device():
                     with torch.cuda.device(a.device):
@@ -244,7 +245,10 @@ def gemm_x3(a2: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = N
     out = resid_out if resid_out is not None else torch.empty((M, N), dtype=torch.float32, device=a2.data.device if blocked else a2.device)
     epi = _lib.EPI_BIAS_RESID_F32 if resid_out is not None else _lib.EPI_BIAS_F32
     if blocked:
-        args = _lib.GemmArgs.make(a2.data.data_ptr(), a2.rows * 64, w2.data.data_ptr(), w2.rows * 64, _opt(bias, torch.float32, "gemm_x3.bias"),
+        if a2.data.device != w2.data.device:
+            raise RuntimeError("gemm_x3: the blocked operands live on different devices")
+        args = _lib.GemmArgs.make(_dev(a2.data, torch.bfloat16, "gemm_x3.a (blocked)"), a2.rows * 64, _dev(w2.data, torch.bfloat16, "gemm_x3.w (blocked)"),
+                                  w2.rows * 64, _opt(bias, torch.float32, "gemm_x3.bias"),
                                   out.data_ptr(), N, M, N, K2, epi, None, 0, None, None, _lib.GEMM_X3 | _lib.GEMM_KBLOCKED)
     else:
         args = _lib.GemmArgs.make(_dev(a2, torch.bfloat16, "gemm_x3.a"), K2, _dev(w2, torch.bfloat16, "gemm_x3.w"), K2,

@@ -292,8 +292,11 @@ def run_corpus(model, source, prompts: Sequence[str], n_model_frames: Optional[i
     ``all_gather_into_tensor`` of the padded ``[ceil(V/N), E]`` blocks (RCCL over xGMI on GPU tensors; gloo on CPU tensors)
     assembles the ``[V, E]`` matrix in corpus order on every rank, and text encoding + scoring are replicated (546 x 4096 x
     1024 is 4.6 GFLOP).  Without an initialised process group it is the single-process run.  Returns the reference's
-    ``{prompt: {"videos", "scores"}}`` dict (``RetrievalResult``); identical on every rank, and — because every video's
-    row depends on that video alone — identical for every N."""
+    ``{prompt: {"videos", "scores"}}`` dict (``RetrievalResult``); identical on every rank.  Every video's row depends on that
+    video alone, so the scores agree for every N to the kernels' tolerance; they are BIT-identical across N when every rank's
+    block is a whole number of ``videos_per_call`` groups of >= 64 frames (4096 videos on 1 / 2 / 4 / 8 ranks at 32 per call):
+    a remainder call of fewer than 64 frames takes the unfolded-LayerNorm / per-head attention kernels, whose bits differ from
+    the folded path's (tools/c3_run.py compares digests only for such shard sizes)."""
     device = torch.device(device) if device is not None else next(model.parameters()).device
     rank, world = _rank_world(group)
     local = corpus_block_rows(model, source, rank, world, n_model_frames, device)

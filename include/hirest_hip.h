@@ -68,7 +68,9 @@ enum hirest_epilogue {
                                         must be readable up to an EVEN number of rows, i.e. M + 1 rows when M is odd),
                                         aux1 = s [N];  out bf16 = rstd * (acc - mean * s) + b' */
     HIREST_EPI_LNFOLD_GELU_BF16 = 8, /* same, then gelu_erf */
-    HIREST_EPI_BIAS_GELU_SPLIT2 = 9, /* HIREST_GEMM_X3 only: out bf16 [M, 2N] = nn.GELU()(acc + bias) (erf form, fp32) in the split operand format
+    HIREST_EPI_BIAS_GELU_SPLIT2 = 9, /* HIREST_GEMM_X3 only: out bf16 [M, 2N] = nn.GELU()(acc + bias) (erf form in fp32 by the bf16 towers' degree-8
+                                        exp2 polynomial, csrc/common.h gelu_erf2: max abs error 1.1e-6 against exact erff, which the separate
+                                        hirest_split2_bf16(act = 1) pass uses — the two routes are NOT bit-equal) in the split operand format
                                         of hirest_split2_bf16 (per 64 columns: hi of 32 outputs | their lo): fc1 of the bf16x3 tower feeding fc2
                                         without an fp32 round trip.  N % 32 == 0, ldo >= 2N. */
     HIREST_EPI_BIAS_RESID2_LNSTATS = 10 /* producer like HIREST_EPI_BIAS_RESID_LNSTATS_F32 with the residual stream kept as two bf16 arrays:

@@ -67,6 +67,9 @@ def test_bench_line_contract():
         if key != "step_captioning_beam3":
             assert e["cpu_baseline"]["kind"] == "port" and e["cpu_baseline"]["value"] > 0 and e["cpu_baseline"]["cores"] >= 1, key
     assert sec["moment_retrieval"]["indices_equal_cpu_oracle"] and sec["moment_segmentation"]["boundaries_equal_cpu_oracle"]
+    # the reference's default --eval_batch_size 32 (args.py:27): indices and boundary lists of the REAL MomentModel (joint_predictions.json d300)
+    assert sec["moment_retrieval_b32"]["indices_equal_real_reference"] and sec["moment_segmentation_b32"]["boundaries_equal_real_reference"]
+    assert sec["moment_retrieval_b32"]["value"] > sec["moment_retrieval"]["value"]
     assert sec["step_captioning_beam5"]["token_ids_equal_cpu_oracle_on_sample"]
     for beams in (3, 5):           # all five captions of the timed batch equal the REAL reference's (caption_predictions.json c3 / c5)
         assert sec[f"step_captioning_beam{beams}"]["token_ids_equal_real_reference"] == "5 of 5 captions"

@@ -108,6 +108,26 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         ent["boundaries_equal_cpu_oracle"] = bool(s_cpu == pred)
     out["moment_segmentation"] = ent
 
+    # ---- the same two tasks at the reference's DEFAULT evaluation batch (args.py:27 --eval_batch_size 32) on the inputs of the real-reference
+    # golden joint_d300 (make_golden.py gen_joint: the REAL MomentModel.test_step at B = 32, T = 300): every index / boundary list compared
+    log("secondary: moment retrieval / segmentation at B = 32")
+    jgold = json.load(open(os.path.join(ROOT, "tests", "golden", "joint_predictions.json")))["d300"]
+    B32 = jgold["B"]
+    dvis, dasr, dtext, dvm, dmm, dbounds = joint_inputs("joint.d300", B32, T, 41)
+    c32 = {"vis_feats": g(dvis), "vis_mask": g(dvm), "asr_feats": g(dasr), "text_feat": g(dtext)}
+    dt, pred = _timeit(lambda: model.test_step(dict(c32, tasks=["moment_retrieval"], moment_mask=g(dmm)))["prediction"], 10, sync)
+    flops = B32 * T * (fusion_flops_per_token() + encoder_flops_per_token(T) + 2 * 2 * H)
+    out["moment_retrieval_b32"] = {"value": B32 / dt, "unit": "videos/s", "ms_per_batch": dt * 1e3, "batch": B32,
+                                   "indices_equal_real_reference": bool(pred == jgold["pred_moment_retrieval"]),
+                                   "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_batch": flops}}
+    dt, pred = _timeit(lambda: model.test_step(dict(c32, tasks=["moment_segmentation"], moment_bound_frames=dbounds))["prediction"], 3, sync)
+    flops = B32 * T * (fusion_flops_per_token() + 20 * (encoder_flops_per_token(T) + 2 * H))
+    out["moment_segmentation_b32"] = {"value": B32 / dt, "unit": "videos/s", "ms_per_batch": dt * 1e3, "batch": B32, "iterations": 20,
+                                      "boundaries_equal_real_reference": bool(pred == jgold["pred_segmentation"]),
+                                      "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                   "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_batch": flops}}
+
     # ---- step captioning (BASELINE configs[4]; modeling.py:556-632) at its own operating point: B = 5, 15-frame
     # moments -> 20 trimmed frames, 48 words, on the inputs of the real-reference goldens tests/golden/caption_predictions.json
     # cases c3 / c5 (make_golden.py gen_caption: the REAL MomentModel.test_step), so ALL FIVE captions of the timed batch are
