@@ -787,12 +787,13 @@ __global__ __launch_bounds__(256 * MT) void gemm_f32_m16ln_stream_kernel(GemmLN 
                 if (issued < items) dma();
             }
         }
-        __syncthreads();                                     // the previous tile's sums have been read
+        // (bare barriers: __syncthreads() also waits for vmcnt(0), i.e. empties every wave's W ring at every tile — round 5)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous tile's sums have been read
         if (have && kq > 0) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) red[kq - 1][t][lane] = acc[t];
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (have && kq == 0) {
             const int tile = tile0 + i * tstep, n = tile * 16 + 4 * slot;
 #pragma unroll

@@ -114,6 +114,58 @@ def frame_features(model, frames: torch.Tensor, batch_size: int = 1024, normaliz
     return feats
 
 
+@torch.no_grad()
+def frame_features_many(model, videos, min_call: int = 256, max_call: int = 1024, normalize: bool = True):
+    """``frame_features`` for a LIST of videos (each [T_i,3,S,S] preprocessed, or uint8 [T_i,H,W,3] decoded frames of one size per
+    video): consecutive videos are encoded TOGETHER until a call holds at least ``min_call`` frames (at most ``max_call``), because a
+    tower call of a few dozen frames loses a fifth of its throughput to tile quantisation (a 64-frame call is 6.09 rounds of 256 x 256
+    tiles run as 7; below 64 frames the LayerNorm fold and the persistent attention are off as well).  extract_features.py:46-69
+    encodes one video at a time; this is the same per-video output — a list of [T_i,E] fp32 GPU tensors — with short videos riding
+    along with their neighbours.  Every frame's embedding depends on that frame alone; its bits are those of ``frame_features`` on the
+    same video whenever both calls take the same kernels (both >= 64 frames), and within the bf16 towers' tolerance otherwise."""
+    videos = list(videos)
+    out = [None] * len(videos)
+    size = model.visual.image_size
+    group, count = [], 0
+
+    def flush():
+        nonlocal group, count
+        if not group:
+            return
+        prepared = []
+        for i in group:
+            f = videos[i]
+            if f.dtype == torch.uint8 and tuple(f.shape[1:3]) != (size, size):
+                from .preprocess import FramePreprocessor
+                pre = getattr(model, "_frame_preprocessor", None)
+                if pre is None:
+                    pre = FramePreprocessor(size, getattr(model.visual, "image_mean", None), getattr(model.visual, "image_std", None))
+                    object.__setattr__(model, "_frame_preprocessor", pre)
+                f = pre(f)
+            prepared.append(f)
+        same = len({(p.dtype, tuple(p.shape[1:])) for p in prepared}) == 1
+        if same:
+            feats = frame_features(model, torch.cat(prepared) if len(prepared) > 1 else prepared[0], batch_size=max_call, normalize=normalize)
+            lo = 0
+            for i, p in zip(group, prepared):
+                out[i] = feats[lo:lo + p.shape[0]]
+                lo += p.shape[0]
+        else:                                   # mixed input formats in one group: nothing to concatenate, one call each
+            for i, p in zip(group, prepared):
+                out[i] = frame_features(model, p, batch_size=max_call, normalize=normalize)
+        group, count = [], 0
+    for i, f in enumerate(videos):
+        n = int(f.shape[0])
+        if group and count + n > max_call:
+            flush()
+        group.append(i)
+        count += n
+        if count >= min_call:
+            flush()
+    flush()
+    return out
+
+
 class FeatureWriter:
     """Streaming ``torch.save`` of per-video feature tensors: ``submit`` enqueues an asynchronous device->pinned-host
     copy on a side stream and returns; a writer thread waits for the copy and writes ``<save_dir>/<name>.pt`` (a plain
