@@ -7,6 +7,7 @@
 // (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, 1/16 of the bf16 rate) — at 10-90 GFLOP per video the
 // whole model is still a few hundred microseconds.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -240,6 +241,106 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmF p) {
         if (n >= p.N) continue;
         epilogue_apply4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, ep[g], m, n);
     }
+}
+
+// The same 64x64 tile with its operands on an LDS-DMA ring (round 5), for problems of dozens of tiles per CU (the fp32 towers' layers).  A slab
+// (64 A rows + 64 W rows x 128 B = 16 KB) is 16 LDS-DMA pieces of 8 whole lines, four per wave, DEPTH - 1 slabs ahead (3 of 4 slots, two blocks
+// per CU), ONE bare barrier per slab:
+//     wait own pieces of slab s (counted vmcnt) | lgkmcnt(0), s_barrier | refill slab s - 1's slot with slab s + DEPTH - 1 | 8 ds_read_b128 | 16 MFMA
+// RAW: every wave waited for its own pieces of slab s before the barrier.  WAR: a wave's fragment reads of slab s - 1 retired (lgkmcnt(0))
+// before it arrived at the barrier of step s, after which the slot is refilled.  Same products in the same order as gemm_f32_kernel (four K
+// quarters walked one after the other, MFMA step j pairs k0 + j with k0 + 16 + j, ((p0 + p1) + p2) + p3) -> same bits.  Row-major operands,
+// K % 32 == 0 (the DMA moves whole 128-B row pieces); everything else stays with the kernel above.
+// LDS image: row r of an operand block at 128 r, global chunk c at position c ^ ((r >> 1) & 7): the 16-lane groups of ds_read_b128 reading one
+// chunk of consecutive rows fall on 16 distinct 16-B slots.
+template <int DEPTH>
+__global__ __launch_bounds__(256, DEPTH <= 4 ? 2 : 1) void gemm_f32_ring_kernel(GemmF p) {
+    constexpr int SLAB = 16384, WOFF = 8192, L = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M0 = blockIdx.y * 64, N0 = blockIdx.x * 64;
+    // this wave's four pieces of a slab: waves 0 / 1 the A rows 0-31 / 32-63, waves 2 / 3 the W rows
+    const char* src[L];
+    int dst[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int r = 32 * (wave & 1) + 8 * j + (lane >> 3);          // row inside the operand's 64-row block
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        if (wave < 2) { int gm = M0 + r; gm = gm < p.M ? gm : p.M - 1; src[j] = reinterpret_cast<const char*>(p.A + (int64_t)gm * p.lda) + 16 * chunk; }
+        else { int gn = N0 + r; gn = gn < p.N ? gn : p.N - 1; src[j] = reinterpret_cast<const char*>(p.W + (int64_t)gn * p.ldw) + 16 * chunk; }
+        dst[j] = (wave < 2 ? 0 : WOFF) + (32 * (wave & 1) + 8 * j) * 128;
+    }
+    const int nslab = p.K / FK;
+    auto dma = [&](int s) {                                  // slab s -> ring slot s % DEPTH
+        char* slot = smem + (s % DEPTH) * SLAB;
+#pragma unroll
+        for (int j = 0; j < L; ++j) glds16(src[j] + (int64_t)s * (FK * 4), slot + dst[j]);
+    };
+#pragma unroll 1
+    for (int s = 0; s < DEPTH - 1 && s < nslab; ++s) dma(s);
+    const int row = lane & 31, half = lane >> 5;
+    const int ra = wm * 32 + row, rw = wn * 32 + row;
+    int fa[4], fw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        fa[c] = ra * 128 + (((4 * half + c) ^ ((ra >> 1) & 7)) << 4);
+        fw[c] = WOFF + rw * 128 + (((4 * half + c) ^ ((rw >> 1) & 7)) << 4);
+    }
+    f32x16 acc, part;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; part[e] = 0.f; }
+    const int quarter = (nslab + 3) >> 2;
+    int u = 0;
+    auto close_quarter = [&]() {                             // partial sum u is complete: acc = ((p0 + p1) + p2) + p3 as they come
+        if (u == 0) acc = part;
+        else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += part[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[e] = 0.f;
+        ++u;
+    };
+#pragma unroll 1
+    for (int s = 0; s < nslab; ++s) {
+        // slabs s .. min(s + DEPTH - 2, nslab - 1) are in flight, in order: slab s has landed once at most DEPTH - 2 slabs are pending
+        if (nslab - s >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 2) * L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + DEPTH - 1 < nslab) dma(s + DEPTH - 1);
+        const char* slot = smem + (s % DEPTH) * SLAB;
+        f32x4 aq[4], wq[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            aq[c] = *reinterpret_cast<const f32x4*>(slot + fa[c]);
+            wq[c] = *reinterpret_cast<const f32x4*>(slot + fw[c]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) part = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j >> 2][j & 3], aq[j >> 2][j & 3], part, 0, 0, 0);
+        if (s + 1 == (u + 1) * quarter || s + 1 == nslab) close_quarter();
+    }
+    while (u < 4) close_quarter();                           // quarters without a slab (K < 4 slabs) still take their place in the sum: + 0
+    const int m = M0 + wm * 32 + row;
+    Epi4 ep[4];                                              // the four column groups' operands in one burst
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ep[g] = epilogue_fetch4(p, m, N0 + wn * 32 + 8 * g + 4 * half);
+    if (m >= p.M) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = N0 + wn * 32 + 8 * g + 4 * half;
+        if (n >= p.N) continue;
+        epilogue_apply4(p, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, ep[g], m, n);
+    }
+}
+
+template <int DEPTH>
+int launch_ring(const GemmF& p, hipStream_t s) {
+    static HirestDevCfg cfg;
+    auto kern = gemm_f32_ring_kernel<DEPTH>;
+    if (int e = hirest_configure(kern, DEPTH * 16384, cfg)) return e;
+    hipLaunchKernelGGL(kern, dim3((p.N + 63) / 64, (p.M + 63) / 64), dim3(256), DEPTH * 16384, s, p);
+    return hirest_launch_status();
 }
 
 // second half of the split form: out = epilogue(((p0 + p1) + p2) + p3), four columns per thread
@@ -1625,6 +1726,12 @@ inline int grid1d(int64_t total, int cap = 4096) { int64_t g = (total + 255) / 2
 
 }  // namespace
 
+static int g_f32_ring = 0;         // hirest_gemm_f32_ring_mode (A/B): 0 automatic, 1 off (the register-prefetch kernel), 2 always the ring
+extern "C" int hirest_gemm_f32_ring_mode(int32_t mode) {
+    if (mode < 0 || mode > 2) return HIREST_E_BADARG;
+    g_f32_ring = mode;
+    return 0;
+}
 static int g_f32_kernel = 0;       // hirest_gemm_f32_select_kernel: A/B and tests
 // 0 automatic (16-column kernel for M <= 256 when K % 32 == 0 [N < 8192 above 32 rows], else the split-K 32x32 kernel for M <= 256),
 // 1 always the 64x64 kernel, 2 automatic without the 16-column kernel
@@ -1667,6 +1774,16 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
         hipLaunchKernelGGL(gemm_f32_skinny_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
         return hirest_launch_status();
     }
+    // row-major operands in whole 32-deep slabs, dozens of tiles per CU (the fp32 towers' layers): the LDS-DMA ring form of the same tile (same
+    // bits), 4 slots and two blocks per CU: 105 -> 111 TFLOP/s at 65 792 rows.  Below ~64 tiles per CU the register-prefetch form with its four
+    // blocks per CU is as fast or faster (9600 x 3072 x 768: 103 vs 100), and a deeper ring with one block per CU loses everywhere — a lone wave per
+    // SIMD pays for its own DMA issue and fragment latency (profiles/r05/gemm_f32_ring_ab.txt)
+    if (g_f32_kernel == 0 && g_f32_ring != 1 && K % FK == 0 && K >= 2 * FK) {
+        int cus = 0; static HirestDevCfg cfg;
+        if (int e = hirest_configure(gemm_f32_ring_kernel<4>, 4 * 16384, cfg, &cus)) return e;
+        const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+        if (g_f32_ring == 2 || tiles >= 64 * (int64_t)cus) return launch_ring<4>(p, reinterpret_cast<hipStream_t>(stream));
+    }
     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     return hirest_launch_status();
 }
@@ -1676,7 +1793,9 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
 // 512 .. 2048 for K and 400 .. 1200 tiles measure the same: the gain is the K = 3072 layer)
 static bool splits(int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
-    return g_f32_kernel == 0 && M > 256 && tiles <= 512 && K >= 1024;
+    // (round 5: from K = 512 — 1500 x 768 x 768, 288 tiles: 38.4 -> 33.6 us; HIREST_F32_SPLIT_MIN_K = A/B of the threshold)
+    static const int min_k = [] { const char* e = getenv("HIREST_F32_SPLIT_MIN_K"); return e ? atoi(e) : 512; }();
+    return g_f32_kernel == 0 && M > 256 && tiles <= 512 && K >= min_k;
 }
 extern "C" size_t hirest_gemm_f32_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     return (M > 0 && N > 0 && K > 0 && splits(M, N, K)) ? (size_t)4 * M * N * 4 : 0;

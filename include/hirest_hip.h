@@ -473,6 +473,10 @@ int hirest_gemm_f32_layouts(const float* A, int64_t lda, int32_t a_kmajor, const
  * share K, operands by LDS-DMA; other M <= 256: the split-K "skinny" kernel, 32x32 tiles; otherwise 64x64 tiles), 1 = always the
  * 64x64 kernel, 2 = automatic without the 16-column kernel.  All three are exact fp32 MFMA and add the same products in the same order: bit-identical results (tests / A-B timing). */
 int hirest_gemm_f32_select_kernel(int32_t which);
+/* The 64x64 kernel's operand path for row-major operands with K % 32 == 0: 0 = automatic (LDS-DMA ring, 4 slots and two blocks per CU, from 64
+ * tiles per CU on: the fp32 towers' layers), 1 = off (two slabs ahead through registers, the only form for k-major operands and ragged K),
+ * 2 = always the ring.  Same bits in every mode (tests / A-B timing). */
+int hirest_gemm_f32_ring_mode(int32_t mode);
 /* out = act(LayerNorm(X; gamma, beta, eps) @ W^T + bias) (+ resid) for M <= 256 rows (N < 8192; the LM-head form N >= 8192, K = 768
  * takes M <= 32), K % 256 == 0, K <= 1024: the rows are
  * normalised inside the GEMM with hirest_layernorm's own arithmetic (same bits as the two calls), and written to ln_out as well
