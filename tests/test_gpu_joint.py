@@ -73,6 +73,30 @@ def test_gemm_f32_kernels_share_their_summation_order(dev):
             assert torch.equal(MomentModel._gemm(big, w, b, act=1)[M:2 * M], outs[0]), (M, N, K)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1500, 768, 768, 1), (300, 2304, 768, 0), (1000, 100, 64, 2), (4100, 772, 96, 3), (257, 64, 3072, 0), (700, 36, 2080, 1)])
+def test_gemm_f32_ring_form_equals_the_register_prefetch_kernel(dev, M, N, K, act):
+    """gemm_f32_ring_kernel (the 64 x 64 tile with its operands on an LDS-DMA ring; automatic from 64 tiles per CU on) against the
+    register-prefetch kernel: same K quarters, same k order -> bit for bit, with bias / activation / residual / periodic epilogue operands,
+    ragged M and N, K of 2 .. 96 slabs (quarters without a slab included)."""
+    from hirest_amd import _lib
+    from hirest_amd.moment_model import MomentModel
+    lib = _lib.load()
+    a = synth.tensor("rg.a", (M, K), 1.0, 4).to(dev)
+    w = synth.tensor("rg.w", (N, K), 0.05, 4).to(dev)
+    b = synth.tensor("rg.b", (N,), 0.3, 4).to(dev)
+    r = synth.tensor("rg.r", (M, N), 1.0, 4).to(dev)
+    pos = synth.tensor("rg.p", (50, N), 0.5, 4).to(dev)
+    outs = []
+    for mode in (1, 2, 0):
+        _lib.check(lib.hirest_gemm_f32_ring_mode(mode), "ring mode")
+        try:
+            outs.append(MomentModel._gemm(a, w, b, resid=r, periodic=pos, period=50, act=act))
+        finally:
+            lib.hirest_gemm_f32_ring_mode(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert lib.hirest_gemm_f32_ring_mode(3) == -1
+
+
 def _gemm_f32_case(dev, M, N, K, act, MomentModel):
     a = synth.tensor("jf.a", (M, K), 1.0, 1)
     w = synth.tensor("jf.w", (N, K), 0.05, 1)
