@@ -9,7 +9,8 @@ for f in bench_n1.json bench_under_rocprofv3.json rocprofv3_kernel_stats_bench.c
          pmc_bench_counters.txt pmc_table_bench.md secondary.json caption_word_timeline.txt caption_captions_per_s.txt pmc_caption_kernels.txt \
          fma_order_probe.txt wave_sum_probe.txt lane_path_probe.txt lm_head_probe.txt train_bench.txt rocprofv3_kernel_stats_train_step.csv \
          train_step_timeline.txt train_host_probe.txt gemm_f32_sweep.txt mfma_f32_peak_probe.txt caption_batch_breakdown.txt \
-         x3_bench.json pmc_x3_kernels.txt pmc_table_x3.md no_profile_ab.txt caption_streams_sweep.txt grid_barrier_probe.txt c3_512_rank_blocks.json c3_n1.json; do
+         x3_bench.json pmc_x3_kernels.txt pmc_table_x3.md no_profile_ab.txt caption_streams_sweep.txt grid_barrier_probe.txt c3_512_rank_blocks.json c3_n1.json \
+         caption_captions_per_s_by_batch.txt lm_head_rows_ab.txt caption_word_timeline_b32_beam5.txt caption_word_timeline_b32_beam3.txt lds_rate_probe_run.txt gemm_f32_ring_ab_run.txt; do
   [ -f $src/$f ] && cp $src/$f $dst/$f
 done
 grep -E "passed|failed|error" $src/pytest_gpu.log | tail -3 > $dst/pytest_gpu_tail.txt

@@ -39,4 +39,10 @@ timeout 400 python tools/caption_streams_sweep.py 2>&1 | grep -v amdgpu.ids > $o
 hipcc --offload-arch=gfx950 -O2 -w -o /tmp/gbp tools/probes/grid_barrier_probe.hip && timeout 120 /tmp/gbp > $out/grid_barrier_probe.txt 2>&1
 timeout 300 python tools/c3_run.py --videos 512 --rank-blocks 8 --out $out/c3_512_rank_blocks.json > /dev/null 2>&1
 timeout 400 python tools/c3_run.py --out $out/c3_n1.json > /dev/null 2>&1
+# round 5: merged / B = 32 captioning (captions/s, word timelines, the LM-head kernels by row count), the LDS rate probe, the fp32 GEMM's operand paths
+CAPT_K="nothing_selected" bash tools/r05_caption.sh > $out/r05_caption.log 2>&1
+cp gpurun_out/capt5/captions.txt $out/caption_captions_per_s_by_batch.txt; cp gpurun_out/capt5/lm_head_rows_ab.txt $out/lm_head_rows_ab.txt
+cp gpurun_out/capt5/word_timeline_b32_beam5.txt $out/caption_word_timeline_b32_beam5.txt; cp gpurun_out/capt5/word_timeline_b32_beam3.txt $out/caption_word_timeline_b32_beam3.txt
+hipcc --offload-arch=gfx950 -O2 -w -o /tmp/lds_rate_probe tools/probes/lds_rate_probe.hip && timeout 60 /tmp/lds_rate_probe > $out/lds_rate_probe_run.txt 2>&1
+timeout 300 python tools/gemm_f32_ring_ab.py 2>&1 | grep -v amdgpu.ids > $out/gemm_f32_ring_ab_run.txt
 date +%s > $out/collected_at
