@@ -20,7 +20,6 @@ TOWER_NO_PRUNE = 2
 TOWER_F32_RESIDUAL = 4
 GEMM_REVERSE = 1
 GEMM_X3 = 2
-GEMM_KBLOCKED = 4
 ABI_VERSION = 3   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
 
 ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}
@@ -266,8 +265,6 @@ _SIGNATURES = {
     "hirest_vision_workspace_bytes_f32": (C.c_size_t, [C.POINTER(VisionTowerF32), C.c_int32]),
     "hirest_vision_embed_f32": (C.c_int, [C.POINTER(VisionTowerF32), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hirest_split2_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
-    "hirest_split2_both_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
-                                          C.c_void_p]),
     "hirest_layernorm_split2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int32,
                                           C.c_int32, C.c_void_p]),
     "hirest_attention_x3_qkv": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

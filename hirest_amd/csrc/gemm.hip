@@ -167,11 +167,9 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) { t128_body<EPI>(p)
 // stage.  Two waves per SIMD cover each other's fragment reads; a 4-slot ring keeps three steps of LDS-DMA in flight (counted vmcnt: a
 // step is 4 instructions per wave); one barrier per step.  At the end group 1 hands its partial tile to group 0 through the (drained) ring:
 // out = (sum over chunk-0 terms) + (sum over chunk-1 terms), a fixed order.
-// KB: operands stored K-step-blocked (HIREST_GEMM_KBLOCKED: element (row, k) at (k / 64) * ld + row * 64 + k % 64) — the eight 128-B
-// row segments one LDS-DMA instruction fetches are then 1 KiB of consecutive bytes instead of eight segments a row stride apart.  The
-// L2 -> LDS path of a CU delivers ~47 GB/s in the strided form and 100 - 125 in the consecutive one (tools/probes), and a
-// 128 x 128 tile needs 32 KiB per 64-deep step: strided, the tile is bound by that path (786 KB for K = 768: 17 us), not by its MFMAs.
-template <int EPI, bool KB>
+// (Round 4 also had a K-step-blocked operand layout for this kernel, HIREST_GEMM_KBLOCKED, for the training step's split-operand path; both
+// were measured slower end to end and removed in round 5: profiles/r04/train_x3_ab.txt.)
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = 4;
@@ -194,10 +192,10 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
     for (int q = 0; q < 4; ++q) {
         const int row = (w4 * 4 + q) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        if (kg == 0) { int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1; src[q] = p.A + (int64_t)gm * (KB ? BK : p.lda) + chunk * 8; }
-        else { int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1; src[q] = p.W + (int64_t)gn * (KB ? BK : p.ldw) + chunk * 8; }
+        if (kg == 0) { int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1; src[q] = p.A + (int64_t)gm * p.lda + chunk * 8; }
+        else { int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1; src[q] = p.W + (int64_t)gn * p.ldw + chunk * 8; }
     }
-    const int64_t kstep = KB ? (kg == 0 ? p.lda : p.ldw) : BK;
+    const int64_t kstep = BK;
     auto stage = [&](int slot, int kt) {
         char* dst = smem + slot * STAGE_BYTES + (kg ? BM * BK * 2 : 0);
 #pragma unroll
@@ -1538,10 +1536,10 @@ int launch256(GemmP p, hipStream_t s) {
 int g_gemm_dbg = 0;
 namespace {
 
-template <int EPI, bool KB>
+template <int EPI>
 int launch_t128x3(const GemmP& p, hipStream_t s) {
     static HirestDevCfg cfg;
-    auto kern = gemm_t128x3<EPI, KB>;
+    auto kern = gemm_t128x3<EPI>;
     if (int e = hirest_configure(kern, 4 * STAGE_BYTES, cfg)) return e;
     hipLaunchKernelGGL(kern, dim3(8 * p.ppx * p.nbn), dim3(512), 4 * STAGE_BYTES, s, p);
     return hirest_launch_status();
@@ -1608,7 +1606,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (a->flags & HIREST_GEMM_X3) {
         if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32 && epi != HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
         if (x3_small(a->M, a->N) && epi != HIREST_EPI_BIAS_GELU_SPLIT2) {
-            snprintf(out, out_len, "gemm_t128x3<%d, %s>", epi, (a->flags & HIREST_GEMM_KBLOCKED) ? "true" : "false");
+            snprintf(out, out_len, "gemm_t128x3<%d>", epi);
             return 0;
         }
         snprintf(out, out_len, g_force_kernel == 9 ? "gemm_pq256x3<%d>" : "gemm_pp256x3<%d>", epi);
@@ -1656,12 +1654,9 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     HirestProfScope prof(HIREST_PROF_GEMM, a->epilogue, a->M, a->N, a->K, s);
     if (a->flags & HIREST_GEMM_X3) {                  // split-operand products: the ping-pong kernel's X3 form, fp32 outputs only
         // fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (2 workgroups per CU)
-        const bool small = x3_small(a->M, a->N), kb = (a->flags & HIREST_GEMM_KBLOCKED) != 0;
-        if (kb && (!small || a->epilogue == HIREST_EPI_BIAS_GELU_SPLIT2)) return HIREST_E_SHAPE;   // the blocked layout exists for the small kernel only
-        if (kb && (a->lda < (int64_t)a->M * 64 || a->ldw < (int64_t)a->N * 64)) return HIREST_E_BADARG;
-        if (small && a->epilogue == HIREST_EPI_BIAS_F32) return kb ? launch_t128x3<HIREST_EPI_BIAS_F32, true>(p, s) : launch_t128x3<HIREST_EPI_BIAS_F32, false>(p, s);
-        if (small && a->epilogue == HIREST_EPI_BIAS_RESID_F32)
-            return kb ? launch_t128x3<HIREST_EPI_BIAS_RESID_F32, true>(p, s) : launch_t128x3<HIREST_EPI_BIAS_RESID_F32, false>(p, s);
+        const bool small = x3_small(a->M, a->N);
+        if (small && a->epilogue == HIREST_EPI_BIAS_F32) return launch_t128x3<HIREST_EPI_BIAS_F32>(p, s);
+        if (small && a->epilogue == HIREST_EPI_BIAS_RESID_F32) return launch_t128x3<HIREST_EPI_BIAS_RESID_F32>(p, s);
         switch (a->epilogue) {
             case HIREST_EPI_BIAS_F32:
                 return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_F32, 1, true, 1>(p, s) : launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);

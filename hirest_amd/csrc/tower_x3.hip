@@ -75,55 +75,6 @@ __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x
 }
 
 
-// Both split forms of one fp32 matrix in one pass (training GEMMs, train.py): out_n [R, 2C] = the row-wise split (as split2_kernel), out_t
-// [C, 2 Rp] = the split of x^T (row c: per 32 source rows, hi of x[32 b .. 32 b + 31][c] | their lo; rows >= R are zeros; Rp = R rounded
-// up to 32) — the operand of the backward products that contract over the ROW index (dW = dY^T X) or read W column-wise (dX = dY W).
-// One workgroup per 32 x 64 tile: coalesced 16-B loads along c, the transposed side goes through LDS.
-__global__ __launch_bounds__(256) void split2_both_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out_n, int64_t ldon,
-                                                         bf16_t* __restrict__ out_t, int64_t ldot, int R, int C, int blocked) {
-    __shared__ float tile[32][65];
-    const int tid = threadIdx.x;
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 64;
-    {   // thread -> row tid >> 3, 8 columns (tid & 7) * 8
-        const int r = tid >> 3, c = (tid & 7) * 8;
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-        if (r0 + r < R) {
-            const float* xr = x + (int64_t)(r0 + r) * ldx + c0 + c;
-            v0 = *reinterpret_cast<const f32x4*>(xr);
-            v1 = *reinterpret_cast<const f32x4*>(xr + 4);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { tile[r][c + e] = v0[e]; tile[r][c + 4 + e] = v1[e]; }
-        if (out_n && r0 + r < R) {
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (bf16_t)v0[e]; lo[e] = (bf16_t)(v0[e] - (float)hi[e]);
-                hi[4 + e] = (bf16_t)v1[e]; lo[4 + e] = (bf16_t)(v1[e] - (float)hi[4 + e]);
-            }
-            const int cc = c0 + c;
-            bf16_t* o = blocked ? out_n + (int64_t)(cc >> 5) * ldon + (int64_t)(r0 + r) * 64 + (cc & 31)
-                                : out_n + (int64_t)(r0 + r) * ldon + (cc >> 5) * 64 + (cc & 31);
-            *reinterpret_cast<bf16x8*>(o) = hi;
-            *reinterpret_cast<bf16x8*>(o + 32) = lo;
-        }
-    }
-    if (!out_t) return;
-    __syncthreads();
-    {   // thread -> column tid >> 2, 8 source rows (tid & 3) * 8: four threads write one 128-B line (64 B hi | 64 B lo)
-        const int c = tid >> 2, rq = (tid & 3) * 8;
-        bf16x8 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = tile[rq + e][c];
-            hi[e] = (bf16_t)v; lo[e] = (bf16_t)(v - (float)hi[e]);
-        }
-        bf16_t* o = blocked ? out_t + (int64_t)blockIdx.y * ldot + (int64_t)(c0 + c) * 64 + rq
-                            : out_t + (int64_t)(c0 + c) * ldot + (int64_t)blockIdx.y * 64 + rq;
-        *reinterpret_cast<bf16x8*>(o) = hi;
-        *reinterpret_cast<bf16x8*>(o + 32) = lo;
-    }
-}
 
 // LayerNorm (layernorm_rows' arithmetic: ln_wave_stats / ln_apply) with the split as its store: one wave per row
 template <int NV>
@@ -184,17 +135,6 @@ extern "C" int hirest_split2_bf16(const float* x, int64_t ldx, hirest_bf16* out,
     return hirest_launch_status();
 }
 
-extern "C" int hirest_split2_both_bf16(const float* x, int64_t ldx, hirest_bf16* out_n, int64_t ldon, hirest_bf16* out_t, int64_t ldot,
-                                       int32_t R, int32_t C, int32_t blocked, void* stream) {
-    if (!x || (!out_n && !out_t) || R <= 0 || C <= 0 || blocked < 0 || blocked > 1) return HIREST_E_BADARG;
-    const int Rp = (R + 31) / 32 * 32;
-    if (C % 64 != 0 || ldx % 4 != 0) return HIREST_E_SHAPE;
-    if (out_n && (ldon % 8 != 0 || ldon < (blocked ? 64 * (int64_t)R : 2 * (int64_t)C))) return HIREST_E_SHAPE;
-    if (out_t && (ldot % 8 != 0 || ldot < (blocked ? 64 * (int64_t)C : 2 * (int64_t)Rp))) return HIREST_E_SHAPE;
-    hipLaunchKernelGGL(split2_both_kernel, dim3(C / 64, Rp / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
-                       reinterpret_cast<bf16_t*>(out_n), ldon, reinterpret_cast<bf16_t*>(out_t), ldot, R, C, blocked);
-    return hirest_launch_status();
-}
 
 extern "C" int hirest_layernorm_split2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, hirest_bf16* out,
                                        int64_t ldo, int32_t rows, int32_t D, void* stream) {

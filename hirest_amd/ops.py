@@ -39,7 +39,6 @@ def on_tensor_device(fn):
     @functools.wraps(fn)
     def wrapped(*args, **kw):
         for a in list(args) + list(kw.values()):
-            a = getattr(a, "data", a) if isinstance(a, BlockedSplit) else a      # (a blocked split operand: its storage tensor)
             if isinstance(a, torch.Tensor) and a.is_cuda:
                 if a.device.index != torch.cuda.current_device():
                     with torch.cuda.device(a.device):
@@ -189,40 +188,6 @@ def split2(x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
     return out
 
 
-class BlockedSplit:
-    """A split operand in the K-step-blocked layout (HIREST_GEMM_KBLOCKED): `data` [K2 / 64, rows, 64] bf16, logical shape [rows, K2]."""
-    __slots__ = ("data", "rows", "k2")
-
-    def __init__(self, data, rows, k2):
-        self.data, self.rows, self.k2 = data, rows, k2
-
-
-@on_tensor_device
-def split2_both(x: torch.Tensor, normal: bool = True, transposed: bool = True, stream=None, blocked: bool = False):
-    """(split of x [R, 2C] or None, split of x^T [C, 2 Rp] or None) in one pass (hirest_split2_both_bf16; Rp = R rounded up to 32, zero
-    filled).  C % 64 == 0; x may be a row-strided view.  blocked: both as BlockedSplit (the layout gemm_x3 reads fastest for small
-    problems)."""
-    lib = _lib.load()
-    R, Cc = x.shape
-    Rp = (R + 31) // 32 * 32
-    if x.dtype != torch.float32 or x.stride(1) != 1:
-        raise ValueError("split2_both: fp32 rows with unit column stride")
-    if blocked:
-        on = torch.empty((Cc // 32, R, 64), dtype=torch.bfloat16, device=x.device) if normal else None
-        ot = torch.empty((Rp // 32, Cc, 64), dtype=torch.bfloat16, device=x.device) if transposed else None
-        ldn, ldt = R * 64, Cc * 64
-    else:
-        on = torch.empty((R, 2 * Cc), dtype=torch.bfloat16, device=x.device) if normal else None
-        ot = torch.empty((Cc, 2 * Rp), dtype=torch.bfloat16, device=x.device) if transposed else None
-        ldn, ldt = 2 * Cc, 2 * Rp
-    _lib.check(lib.hirest_split2_both_bf16(x.data_ptr(), x.stride(0), on.data_ptr() if normal else None, ldn,
-                                           ot.data_ptr() if transposed else None, ldt, R, Cc, int(blocked),
-                                           stream_ptr() if stream is None else stream), "hirest_split2_both_bf16")
-    if blocked:
-        return (BlockedSplit(on, R, 2 * Cc) if normal else None), (BlockedSplit(ot, Cc, 2 * Rp) if transposed else None)
-    return on, ot
-
-
 @on_tensor_device
 def gemm_x3(a2: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = None, resid_out: Optional[torch.Tensor] = None,
             gelu_split: bool = False, stream=None) -> torch.Tensor:
@@ -230,11 +195,8 @@ def gemm_x3(a2: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = N
     the product is added into it (x += ...); with `gelu_split` the result is nn.GELU()(A W^T + bias) as a split operand [M, 2N] bf16
     (HIREST_EPI_BIAS_GELU_SPLIT2: the next layer's A operand, no fp32 round trip)."""
     lib = _lib.load()
-    blocked = isinstance(a2, BlockedSplit)
-    if blocked != isinstance(w2, BlockedSplit) or (blocked and (gelu_split or a2.k2 != w2.k2)):
-        raise ValueError("gemm_x3: both operands blocked (same depth, fp32 output) or neither")
-    M, K2 = (a2.rows, a2.k2) if blocked else a2.shape
-    N = w2.rows if blocked else w2.shape[0]
+    M, K2 = a2.shape
+    N = w2.shape[0]
     if gelu_split:
         out = torch.empty((M, 2 * N), dtype=torch.bfloat16, device=a2.device)
         args = _lib.GemmArgs.make(_dev(a2, torch.bfloat16, "gemm_x3.a"), K2, _dev(w2, torch.bfloat16, "gemm_x3.w"), K2,
@@ -242,17 +204,10 @@ def gemm_x3(a2: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor] = N
                                   None, None, _lib.GEMM_X3)
         _lib.check(lib.hirest_gemm_bf16(C.byref(args), stream_ptr()), "hirest_gemm_bf16 (x3, gelu + split)")
         return out
-    out = resid_out if resid_out is not None else torch.empty((M, N), dtype=torch.float32, device=a2.data.device if blocked else a2.device)
+    out = resid_out if resid_out is not None else torch.empty((M, N), dtype=torch.float32, device=a2.device)
     epi = _lib.EPI_BIAS_RESID_F32 if resid_out is not None else _lib.EPI_BIAS_F32
-    if blocked:
-        if a2.data.device != w2.data.device:
-            raise RuntimeError("gemm_x3: the blocked operands live on different devices")
-        args = _lib.GemmArgs.make(_dev(a2.data, torch.bfloat16, "gemm_x3.a (blocked)"), a2.rows * 64, _dev(w2.data, torch.bfloat16, "gemm_x3.w (blocked)"),
-                                  w2.rows * 64, _opt(bias, torch.float32, "gemm_x3.bias"),
-                                  out.data_ptr(), N, M, N, K2, epi, None, 0, None, None, _lib.GEMM_X3 | _lib.GEMM_KBLOCKED)
-    else:
-        args = _lib.GemmArgs.make(_dev(a2, torch.bfloat16, "gemm_x3.a"), K2, _dev(w2, torch.bfloat16, "gemm_x3.w"), K2,
-                                  _opt(bias, torch.float32, "gemm_x3.bias"), out.data_ptr(), N, M, N, K2, epi, None, 0, None, None, _lib.GEMM_X3)
+    args = _lib.GemmArgs.make(_dev(a2, torch.bfloat16, "gemm_x3.a"), K2, _dev(w2, torch.bfloat16, "gemm_x3.w"), K2,
+                              _opt(bias, torch.float32, "gemm_x3.bias"), out.data_ptr(), N, M, N, K2, epi, None, 0, None, None, _lib.GEMM_X3)
     _lib.check(lib.hirest_gemm_bf16(C.byref(args), stream_ptr() if stream is None else stream), "hirest_gemm_bf16 (x3)")
     return out
 

@@ -43,13 +43,8 @@ def _chk(code, what):
     _lib.check(code, what)
 
 
-# Round 4, opt-in (HIREST_TRAIN_GEMM=bf16x3 or train.GEMM_PRECISION): the Linear-layer products of a step (forward, dX, dW) as
-# split-operand GEMMs — both operands split into bf16 hi + lo, three MFMAs per product term, fp32 accumulation (ops.gemm_x3 on the
-# 128 x 128 small-problem kernel gemm_t128x3, operands in the K-step-blocked layout hirest_split2_both_bf16 writes; relative error ~4e-6
-# against the exact-fp32 MFMA products, gradients inside the same 1e-3 bar: tests/test_gpu_train.py).  MEASURED SLOWER at B = 5, T = 300:
-# 3.3 vs 2.8 ms per step — a GEMM of this size is 24 - 70 us in the split form against 35 - 83 us in fp32 (19 of 32 us are launch, ring
-# fill and barriers: DESIGN 4.5a), and the ~50 extra split launches cost more than that saves.  The default stays the exact fp32 products.
-GEMM_PRECISION = os.environ.get("HIREST_TRAIN_GEMM", "fp32")
+# (Round 4 built the step's Linear-layer products as split-operand bf16x3 GEMMs as well — 3.3 vs 2.8 ms per step: slower, the ~50 extra split
+# launches cost more than the faster products return — and round 5 removed that opt-in path again: profiles/r04/train_x3_ab.txt)
 SIDE_STREAM_DW = True      # weight-gradient GEMMs of a backward on a second stream (_K.side_open)
 _SIDE = {}
 
@@ -57,42 +52,11 @@ _SIDE = {}
 class _K:
     """Thin tensor-level wrappers over the training entry points (device fp32 contiguous in, fresh tensors out)."""
 
-    _memo = None     # split operands of the current backward: (data_ptr, shape, stride) -> [normal, transposed, the source tensor]
-
-    @staticmethod
-    def _x3(M=1, N=1):
-        """The split-operand path applies (and the problem is one for the small-problem kernel, whose blocked operand layout the split
-        kernels write: fewer than 256 tiles of 256 x 256)."""
-        return GEMM_PRECISION == "bf16x3" and ((M + 255) // 256) * ((N + 255) // 256) < 256
-
-    @staticmethod
-    def _split(x, normal, transposed, stream=None):
-        """Split forms of x, memoised for the duration of a backward (dY is the operand of both dX and dW)."""
-        key = (x.data_ptr(), tuple(x.shape), x.stride(0))
-        ent = _K._memo.get(key) if _K._memo is not None else None
-        if ent is None:
-            ent = [None, None, x]          # x itself is held: a freed dY's address is readily reused by the next [R, 768] gradient of the
-            if _K._memo is not None:       # same backward, and the key (pointer, shape, stride) would then return the stale split
-                _K._memo[key] = ent
-        need_n, need_t = normal and ent[0] is None, transposed and ent[1] is None
-        if need_n or need_t:
-            on, ot = ops.split2_both(x, need_n, need_t, stream=stream, blocked=True)
-            if need_n:
-                ent[0] = on
-            if need_t:
-                ent[1] = ot
-        return ent[0] if normal else None, ent[1] if transposed else None
-
     @staticmethod
     def gemm(a, w, bias=None, resid=None, periodic=None, period=0, act=0):
         lib = _lib.load()
         M, K = a.shape
         N = w.shape[0]
-        if (_K._x3(M, N) and resid is None and periodic is None and act == 0 and K % 64 == 0 and N % 4 == 0 and a.stride(1) == 1 and w.stride(1) == 1
-                and a.stride(0) % 4 == 0 and w.stride(0) % 4 == 0):
-            a2, _ = ops.split2_both(a, True, False, blocked=True)
-            w2, _ = ops.split2_both(w, True, False, blocked=True)
-            return ops.gemm_x3(a2, w2, bias)
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         ws, wsb = ops.f32_gemm_workspace(a.device, lib.hirest_gemm_f32_workspace_bytes(M, N, K))
         _chk(lib.hirest_gemm_f32_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
@@ -137,7 +101,6 @@ class _K:
 
     @staticmethod
     def side_open(device):
-        _K._memo = {}
         if not SIDE_STREAM_DW:
             return
         st = _SIDE.get(device.index)
@@ -149,7 +112,6 @@ class _K:
     @staticmethod
     def side_join():
         st, _K._side = _K._side, None
-        _K._memo = None
         if st is not None and st["used"]:
             torch.cuda.current_stream().wait_stream(st["stream"])
             st["keep"].clear()
@@ -161,11 +123,6 @@ class _K:
         B[n][k] = W[k][n]); STRIDED_GEMM = False: through a zero-padded transposed copy and hirest_gemm_f32 (round 2)."""
         R, O = dy.shape
         I = w.shape[1]
-        if (_K._x3(R, I) and O % 64 == 0 and I % 64 == 0 and dy.stride(1) == 1 and w.stride(1) == 1 and dy.stride(0) % 4 == 0
-                and w.stride(0) % 4 == 0):
-            dy2, _ = _K._split(dy, True, _K._memo is not None)       # (inside a backward: the transposed form for dW in the same pass)
-            _, wt2 = ops.split2_both(w, False, True, blocked=True)    # [I, 2 O]: row i = column i of W
-            return ops.gemm_x3(dy2, wt2, None, resid_out=resid.clone() if resid is not None else None)
         if STRIDED_GEMM and 2.0 * R * I * O <= STRIDED_MAX_FLOP:
             dx = _K.strided(dy, dy.stride(0), 1, w, 1, w.stride(0), R, I, O)
         elif w.shape[0] % 16 != 0:
@@ -184,24 +141,6 @@ class _K:
             return _K.strided(dy, 1, dy.stride(0), x, 1, x.stride(0), dy.shape[1], x.shape[1], dy.shape[0])
         R, O = dy.shape
         I = x.shape[1]
-        if (_K._x3(O, I) and O % 64 == 0 and I % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 4 == 0
-                and x.stride(0) % 4 == 0):
-            st = _K._side if side else None
-            _, dyt2 = _K._split(dy, _K._memo is not None, True)      # main stream: dX reads the other form
-            if st is None:
-                _, xt2 = ops.split2_both(x, False, True, blocked=True)
-                return ops.gemm_x3(dyt2, xt2, None)
-            if st["used"] == len(st["events"]):
-                st["events"].append(torch.cuda.Event())
-            ev = st["events"][st["used"]]
-            st["used"] += 1
-            ev.record()
-            st["stream"].wait_event(ev)
-            sp = st["stream"].cuda_stream
-            _, xt2 = ops.split2_both(x, False, True, stream=sp, blocked=True)
-            dw = ops.gemm_x3(dyt2, xt2, None, stream=sp)
-            st["keep"].append((dy, x, dyt2, xt2))
-            return dw
         if (LAYOUT_GEMM and O % 4 == 0 and I % 4 == 0 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.stride(1) == 1
                 and x.stride(1) == 1):
             st = _K._side if side else None

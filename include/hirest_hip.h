@@ -107,10 +107,6 @@ enum { HIREST_GEMM_REVERSE = 1,
                                 * + W_hi A_hi per 32 k in fp32 (products carry ~16 mantissa bits at 3 bf16 MFMAs each).  Epilogues
                                 * HIREST_EPI_BIAS_F32 / HIREST_EPI_BIAS_RESID_F32 (+ GELU_SPLIT2); the persistent ping-pong kernel, or — for
                                 * problems of fewer than 256 tiles of 256 x 256 — an 8-wave 128 x 128 kernel (gemm_t128x3). */
-       , HIREST_GEMM_KBLOCKED = 4  /* with HIREST_GEMM_X3, small problems only: A and W are stored K-step-blocked — element (row, k) at
-                                * (k / 64) * ld + row * 64 + k % 64, lda / ldw = the slab stride in elements (>= rows * 64): what
-                                * hirest_split2_both_bf16 writes with blocked = 1.  One LDS-DMA instruction then reads 1 KiB of consecutive
-                                * bytes (the joint model's training GEMMs, hirest_amd/train.py). */
      };
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
@@ -410,14 +406,6 @@ typedef struct hirest_vision_tower_x3 {
 } hirest_vision_tower_x3;
 
 int hirest_split2_bf16(const float* x, int64_t ldx, hirest_bf16* out, int64_t ldo, int64_t rows, int32_t D, int32_t act, void* stream);
-/* Both split forms of x [R, C] fp32 in one pass (either output may be null): out_n [R, 2C] as hirest_split2_bf16; out_t [C, 2 Rp], Rp = R
- * rounded up to 32, = the split of x^T (row c, block b: hi of x[32 b .. 32 b + 31][c] | their lo; source rows >= R give zeros) — the
- * operand form of the training products that contract over the row index (dW = dY^T X) or read a weight column-wise (dX = dY W;
- * hirest_amd/train.py, modeling.py:226-270 through autograd).  C % 64 == 0. */
-int hirest_split2_both_bf16(const float* x, int64_t ldx, hirest_bf16* out_n, int64_t ldon, hirest_bf16* out_t, int64_t ldot,
-                            int32_t R, int32_t C, int32_t blocked, void* stream);
-/* blocked = 1: both outputs in the K-step-blocked layout of HIREST_GEMM_KBLOCKED instead ([C / 32 slabs][R rows][64] for out_n with
- * ldon = slab stride >= R * 64 elements; [Rp / 32 slabs][C rows][64] for out_t with ldot >= C * 64). */
 int hirest_layernorm_split2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, hirest_bf16* out, int64_t ldo,
                             int32_t rows, int32_t D, void* stream);
 /* softmax(q k^T * scale) v for fp32 q / k / v rows (row strides ldq / ldkv, head h at column h * dh; out [B * Tq, H * dh]) with both products

@@ -43,18 +43,8 @@ def _setup(golden_dir, case, dev):
     return model, batch, seg_batch, cap_batch, np.load(os.path.join(golden_dir, f"train_{case}.npz"))
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
-def gemm_precision(request):
-    """train.GEMM_PRECISION: the exact-fp32 products (default) and the opt-in split-operand products, against the same goldens and bars."""
-    from hirest_amd import train
-    old = train.GEMM_PRECISION
-    train.GEMM_PRECISION = request.param
-    yield request.param
-    train.GEMM_PRECISION = old
-
-
 @pytest.mark.parametrize("case", ["a", "b"])
-def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case, gemm_precision):
+def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
     model, batch, seg_batch, cap_batch, g = _setup(golden_dir, case, dev)
     model.eval()                                   # dropout off: the arithmetic the goldens pin
     worst = 0.0
@@ -276,9 +266,8 @@ def test_grouped_column_sums_equal_the_single_calls():
         assert torch.equal(w, o), i
 
 
-def test_weight_gradients_on_the_side_stream_equal_the_single_stream_backward(dev, golden_dir, gemm_precision):
-    """(With the split-operand products too: their per-backward memo of split dY forms must hold the source tensor, or a recycled
-    address returns a stale split in the single-stream backward — ADVICE r4.)  The dW GEMMs of a backward run on a second stream behind "dY is ready" events (train.SIDE_STREAM_DW): same kernels on the same
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_backward(dev, golden_dir):
+    """The dW GEMMs of a backward run on a second stream behind "dY is ready" events (train.SIDE_STREAM_DW): same kernels on the same
     operands, so every gradient must equal the single-stream backward bit for bit — in train mode (same seed, same dropout masks),
     for all three tasks, repeatedly (a missing dependency would show as a race)."""
     from hirest_amd import train

@@ -229,31 +229,10 @@ def test_x3_tower_attention_ab(dev, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,C", [(1500, 768), (37, 64), (240, 3072)])
-def test_split2_both_forms_and_layouts(dev, R, C):
-    """hirest_split2_both_bf16: the row-wise split == hirest_split2_bf16, the transposed one == the split of the zero-padded transpose,
-    and the K-step-blocked layout holds the same values slab by slab."""
-    from hirest_amd import ops
-    g = torch.Generator(device="cpu"); g.manual_seed(R + C)
-    x = torch.randn(R, C, generator=g).to(dev)
-    on, ot = ops.split2_both(x)
-    Rp = (R + 31) // 32 * 32
-    xt = torch.zeros(C, Rp, device=dev); xt[:, :R] = x.t()
-    ref_n, ref_t = ops.split2(x), ops.split2(xt.contiguous())
-    assert torch.equal(on, ref_n) and torch.equal(ot, ref_t)
-    bn, bt = ops.split2_both(x, blocked=True)
-    assert (bn.rows, bn.k2, bt.rows, bt.k2) == (R, 2 * C, C, 2 * Rp)
-    assert torch.equal(bn.data.permute(1, 0, 2).reshape(R, 2 * C), ref_n)
-    assert torch.equal(bt.data.permute(1, 0, 2).reshape(C, 2 * Rp), ref_t)
-    v = x[:, 64:128] if C >= 128 else x                    # a row-strided view
-    assert torch.equal(ops.split2_both(v, True, False)[0], ops.split2(v.contiguous()))
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(1500, 768, 768), (300, 2304, 768), (1500, 768, 3072), (131, 132, 64), (240, 30528, 768)])
 def test_gemm_x3_small_problem_kernel(dev, M, N, K):
     """Problems of fewer than 256 tiles of 256 x 256 take gemm_t128x3 (8 waves, the two 16-deep chunks of a step on two wave groups):
-    against fp64, in the row-major and the K-step-blocked operand layout (same bits), bias and accumulate-into forms."""
+    against fp64, bias and accumulate-into forms."""
     from hirest_amd import ops
     g = torch.Generator(device="cpu"); g.manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).to(dev)
@@ -262,9 +241,7 @@ def test_gemm_x3_small_problem_kernel(dev, M, N, K):
     ref = a.double() @ w.double().t() + b.double()
     out = ops.gemm_x3(ops.split2(a), ops.split2(w), b)
     assert (out.double() - ref).abs().max().item() <= 2 ** -16 * ref.abs().max().item() * 4
-    a2, _ = ops.split2_both(a, True, False, blocked=True)
-    w2, _ = ops.split2_both(w, True, False, blocked=True)
-    assert torch.equal(ops.gemm_x3(a2, w2, b), out)
+    a2, w2 = ops.split2(a), ops.split2(w)
     r = torch.randn(M, N, generator=g).to(dev)
     r0 = r.clone()
     ops.gemm_x3(a2, w2, None, resid_out=r)
