@@ -807,7 +807,7 @@ class MomentModel(nn.Module):
         return merged
 
     @torch.no_grad()
-    def caption_batches(self, batches, num_beams=5, streams=2, return_ids=False, graphs=True, merge=True, rows_in_flight=None):
+    def caption_batches(self, batches, num_beams=5, streams=1, return_ids=False, graphs=True, merge=True, rows_in_flight=None):
         """Step captioning over a LIST of loader batches (the evaluation loop of run.py:328-336 / modeling.py:556-632 calls
         test_step once per batch).
 
@@ -815,7 +815,8 @@ class MomentModel(nn.Module):
         `rows_in_flight` rows (default CAPTION_ROWS_IN_FLIGHT = 160 = the reference's default --eval_batch_size 32 at beam 5,
         args.py:27) — a word's 162 MB of decoder weights are then streamed once for all of them instead of once per batch; each
         sample keeps its own done flag and the search ends when all have emitted [SEP].  The merged groups (if more than one) then go
-        through the machinery below, up to `streams` in flight.  merge=False: every loader batch is its own search (round 4).
+        through the machinery below, up to `streams` in flight (default 1: a search of ~150 rows is matrix-pipe time, a second one beside
+        it gains nothing — 1697 vs 1616 captions/s for twelve batches of 5 at beam 5).  merge=False: every loader batch is its own search (round 4).
 
         Up to `streams` searches in flight, each on its own HIP stream and host thread.
 

@@ -173,9 +173,9 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         out[f"step_captioning_beam{beams}"] = ent
         # the same batch as an evaluation loop sees it (run.py:328-336: one test_step per loader batch): MomentModel.caption_batches
         # captions consecutive loader batches with ONE beam search over the union of their beam rows (up to 160 rows: 12 batches of 5
-        # videos = two searches of 30 videos, both in flight on their own streams), so a word's decoder + LM-head weights are
+        # videos = two searches of 30 videos at beam 5, one after the other; beam 3: 50 + 10), so a word's decoder + LM-head weights are
         # streamed once per SEARCH, not once per batch.  Same token ids per batch (tests/test_gpu_joint.py).
-        nb, ns = 12, 2
+        nb, ns = 12, 1
         many = [bcp] * nb
         model.caption_batches(many, num_beams=beams, streams=ns)                           # warm-up: streams, allocator pools, graphs
         sync(); t0 = time.perf_counter()
@@ -190,7 +190,7 @@ def measure(dev=None, cpu=True, log=lambda m: None):
             "value": B / dtp, "unit": "captions/s", "ms_per_batch": dtp * 1e3, "beam": beams, "max_words": 48, "batches": nb,
             "merged_searches": searches, "beam_rows_per_search": rows, "searches_in_flight": ns,
             "how": "MomentModel.caption_batches (default merge=True): loader batches of 5 videos captioned by one beam search per 160 beam rows; "
-                   "the searches replay their word steps from hipGraphs on their own streams",
+                   "one search after the other (a second search in flight gains nothing at ~150 rows)",
             "token_ids_equal_real_reference": f"{sum(int(list(a) == b) for r_ in res for a, b in zip(r_['token_ids'], want))} of {nb * len(want)} captions",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_word_step": bytes_per_word,
