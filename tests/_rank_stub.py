@@ -35,10 +35,11 @@ def main():
         allv = retrieval.gather_rows(pooled, V_local * world)
         return allv.sum().item()
 
-    elapsed, last = launch.timed_steps(step, args.warmup, args.steps, lambda: None)
+    info = {}
+    elapsed, last = launch.timed_steps(step, args.warmup, args.steps, lambda: None, info=info)
     if rank == 0:
         print(json.dumps({"n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
-                          "warmup": args.warmup, "step_calls": len(calls), "elapsed": elapsed, "gathered_sum": last,
+                          "warmup": args.warmup, "step_calls": len(calls), "elapsed": elapsed, "per_rank_s": info["per_rank_s"], "gathered_sum": last,
                           "expected_sum": float(V_local * E * sum(range(1, world + 1)))}), flush=True)
     if world > 1:
         dist.barrier()

@@ -33,11 +33,13 @@ def test_self_launch_world2():
     assert d["step_calls"] == 5                       # W untimed + exactly K timed
     assert d["gathered_sum"] == d["expected_sum"]     # both ranks' rows arrived, in the preallocated gather buffer
     assert d["elapsed"] > 0
+    # every rank's own time up to its own sync, before the closing barrier: one entry per rank, none longer than the reported MAX + barrier
+    assert len(d["per_rank_s"]) == 2 and all(0 < t <= d["elapsed"] * 1.001 for t in d["per_rank_s"])
 
 
 def test_single_rank_needs_no_launcher():
     d = _json_line(_run(["--gpus", "1"]).stdout)
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["gathered_sum"] == d["expected_sum"]
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["gathered_sum"] == d["expected_sum"] and len(d["per_rank_s"]) == 1
 
 
 def test_fewer_devices_than_ranks_fails_loudly():
