@@ -12,7 +12,10 @@ and stores inputs-by-seed + reference outputs as small ``.npz``/``.json`` fixtur
 Nothing from the reference is copied: the fixtures hold only numbers.  The GPU box never
 sees /root/reference; tests there compare against these files.
 
-    python tests/golden/make_golden.py [--only NAME ...]
+    python tests/golden/make_golden.py [--only NAME ...] [--cases CASE ...]
+
+--cases (jobs "joint" and "caption"): generate only the named cases and merge them into the job's json, leaving the committed
+fixtures of the other cases byte for byte as they are (round 5 added c300 / d300 and d3 / d5 this way).
 """
 import argparse
 import json
