@@ -67,6 +67,8 @@ def test_bench_line_contract():
         if key != "step_captioning_beam3":
             assert e["cpu_baseline"]["kind"] == "port" and e["cpu_baseline"]["value"] > 0 and e["cpu_baseline"]["cores"] >= 1, key
     assert sec["moment_retrieval"]["indices_equal_cpu_oracle"] and sec["moment_segmentation"]["boundaries_equal_cpu_oracle"]
+    # the timed B = 5, T = 300 batch is the real-reference golden joint_c300: exact indices / boundary lists of the REAL MomentModel
+    assert sec["moment_retrieval"]["indices_equal_real_reference"] and sec["moment_segmentation"]["boundaries_equal_real_reference"]
     # the reference's default --eval_batch_size 32 (args.py:27): indices and boundary lists of the REAL MomentModel (joint_predictions.json d300)
     assert sec["moment_retrieval_b32"]["indices_equal_real_reference"] and sec["moment_segmentation_b32"]["boundaries_equal_real_reference"]
     assert sec["moment_retrieval_b32"]["value"] > sec["moment_retrieval"]["value"]

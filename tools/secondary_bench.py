@@ -70,7 +70,10 @@ def measure(dev=None, cpu=True, log=lambda m: None):
     B, T = 5, 300
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
-    vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"jb.{T}", B, T, 43)
+    # the inputs of the real-reference golden joint_c300 (make_golden.py gen_joint: the REAL MomentModel.test_step at B = 5, T = 300), so the timed
+    # batches' indices and boundary lists are compared with the reference's, not only with the CPU oracle's
+    vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs("joint.c300", B, T, 41)
+    jgold5 = json.load(open(os.path.join(ROOT, "tests", "golden", "joint_predictions.json")))["c300"]
     g = lambda t: t.to(dev)
     common = {"vis_feats": g(vis), "vis_mask": g(vis_mask), "asr_feats": g(asr), "text_feat": g(text)}
     out = {"operating_point": f"B={B} videos, T={T} frames, fp32 (joint model), synthetic weights / features; CPU = oracle/ref_cpu.py, "
@@ -92,6 +95,7 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         t0 = time.perf_counter(); p_cpu, _, _ = O.moment_retrieval(sd, vis, text, asr, vis_mask, moment_mask); tc = time.perf_counter() - t0
         ent["cpu_baseline"] = {"value": B / tc, "unit": "videos/s", "cores": threads, "kind": "port", "sample": "one batch"}
         ent["indices_equal_cpu_oracle"] = bool(p_cpu == pred)
+    ent["indices_equal_real_reference"] = bool(pred == jgold5["pred_moment_retrieval"])
     out["moment_retrieval"] = ent
 
     # ---- moment segmentation, 20 iterations (modeling.py:353-474)
@@ -106,6 +110,7 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         t0 = time.perf_counter(); s_cpu, _ = O.moment_segmentation(sd, vis, text, asr, vis_mask, bounds); tc = time.perf_counter() - t0
         ent["cpu_baseline"] = {"value": B / tc, "unit": "videos/s", "cores": threads, "kind": "port", "sample": "one batch"}
         ent["boundaries_equal_cpu_oracle"] = bool(s_cpu == pred)
+    ent["boundaries_equal_real_reference"] = bool(pred == jgold5["pred_segmentation"])
     out["moment_segmentation"] = ent
 
     # ---- the same two tasks at the reference's DEFAULT evaluation batch (args.py:27 --eval_batch_size 32) on the inputs of the real-reference
