@@ -18,7 +18,7 @@ __device__ __forceinline__ f32x4 lds_read16(const char* p) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p));
     return v;
 }
-__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, float* out, long* t, int iters, int readers, int dma, int mfma_sibling) {
+__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, float* out, long* t, int iters, int readers, int dma, int mfma_sibling, int one_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, float
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ((it * 64 + ph * 32 + wave * pieces + q) & 63) * 1024),
                                                          (__attribute__((address_space(3))) void*)(smem + ((it + 1) & 1) * SLOT + ((wave * pieces + q + ph * 32) & 63) * 1024), 16, 0, 0);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!one_batch || ph == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one_batch: all 24 reads of the step behind ONE wait
 #pragma unroll
                 for (int i = 0; i < 12; ++i) acc += v[i];
             }
@@ -82,13 +82,15 @@ int main() {
     hipMalloc(&out, (size_t)cus * 512 * 4); hipMalloc(&t, 32);
     hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT);
     const int iters = 4000;
-    struct V { const char* name; int readers, dma, sib; } vs[] = {
+    struct V { const char* name; int readers, dma, sib, one; } vs[] = {
         {"4 reading waves (one per SIMD)", 4, 0, 0}, {"8 reading waves (two per SIMD)", 8, 0, 0},
         {"4 reading waves + their LDS-DMA refill", 4, 1, 0}, {"8 reading waves + their LDS-DMA refill", 8, 1, 0},
-        {"4 reading waves, MFMA in the sibling waves", 8, 0, 1}, {"4 reading waves + LDS-DMA, MFMA in the sibling waves", 8, 1, 1}};
+        {"4 reading waves, MFMA in the sibling waves", 8, 0, 1}, {"4 reading waves + LDS-DMA, MFMA in the sibling waves", 8, 1, 1},
+        {"4 reading waves, 24 reads per wait", 4, 0, 0, 1}, {"4 reading waves, 24 reads per wait, MFMA siblings", 8, 0, 1, 1},
+        {"4 reading waves + LDS-DMA, 24 reads per wait, MFMA siblings", 8, 1, 1, 1}};
     printf("# one workgroup per CU on %d CUs, %d steps; per step a reading wave issues 24 ds_read_b128 (24 KB) in two phases\n", cus, iters);
     for (const V& v : vs) {
-        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe, dim3(cus), dim3(512), 2 * SLOT, 0, src, out, t, iters, v.readers, v.dma, v.sib);
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe, dim3(cus), dim3(512), 2 * SLOT, 0, src, out, t, iters, v.readers, v.dma, v.sib, v.one);
         hipDeviceSynchronize(); hipMemcpy(h, t, 32, hipMemcpyDeviceToHost);
         const int nread = v.sib ? 4 : v.readers;
         const double bytes = (double)nread * 24 * 1024 * iters, mhz = 100.0 * h[0] / h[1];
