@@ -65,7 +65,8 @@ def small_calls(model, frames):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
         out[str(n)] = {"frames_per_s": n / dt, "ms_per_call": dt * 1e3}
     return {"unit": "frames/s by frames per encode_image call", "by_frames_per_call": out,
-            "note": "tile quantisation: a 64-frame call is 65 row panels = 6.09 rounds of 256 x 256 tiles on 256 CUs for fc1, run as 7"}
+            "note": "below 256 frames the persistent attention walks one head per workgroup (one frame per workgroup left 192 of 256 CUs idle at 64 frames); "
+                    "what remains is tile quantisation: a 64-frame call is 65 row panels = 6.09 rounds of 256 x 256 tiles on 256 CUs for fc1, run as 7"}
 
 
 def matched_recall(model, dev):

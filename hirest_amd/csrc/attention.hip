@@ -726,7 +726,9 @@ int g_attn_dbg = 0;   // timing experiments only (hirest_attention_debug_mode)
 int g_attn_skew = 12; // de-phasing of the second wave of each SIMD, in units of ~64 cycles (hirest_attention_set_skew; results unchanged)
 int g_attn_stagger = 16;   // start offset between the CUs of an XCD, in units of ~64 cycles x (CU index mod 16) (hirest_attention_set_stagger)
 int g_attn_pace = 0;  // producer wave: ~64 x pace cycles between two K pieces (hirest_attention_set_pace)
-int g_attn_map = 0;   // 1 = v3 walks frames with one head per workgroup when the shape allows (hirest_attention_set_mapping); same arithmetic per (frame, head); measured: 19 % fewer bytes fetched, not faster
+int g_attn_map = 2;   // hirest_attention_set_mapping: 0 = v3 gives every workgroup one frame (its heads in order), 1 = one head per workgroup over frames when the
+                      // shape allows, 2 (default) = automatic: by head below 256 frames — a call of 64 frames is 64 per-frame workgroups on 256 CUs (0.131 ms)
+                      // against 256 per-head ones (0.045 ms); from 256 frames on the per-frame walk is as fast or faster (1024: 0.83 vs 1.00 ms).  Same bits.
 int g_attn_variant = 7;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame, 9 waves), 4 = v3 with 12 waves,
                           // 5 = v3 with the lean softmax arithmetic, 6 = 5 + producer wave, 7 (default for N > 80) = v3 + producer wave (v3's bits)
 
@@ -739,7 +741,7 @@ int launch3_impl(const bf16_t* qkv, bf16_t* out, int B, int N, int H, float scal
     auto kern = attention_kernel_v3<DH, DP, NT, FAST, DBG, NW, LEAN, PROD>;
     if (int e = hirest_configure(kern, LDS, cfg)) return e;
     // head-per-workgroup mapping when the H heads of FL = 32 / H frames fill the 32 CUs of an XCD exactly (EVA-g/14: H = 16, FL = 2)
-    const bool by_head = g_attn_map && H <= 32 && 32 % H == 0 && B >= 8 * (32 / H) * 4;
+    const bool by_head = (g_attn_map == 1 || (g_attn_map == 2 && B < 256)) && H <= 32 && 32 % H == 0 && B >= 8 * (32 / H) * 4;
     const int grid = by_head ? 256 : B;
     hipLaunchKernelGGL(kern, dim3(grid), dim3((NW + (PROD ? 1 : 0)) * 64), LDS, s, qkv, out, N, H, scale * 1.44269504088896340736f, causal, g_attn_dbg, nq,
                        g_attn_skew, B, by_head ? 1 : 0, g_attn_pace, g_attn_stagger);
@@ -798,7 +800,7 @@ extern "C" int hirest_attention_set_pace(int32_t units) {
 }
 
 extern "C" int hirest_attention_set_mapping(int32_t by_head) {
-    if (by_head < 0 || by_head > 1) return HIREST_E_BADARG;
+    if (by_head < 0 || by_head > 2) return HIREST_E_BADARG;
     g_attn_map = by_head;
     return 0;
 }

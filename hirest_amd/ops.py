@@ -96,9 +96,10 @@ def attention_select_kernel(which: int):
     _lib.check(_lib.load().hirest_attention_select_kernel(int(which)), "hirest_attention_select_kernel")
 
 
-def attention_set_mapping(by_head: bool):
-    """Persistent attention kernel: one head per workgroup over frames (True, default) or one frame per workgroup (False)."""
-    _lib.check(_lib.load().hirest_attention_set_mapping(int(bool(by_head))), "hirest_attention_set_mapping")
+def attention_set_mapping(by_head: Optional[bool] = None):
+    """Persistent attention kernel: one head per workgroup over frames (True), one frame per workgroup (False), or automatic (None, the
+    default: by head below 256 frames)."""
+    _lib.check(_lib.load().hirest_attention_set_mapping(2 if by_head is None else int(bool(by_head))), "hirest_attention_set_mapping")
 
 
 @on_tensor_device

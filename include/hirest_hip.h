@@ -165,11 +165,11 @@ int hirest_attention_bf16_rows(const hirest_bf16* qkv, hirest_bf16* out,
  * LDS-DMA (same bits as 3), 5 = 3 with the softmax on fewer VALU instructions (row sums taken from the P.V product through a
  * column of ones in V's pad; last-bit differences from 3), 6 = 5 + the producer wave.  For tests / A-B timing. */
 int hirest_attention_select_kernel(int32_t which);
-/* Persistent kernel, which (frame, head) pairs a workgroup walks: 0 = one frame per workgroup, its heads in order; 1 (default) =
- * one head per workgroup over frames b0, b0 + 16, ..., the 16 heads of two frames running on the 32 CUs of one XCD at the same time
- * so that the 128-B lines two neighbouring heads' 176-B row slices share are L2 hits instead of second fetches (used when 32 % H
- * == 0 and the batch is large enough; anything else takes mapping 0).  Per (frame, head) the arithmetic is the same: results are
- * bit-identical. */
+/* Persistent kernel, which (frame, head) pairs a workgroup walks: 0 = one frame per workgroup, its heads in order; 1 = one head per
+ * workgroup over frames b0, b0 + 16, ..., the 16 heads of two frames running on the 32 CUs of one XCD at the same time (used when
+ * 32 % H == 0 and the batch is large enough; anything else takes mapping 0); 2 (default) = automatic: mapping 1 below 256 frames, where
+ * one workgroup per frame leaves CUs idle (64 frames: 0.131 -> 0.045 ms per launch), mapping 0 from 256 frames on.  Per (frame, head)
+ * the arithmetic is the same: results are bit-identical. */
 int hirest_attention_set_mapping(int32_t by_head);
 /* Persistent kernel with a producer wave: ~64 * units cycles between two K pieces of the next step's K image (0 = one burst).
  * Results are unchanged. */

@@ -211,7 +211,7 @@ def test_attention(dev, ops, B, N, H, dh, causal, qscale, variant):
 
 
 @pytest.mark.parametrize("B,N,H,dh,q_rows", [(70, 257, 16, 88, 257), (128, 257, 16, 88, 1), (300, 100, 4, 64, 100), (97, 257, 8, 88, 33)])
-@pytest.mark.parametrize("variant", [3, 5, 6], ids=["v3", "v3lean", "v3prod"])
+@pytest.mark.parametrize("variant", [3, 5, 6, 7], ids=["v3", "v3lean", "v3leanprod", "v3prod-default"])
 def test_attention_by_head_mapping_is_bit_identical(dev, ops, B, N, H, dh, q_rows, variant):
     """hirest_attention_set_mapping: one head per workgroup over frames == one frame per workgroup over heads (default), for batch
     sizes that leave some workgroups a step short, and for the leading-rows form."""
@@ -230,7 +230,7 @@ def test_attention_by_head_mapping_is_bit_identical(dev, ops, B, N, H, dh, q_row
             outs.append(out.reshape(B, N, D)[:, :q_rows].clone())
     finally:
         ops.attention_select_kernel(ops.ATTENTION_DEFAULT_KERNEL)
-        ops.attention_set_mapping(False)
+        ops.attention_set_mapping(None)                 # back to automatic (by head below 256 frames)
     assert torch.equal(outs[0], outs[1])
     assert bool(torch.isfinite(outs[1].float()).all()) and float(outs[1].float().abs().max()) < 9.0
 
