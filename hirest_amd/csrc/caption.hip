@@ -329,7 +329,8 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
 
     // (the LM head's LayerNorm-prologue form exists as the streaming kernel for D = 768 only: hirest_gemm_f32_ln rejects N >= 8192
     //  with another depth, so such a decoder takes the separate-kernel path instead of failing the step)
-    const bool fused_ln = g_caption_mode == 0 && R <= 256 && D % 256 == 0 && D <= 1024 && (d->vocab_padded < 8192 || D == 768);
+    // (above 256 rows the LayerNorm-GEMMs exist in the row-group streaming form only, i.e. for D = 768)
+    const bool fused_ln = g_caption_mode == 0 && (R <= 256 || D == 768) && D % 256 == 0 && D <= 1024 && (d->vocab_padded < 8192 || D == 768);
     if (fused_ln) {
         // every LayerNorm (and the token + position embedding) is the prologue of the GEMM that consumes it (hirest_gemm_f32_ln):
         // a = the pre-LayerNorm sum of the previous sub-layer, x / b = the normalised rows (written by the GEMM, residual of the next)

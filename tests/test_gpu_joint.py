@@ -573,6 +573,10 @@ def test_caption_batches_with_three_in_flight_equal_sequential_calls(dev, golden
         got = model.caption_batches(batches, num_beams=beams, streams=streams, return_ids=True, graphs=graphs, rows_in_flight=rows)
         assert [g["token_ids"] for g in got] == [w["token_ids"] for w in want], (rows, streams, graphs)
         assert [g["prediction"] for g in got] == [w["prediction"] for w in want]
+    # more than 256 rows in one search (38 videos x 7 beams = 266): the LayerNorm-GEMMs in their row-group form only, same tokens
+    want7 = [model.test_step(b, num_beams=7, return_ids=True)["token_ids"] for b in batches]
+    got7 = model.caption_batches(batches, num_beams=7, return_ids=True, rows_in_flight=1000)
+    assert [g["token_ids"] for g in got7] == want7
     assert model.caption_batches(batches[:1], num_beams=beams, streams=3, return_ids=True)[0]["token_ids"] == want[0]["token_ids"]
     assert model.caption_batches([], num_beams=beams) == []
     # early stop inside the graph path: with [SEP] made the likeliest word every search ends after its first word, two chunks late at most
