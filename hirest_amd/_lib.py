@@ -191,6 +191,7 @@ _SIGNATURES = {
                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_gemm_f32_rows_ln_mode": (C.c_int, [C.c_int32]),
     "hirest_gemm_f32_ring_mode": (C.c_int, [C.c_int32]),
+    "hirest_gemm_f32_rows_preferred": (C.c_int, [C.c_int32]),
     "hirest_gemm_f32_rows_colmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_caption_beam_step": (C.c_int, [C.POINTER(CaptionDecoder), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

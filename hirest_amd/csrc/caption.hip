@@ -366,7 +366,7 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
             // a merged search (60 - 160 beam rows): by now a compute problem — LayerNorm once, then the row-group streaming product
             // with five row tiles per wave (its LayerNorm-prologue form holds three), which also leaves the tile maxima for the tail
             CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));
-            if (tile_max_out && D == 768) {
+            if (tile_max_out && D == 768 && hirest_gemm_f32_rows_preferred(R)) {
                 float* tm = reinterpret_cast<float*>(base + w.tm);
                 CK(hirest_gemm_f32_rows_colmax(b, D, d->lm_w, D, d->lm_b, logits, d->vocab_padded, tm, R, d->vocab_padded, D, stream));
                 *tile_max_out = tm;

@@ -1726,6 +1726,7 @@ inline int grid1d(int64_t total, int cap = 4096) { int64_t g = (total + 255) / 2
 
 }  // namespace
 
+extern "C" int hirest_gemm_f32_rows_preferred(int32_t M);
 static int g_f32_ring = 0;         // hirest_gemm_f32_ring_mode (A/B): 0 automatic, 1 off (the register-prefetch kernel), 2 always the ring
 extern "C" int hirest_gemm_f32_ring_mode(int32_t mode) {
     if (mode < 0 || mode > 2) return HIREST_E_BADARG;
@@ -1752,8 +1753,9 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
     // (a 3072-deep product is a chain of 192 dependent MFMAs per K quarter: one row tile per wave, i.e. twice the blocks, halves it)
     if (M > 32 && M <= 256 && K % FK == 0 && g_f32_kernel == 0 && N < 8192)
         return K >= 2048 ? launch_m16<1, 1, 4>(p, reinterpret_cast<hipStream_t>(stream)) : launch_m16<2, 1, 6>(p, reinterpret_cast<hipStream_t>(stream));
-    // a merged beam search's LM head (60 - 160 rows x 30 522 columns): A fragments in registers, W streamed once per row group
-    if (M > 32 && M <= 256 && N >= 8192 && K == 768 && !resid && !periodic && g_f32_kernel == 0)
+    // a merged beam search's LM head (60 - 160 rows x 30 522 columns): A fragments in registers, W streamed once per row group — when its row
+    // groups pad the rows less than 64-row tiles do (96, 150, 160 rows; at 60, 100, 256 the 64x64 kernel below is faster: hirest_gemm_f32_rows_preferred)
+    if (M > 32 && M <= 256 && N >= 8192 && K == 768 && !resid && !periodic && g_f32_kernel == 0 && hirest_gemm_f32_rows_preferred(M))
         return rows_stream_plain(p, nullptr, reinterpret_cast<hipStream_t>(stream));
     // other wide problems of 48 - 256 rows: the 64x64 kernel beats the split-K kernel's lane = row loads from 60 rows on (LM head: 63 vs 97 us at
     // 96 rows, 93 vs 150 at 160)
@@ -1869,6 +1871,16 @@ extern "C" int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const floa
     const int e = hirest_gemm_f32_ln(X, ldx, nullptr, nullptr, nullptr, gamma, beta, eps, nullptr, 0, W, ldw, bias, nullptr, 0, out, ldo, M, N, K, 0, stream);
     g_ln_colmax = nullptr;
     return e;
+}
+
+// 1 when the row-group streaming kernel pads M rows to fewer rows (groups of 16 x 1..5) than 64-row tiles do: measured on the LM head, it then
+// beats the 64x64 kernel (96 rows: 55 vs 62 us, 160: 80 vs 94) and loses otherwise (60: 44 vs 37, 100: 71 vs 62, 256: 129 vs 125)
+extern "C" int hirest_gemm_f32_rows_preferred(int32_t M) {
+    if (M <= 32) return 0;
+    const int tiles = (M + 15) / 16;
+    int best = 1 << 30;
+    for (int mt = 3; mt <= 5; ++mt) { const int padded = ((tiles + mt - 1) / mt) * mt; best = padded < best ? padded : best; }   // (the splits its chooser takes for wide products)
+    return best * 16 < ((M + 63) / 64) * 64 ? 1 : 0;
 }
 
 // out = A @ W^T + bias for the rows of a merged beam search (K = 768, N >= 16) through the row-group streaming kernel, which

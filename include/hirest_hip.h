@@ -488,6 +488,9 @@ int hirest_gemm_f32_ln_colmax(const float* X, int64_t ldx, const float* gamma, c
 /* A/B switch of hirest_gemm_f32_ln's row-group form (above 32 rows): 0 = one block per CU with a 12-slab ring and 1 - 3 row tiles per wave,
  * 1 / 2 = one row tile per wave, 4-slab rings, one / two blocks per CU (2 is the default).  Same bits. */
 int hirest_gemm_f32_rows_ln_mode(int32_t mode);
+/* 1 when hirest_gemm_f32 dispatches an M-row, N >= 8192, K = 768 product to that kernel (its row groups pad M less than 64-row tiles do), 0 when the
+ * 64x64 kernel takes it. */
+int hirest_gemm_f32_rows_preferred(int32_t M);
 int hirest_gemm_f32_rows_colmax(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
                                 float* colmax, int32_t M, int32_t N, int32_t K, void* stream);
 /* softmax(fl(fl(q.k*scale) + add_const)) v over packed fp32 qkv [B*T, 3*H*dh]; no key masking (the
