@@ -20,7 +20,7 @@ TOWER_NO_PRUNE = 2
 TOWER_F32_RESIDUAL = 4
 GEMM_REVERSE = 1
 GEMM_X3 = 2
-ABI_VERSION = 3   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
+ABI_VERSION = 4   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
 
 ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}
 
@@ -299,12 +299,14 @@ def load():
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m hirest_amd.build` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
-        fn.restype, fn.argtypes = res, args
+    # the version check comes first: a stale .so then fails with "rebuild", not with an AttributeError on a symbol it predates
+    lib.hirest_abi_version.restype, lib.hirest_abi_version.argtypes = C.c_int, []
     if lib.hirest_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libhirest_hip.so ABI version {lib.hirest_abi_version()} != binding {ABI_VERSION}: rebuild with "
                            "`python -m hirest_amd.build --force`")
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
     if os.environ.get("HIREST_ATTENTION_KERNEL"):      # A/B timing of the bf16 attention forms without touching the caller
         check(lib.hirest_attention_select_kernel(int(os.environ["HIREST_ATTENTION_KERNEL"])), "HIREST_ATTENTION_KERNEL")
     _lib = lib

@@ -891,7 +891,7 @@ template <int EPI, int WN, bool DBG, int RD = 1>   // RD: residual look-ahead of
 __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     // timing-experiment switches (hirest_gemm_debug_mode) exist only in the DBG instantiation: a branch inside the K loop
     // splits the scheduling region and destroys the MFMA / ds_read / LDS-DMA interleave
-    const int dbg = DBG ? p.dbg : 0;
+    const int dbg = DBG ? p.dbg : 0, stagger = DBG ? p.stagger : 0;
     constexpr int NW = 512 / WN;        // 8 or 4 waves: 2 (M) x NW/2 (N)
     constexpr int NI = WN / 16;         // 16-column MFMA tiles per wave (4 or 8); 8 16-row tiles
     constexpr int PPW = 32 / NW;        // LDS-DMA pieces per operand per wave per step
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3, nslot = gridDim.x >> 3;
     int p_lo, np;
-    xcd_panels(p, xcd, p_lo, np);
+    xcd_panels<DBG>(p, xcd, p_lo, np);
     if (np <= 0) return;
     // Work list of the XCD = units, unit j goes to CU slot j % nslot.  The ~32 tiles in flight form a patch (a panels x
     // b column tiles) whose operand lines are shared through the XCD's L2:
@@ -926,9 +926,9 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
     if (panel_major) nunit = (np >> 1) * upp + ((np & 1) ? ncf + (half_edge ? 1 : 0) : 0);
     else { const int rem = np % GROUP_M; nunit = (np / GROUP_M) * ugf + (rem ? rem * ncf + (half_edge ? (rem + 1) / 2 : 0) : 0); }
     if (slot >= nunit) return;
-    if (p.stagger) {   // timing experiment: de-synchronise the CUs so that their HBM-heavy epilogues do not coincide
-        const int who = p.stagger == 1 ? (slot & 3) : p.stagger == 2 ? (xcd & 3) : ((slot + xcd) & 7);
-        const int units = who * (p.stagger == 3 ? (p.K / Q_BK + 15) / 16 : (p.K / Q_BK + 7) / 8);
+    if (stagger) {   // timing experiment: de-synchronise the CUs so that their HBM-heavy epilogues do not coincide
+        const int who = stagger == 1 ? (slot & 3) : stagger == 2 ? (xcd & 3) : ((slot + xcd) & 7);
+        const int units = who * (stagger == 3 ? (p.K / Q_BK + 15) / 16 : (p.K / Q_BK + 7) / 8);
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
     }
     // tile `sub` of unit j -> origin; returns the number of tiles in the unit (1 or 2)
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 advance();
             }
-            epilogue_p<EPI, NI, epi_is_lnfold(EPI), 8, RD>(p, acc, stg, M0 + wr * 128, N0 + wc * WN, lane);
+            epilogue_p<EPI, NI, epi_is_lnfold(EPI), 8, RD, false, DBG>(p, acc, stg, M0 + wr * 128, N0 + wc * WN, lane);
         } else {
             for (int t = 0; t < nst; ++t, ++g) {
                 HX_WAIT_VM(0);
@@ -1139,10 +1139,13 @@ __global__ __launch_bounds__(WN == 64 ? 512 : 256) void gemm_p256(GemmP p) {
 //        (k - 1)-th: group 0's Q1 LOAD(g) follows hardware barrier 4 g - 1, group 1's Q2 LOAD(g - 1) — its wait — precedes it).
 //   WAR  reads of LOAD(p) are retired before that phase's first barrier; the refill is issued in LOAD(p + 1), which for group 0 follows
 //        hardware barrier 2 p + 1 (group 1's LOAD(p) precedes it) and for group 1 follows 2 p + 2.
-template <int EPI, int RD, bool X3, int PH2 = 0>      // PH2: 0 four phases per step, 1 two phases (issuing the LDS-DMA before the fragment reads
+// DBG: the walk / timing switches of hirest_gemm_debug_mode (team walk, A wrap, staggered start, epilogue knock-outs, old XCD split) exist
+// only in the gemm_pq256_dbg instantiations; every production kernel is compiled with them folded away.
+template <int EPI, int RD, bool X3, int PH2 = 0, bool DBG = false>      // PH2: 0 four phases per step, 1 two phases (issuing the LDS-DMA before the fragment reads
                                                       // of a LOAD instead of after them measured 0.3-0.7 % slower: not kept)
 __device__ __forceinline__ void pp256_body(const GemmP& p) {
     constexpr int NI = 4;
+    const int sched = DBG ? p.sched : 0, stagger = DBG ? p.stagger : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1152,7 +1155,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3, nslot = gridDim.x >> 3;
     int p_lo, np;
-    xcd_panels(p, xcd, p_lo, np);
+    xcd_panels<DBG>(p, xcd, p_lo, np);
     if (np <= 0) return;
     const bool panel_major = p.nbn <= 8;
     const int nunit = np * p.nbn;
@@ -1163,7 +1166,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
     // TEAM walk (p.sched bit 2 = hirest_gemm_debug_mode bit 18, A/B): the slots form nslot / nbn fixed teams of nbn CUs — team t takes
     // panels t, t + teams, ... one column tile per member, so the same nbn CUs start every panel together and stay K-aligned — and the
     // nslot % nbn slots left over each walk whole panels of the tail of the XCD's range on their own, column after column.
-    const bool team_walk = (p.sched & 4) && panel_major && p.nbn <= nslot && nunit >= nslot;
+    const bool team_walk = DBG && (sched & 4) && panel_major && p.nbn <= nslot && nunit >= nslot;
     const int teams = team_walk ? nslot / p.nbn : 0, tslots = teams * p.nbn, solo = nslot - tslots;
     const int np_solo = team_walk && solo ? (np * solo + nslot / 2) / nslot : 0, np_team = np - np_solo;
     int count;
@@ -1171,9 +1174,9 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
     else if (slot < tslots) { const int tm = slot / p.nbn; count = tm < np_team ? (np_team - tm + teams - 1) / teams : 0; }
     else { const int sl_ = slot - tslots; count = sl_ < np_solo ? ((np_solo - sl_ + solo - 1) / solo) * p.nbn : 0; }
     if (count <= 0) return;
-    if (p.stagger) {   // timing experiment: de-synchronise the CUs so that their HBM-heavy epilogues do not coincide
-        const int who = p.stagger == 1 ? (slot & 3) : p.stagger == 2 ? (xcd & 3) : ((slot + xcd) & 7);
-        const int units = who * (p.stagger == 3 ? (p.K / Q_BK + 15) / 16 : (p.K / Q_BK + 7) / 8);
+    if (stagger) {   // timing experiment: de-synchronise the CUs so that their HBM-heavy epilogues do not coincide
+        const int who = stagger == 1 ? (slot & 3) : stagger == 2 ? (xcd & 3) : ((slot + xcd) & 7);
+        const int units = who * (stagger == 3 ? (p.K / Q_BK + 15) / 16 : (p.K / Q_BK + 7) / 8);
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
     }
     auto team_origin = [&](int i, int& M0, int& N0) {        // i-th unit of this slot under the team walk
@@ -1228,7 +1231,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
             }
         // TIMING EXPERIMENT (p.sched bit 3 = hirest_gemm_debug_mode bit 19; results are wrong): the A operand of every tile wraps into the
         // XCD's first four panels (2.9 MB: L2-resident after the first touch) — what a perfect L2 hit rate on A would be worth
-        const int Ma = (p.sched & 8) ? (p_lo + ((M0 / T_BM - p_lo) & 3)) * T_BM : M0;
+        const int Ma = (DBG && (sched & 8)) ? (p_lo + ((M0 / T_BM - p_lo) & 3)) * T_BM : M0;
         a_base = reinterpret_cast<const char*>(p.A + (int64_t)Ma * p.lda);
         w_base = reinterpret_cast<const char*>(p.W + (int64_t)N0 * p.ldw);
     };
@@ -1366,7 +1369,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
                 mfma_q(1, 0, W0);
                 bar();
             }
-            epilogue_p<EPI, NI, false, 8, RD>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
+            epilogue_p<EPI, NI, false, 8, RD, false, DBG>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
         } else if (PH2) {
             for (int t = 0; t < nst; ++t, ++g) {             // the same wait / DMA / barrier skeleton for a wave in the padding of an edge tile
                 HX_WAIT_VM(6);
@@ -1416,7 +1419,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
                 mfma_q(1, 0, W0);
                 bar();
             }
-            epilogue_p<EPI, NI, false, 8, RD>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
+            epilogue_p<EPI, NI, false, 8, RD, false, DBG>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
         } else {
             // the same wait / DMA / barrier skeleton for a wave whose output block lies in the padding of a ragged edge tile
             for (int t = 0; t < nst; ++t, ++g) {
@@ -1447,14 +1450,18 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS ? 2 : 1), false, 1>(p); }      // two-phase schedule (PH2); the two-array residual epilogue decodes its loads a pass late: look-ahead 2 (1.258 -> 1.206 ms on proj; 3: 1.27-1.30)      // two-phase schedule (PH2)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pq256x3(GemmP p) { pp256_body<EPI, 1, true, 1>(p); }
+template <int EPI>      // the measurement variant of gemm_pq256: same schedule and arithmetic, with the hirest_gemm_debug_mode switches live
+__global__ __launch_bounds__(512) void gemm_pq256_dbg(GemmP p) { pp256_body<EPI, (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS ? 2 : 1), false, 1, true>(p); }
 
 
-template <int EPI, int RD = 1, bool X3 = false, int PH2 = 0>
+template <int EPI, int RD = 1, bool X3 = false, int PH2 = 0, bool DBG = false>
 int launch_pp256(GemmP p, hipStream_t s) {
+    static_assert(!DBG || (PH2 && !X3), "the switch-carrying instantiation exists for gemm_pq256 only");
     static HirestDevCfg cfg;
     int cus = 0;
     auto kern = [] {
-        if constexpr (X3 && PH2) return gemm_pq256x3<EPI>;
+        if constexpr (DBG) return gemm_pq256_dbg<EPI>;
+        else if constexpr (X3 && PH2) return gemm_pq256x3<EPI>;
         else if constexpr (X3) return gemm_pp256x3<EPI>;
         else if constexpr (PH2) return gemm_pq256<EPI>;
         else return gemm_pp256<EPI, RD>;
@@ -1547,6 +1554,9 @@ int launch_t128x3(const GemmP& p, hipStream_t s) {
 static inline bool x3_small(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) < 256; }
 int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
 
+// walk / knock-out switches of hirest_gemm_debug_mode that only gemm_pq256_dbg reads (bits 10-19)
+static inline bool pq_switches(const GemmP& p) { return p.sched || p.stagger || p.epi_dbg; }
+
 // LN-fold epilogues exist in the persistent kernels only
 template <int EPI>
 int launch_fused(const GemmP& p, hipStream_t s) {
@@ -1560,6 +1570,7 @@ int launch_fused(const GemmP& p, hipStream_t s) {
     // same bits; 6 / 8 select those for A/B
     if (g_force_kernel == 6) return launch_p256_impl<EPI, 64, false>(q, s);
     if (g_force_kernel == 8) return launch_pp256<EPI>(q, s);
+    if (pq_switches(q)) return launch_pp256<EPI, 1, false, 1, true>(q, s);      // measurement variant (gemm_pq256_dbg)
     return launch_pp256<EPI, 1, false, 1>(q, s);
 }
 
@@ -1569,11 +1580,12 @@ int launch(const GemmP& p, hipStream_t s) {
     const bool big = (int64_t)p.M * p.N >= (int64_t)2048 * 1024 && p.M >= 512 && p.N >= 256;
     // large problems: the two-phase ping-pong kernel (round 4; p256 / pp256 stay selectable: 6 / 8)
     constexpr bool has_dbg_inst = EPI == HIREST_EPI_BIAS_BF16 || EPI == HIREST_EPI_BIAS_GELU_BF16 || EPI == HIREST_EPI_BIAS_RESID_F32;
-    if (g_force_kernel == 0 && big && !(p.dbg && has_dbg_inst)) return launch_pp256<EPI, 1, false, 1>(p, s);
+    if (g_force_kernel == 0 && big && !(p.dbg && has_dbg_inst))
+        return pq_switches(p) ? launch_pp256<EPI, 1, false, 1, true>(p, s) : launch_pp256<EPI, 1, false, 1>(p, s);
     if (g_force_kernel == 6 || (g_force_kernel == 0 && big)) return launch_p256<EPI, 64>(p, s);      // (timing-experiment bits exist in p256 only)
     if (g_force_kernel == 7) return launch_p256<EPI, 128>(p, s);
     if (g_force_kernel == 8) return launch_pp256<EPI>(p, s);
-    if (g_force_kernel == 9) return launch_pp256<EPI, 1, false, 1>(p, s);
+    if (g_force_kernel == 9) return pq_switches(p) ? launch_pp256<EPI, 1, false, 1, true>(p, s) : launch_pp256<EPI, 1, false, 1>(p, s);
     if (g_force_kernel == 5) return launch256q<EPI>(p, s);
     if (g_force_kernel == 4) return launch256p<EPI>(p, s);
     if (g_force_kernel == 2) return launch256<EPI, 4>(p, s);
@@ -1617,7 +1629,8 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     const bool big = fused ? (a->M >= 64 && a->N >= 256) : ((int64_t)a->M * a->N >= (int64_t)2048 * 1024 && a->M >= 512 && a->N >= 256);
     const bool dbg_inst = !fused && (g_gemm_dbg & ~(512 | 3072 | 0xF000 | 0xF0000)) && (epi == HIREST_EPI_BIAS_BF16 || epi == HIREST_EPI_BIAS_GELU_BF16 || epi == HIREST_EPI_BIAS_RESID_F32);
     if (fused && !big) return HIREST_E_SHAPE;
-    if (f == 9 || (fused && f != 6 && f != 8) || (!fused && f == 0 && big && !dbg_inst)) snprintf(out, out_len, "gemm_pq256<%d>", epi);
+    const bool sw = (g_gemm_dbg & (3072 | 0xF000 | 0xF0000)) != 0;      // stagger / epilogue knock-outs / walk switches: the measurement variant
+    if (f == 9 || (fused && f != 6 && f != 8) || (!fused && f == 0 && big && !dbg_inst)) snprintf(out, out_len, sw ? "gemm_pq256_dbg<%d>" : "gemm_pq256<%d>", epi);
     else if (fused) {
         if (f == 8) snprintf(out, out_len, "gemm_pp256<%d, 1>", epi);
         else snprintf(out, out_len, "gemm_p256<%d, 64, false, 1>", epi);
@@ -1635,6 +1648,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
 extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     if (!a || a->struct_size != sizeof(hirest_gemm_args) || !a->A || !a->W || !a->out) return HIREST_E_BADARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return HIREST_E_BADARG;
+    if (a->flags & ~(HIREST_GEMM_REVERSE | HIREST_GEMM_X3)) return HIREST_E_BADARG;      // (a retired flag, e.g. round 4's K-blocked operands, must not be read as row-major)
     if (a->K % BK != 0 || a->K % T_BK != 0 || a->N % 4 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return HIREST_E_SHAPE;
     GemmP p;
     p.A = reinterpret_cast<const bf16_t*>(a->A); p.lda = a->lda;

@@ -24,8 +24,12 @@ struct GemmP {
 
 constexpr int GROUP_M = 8;                        // M-panels walked together inside one XCD
 // M panels of XCD x: an even split, [x nbm / 8, (x + 1) nbm / 8) (1028 panels = 4 x 129 + 4 x 128, not 7 x 129 + 125)
+// DBG (here and in the epilogues below): the A/B and knock-out switches of hirest_gemm_debug_mode are read only by the *_dbg kernel
+// instantiations; in the production code objects they fold to constants (a run-time branch on them cost gemm_pq256<10> a spilled register and
+// 1 - 3 % of fc2 / proj in round 5).
+template <bool DBG = false>
 __device__ __forceinline__ void xcd_panels(const GemmP& p, int xcd, int& p_lo, int& np) {
-    if (p.sched & 1) { p_lo = xcd * p.ppx; np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np; return; }   // A/B: the old split
+    if (DBG && (p.sched & 1)) { p_lo = xcd * p.ppx; np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np; return; }   // A/B: the old split
     p_lo = (int)(((long long)xcd * p.nbm) >> 3);
     np = (int)(((long long)(xcd + 1) * p.nbm) >> 3) - p_lo;
 }
@@ -77,8 +81,9 @@ __device__ __forceinline__ float sum8(float v) {   // over the 8 lanes lane & ~7
 // S2 (HIREST_EPI_BIAS_RESID2_LNSTATS): the residual stream is kept as TWO bf16 arrays, hi = bf16(x) — which is the copy the next GEMM streams
 // anyway — and lo = bf16(x - hi) (16 significand bits; p.out = lo [M, ldo], p.aux0 = hi [M, N], both in / out).  The epilogue reads 2 + 2
 // bytes per element and writes 2 + 2 instead of reading 4 and writing 4 + 2: a fifth less traffic on the byte-bound residual GEMMs.
-template <int NI, int NM, int RD, bool S2 = false>
+template <int NI, int NM, int RD, bool S2 = false, bool DBG = false>
 __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8][NI], int jc, char* stg, int Mw, int Nw, int lane) {
+    const int epi_dbg = DBG ? p.epi_dbg : 0, sched = DBG ? p.sched : 0;   // knock-out / A-B switches: compile-time zero in production kernels
     const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;
     const int rr = lane >> 3, rc = lane & 7;
     float* outp = reinterpret_cast<float*>(p.out);
@@ -106,8 +111,8 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
                 const int col = (rc & 1) ? n1 - 4 : n0;
                 union { bf16x8 v; bf16x4 h[2]; float f[4]; } hv, lv;
                 hv.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; lv.v = hv.v;
-                if (col + 8 <= p.N && !(p.epi_dbg & 1)) {
-                    if (p.sched & 2) {                               // A/B (hirest_gemm_debug_mode bit 17): cached instead of streaming loads
+                if (col + 8 <= p.N && !(epi_dbg & 1)) {
+                    if (sched & 2) {                               // A/B (hirest_gemm_debug_mode bit 17): cached instead of streaming loads
                         hv.v = *reinterpret_cast<const bf16x8*>(xb + mr * p.N + col);
                         lv.v = *reinterpret_cast<const bf16x8*>(xlo + mr * p.ldo + col);
                     } else {
@@ -121,8 +126,8 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
                 continue;
             }
             const float* row = outp + (int64_t)(m < p.M ? m : p.M - 1) * p.ldo;
-            o[0][it] = (n0 < p.N && !(p.epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            o[1][it] = (n1 < p.N && !(p.epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            o[0][it] = (n0 < p.N && !(epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            o[1][it] = (n1 < p.N && !(epi_dbg & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + n1)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     f32x4 ring[RD + 1][2][2];                                        // pass mi lives in ring[mi % (RD + 1)]
@@ -167,8 +172,8 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
             const int m = Mw + mi * 16 + it * 8 + rr;
             const bool okm = m < p.M, ok0 = okm && n0 < p.N, ok1 = okm && n1 < p.N;
             if constexpr (!S2) {
-                if (ok0 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
-                if (ok1 && !(p.epi_dbg & 2)) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
+                if (ok0 && !(epi_dbg & 2)) __builtin_nontemporal_store(wv[0][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n0));
+                if (ok1 && !(epi_dbg & 2)) __builtin_nontemporal_store(wv[1][it], reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n1));
             }
             union { bf16x4 v; float f[2]; } b0, b1, snd, rcv;
             float ps = 0.f, pq = 0.f;
@@ -184,7 +189,7 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
             int col;
             if (rc & 1) { w8.f[0] = rcv.f[0]; w8.f[1] = rcv.f[1]; w8.f[2] = b1.f[0]; w8.f[3] = b1.f[1]; col = n1 - 4; }
             else        { w8.f[0] = b0.f[0]; w8.f[1] = b0.f[1]; w8.f[2] = rcv.f[0]; w8.f[3] = rcv.f[1]; col = n0; }
-            if (okm && col + 8 <= p.N && !(p.epi_dbg & 4)) __builtin_nontemporal_store(w8.v, reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col));
+            if (okm && col + 8 <= p.N && !(epi_dbg & 4)) __builtin_nontemporal_store(w8.v, reinterpret_cast<bf16x8*>(xb + (int64_t)m * p.N + col));
             if constexpr (S2) {                                      // lo = bf16(x - hi), regrouped like hi: 16 B per lane, whole lines per row
                 union { bf16x4 v; float f[2]; } l0, l1, ls, lr;
 #pragma unroll
@@ -197,10 +202,10 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
                 union { bf16x8 v; float f[4]; } q8;
                 if (rc & 1) { q8.f[0] = lr.f[0]; q8.f[1] = lr.f[1]; q8.f[2] = l1.f[0]; q8.f[3] = l1.f[1]; }
                 else        { q8.f[0] = l0.f[0]; q8.f[1] = l0.f[1]; q8.f[2] = lr.f[0]; q8.f[3] = lr.f[1]; }
-                if (okm && col + 8 <= p.N && !(p.epi_dbg & 2)) __builtin_nontemporal_store(q8.v, reinterpret_cast<bf16x8*>(xlo + (int64_t)m * p.ldo + col));
+                if (okm && col + 8 <= p.N && !(epi_dbg & 2)) __builtin_nontemporal_store(q8.v, reinterpret_cast<bf16x8*>(xlo + (int64_t)m * p.ldo + col));
             }
             ps = sum8(ps); pq = sum8(pq);
-            if (rc == 0 && okm && Nw < p.N && !(p.epi_dbg & 8)) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
+            if (rc == 0 && okm && Nw < p.N && !(epi_dbg & 8)) *reinterpret_cast<f32x2*>(part + ((int64_t)m * G + (Nw >> 6)) * 2) = f32x2{ps, pq};
         }
     }
 }
@@ -217,12 +222,12 @@ __device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane
 
 // SREG (gemm_d2, whose two workgroups per CU leave no LDS for them): the (mean, rstd) pairs of the lane's NM rows go
 // straight from global memory (L2-resident, written by hirest_ln_stats_finalize) into registers at the start of the epilogue.
-template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1, bool SREG = false>   // PRE: the caller has already brought the row statistics into LDS
+template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1, bool SREG = false, bool DBG = false>   // PRE: the caller has already brought the row statistics into LDS
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
     if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 || EPI == HIREST_EPI_BIAS_RESID2_LNSTATS) {
 #pragma unroll
         for (int jc = 0; jc < NI; jc += 4)                            // one 64-column group at a time
-            if (Nw + jc * 16 < p.N) epilogue_lnstats<NI, NM, RD, EPI == HIREST_EPI_BIAS_RESID2_LNSTATS>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
+            if (Nw + jc * 16 < p.N) epilogue_lnstats<NI, NM, RD, EPI == HIREST_EPI_BIAS_RESID2_LNSTATS, DBG>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
         return;
     }
     constexpr bool FOLD = epi_is_lnfold(EPI);

@@ -1182,7 +1182,7 @@ int launch_rows_stream(const GemmLN& q, int ng, int k, hipStream_t s) {
     if (q.g.resid || q.g.periodic) return HIREST_E_SHAPE;
     const int ntile = (q.g.N + 15) / 16, ncs = 8 * k;
     const int max_mine = (ntile + ncs - 1) / ncs;
-    const int lds = FIXED + max_mine * 64;
+    const int lds = FIXED + ((max_mine + 15) / 16) * 16 * 64;      // the bias pre-load writes whole 1-KiB LDS-DMA pieces (16 tiles each)
     if (lds > 160 * 1024) return HIREST_E_SHAPE;
     hipLaunchKernelGGL(kern, dim3(8 * ng * k), dim3(256), lds, s, q, ng, max_mine);
     return hirest_launch_status();

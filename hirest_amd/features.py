@@ -94,19 +94,48 @@ def trim_to_duration(features: torch.Tensor, v_duration: float) -> torch.Tensor:
     return features[:n] if features.shape[0] != n else features
 
 
+def _model_input_size(model) -> int:
+    """Input resolution of the frame tower: EVA-CLIP keeps it as ``visual.image_size``, the OpenAI CLIP port as ``input_resolution``."""
+    vis = getattr(model, "visual", None)
+    size = getattr(vis, "image_size", None) or getattr(vis, "input_resolution", None) or getattr(model, "input_resolution", None)
+    if size is None:
+        raise AttributeError("model exposes neither visual.image_size nor input_resolution: cannot preprocess uint8 frames")
+    return int(size[0] if isinstance(size, (tuple, list)) else size)
+
+
+def _prepare_frames(model, frames: torch.Tensor) -> torch.Tensor:
+    """uint8 [T,H,W,3] decoded frames -> the model's input (resize + crop + normalise on the device); anything else passes through.
+    The input size is looked up only when uint8 frames actually arrive (preprocessed float frames need nothing from the model)."""
+    if frames.dtype != torch.uint8:
+        return frames
+    size = _model_input_size(model)
+    if tuple(frames.shape[1:3]) == (size, size):
+        return frames
+    from .preprocess import FramePreprocessor
+    pre = getattr(model, "_frame_preprocessor", None)
+    if pre is None:
+        vis = getattr(model, "visual", None)
+        pre = FramePreprocessor(size, getattr(vis, "image_mean", None), getattr(vis, "image_std", None))
+        object.__setattr__(model, "_frame_preprocessor", pre)
+    return pre(frames)
+
+
+def _embed_dim(model) -> int:
+    for owner, name in ((model, "embed_dim"), (getattr(model, "visual", None), "output_dim"), (getattr(model, "visual", None), "num_classes")):
+        v = getattr(owner, name, None)
+        if isinstance(v, int) and v > 0:
+            return v
+    raise AttributeError("cannot tell the embedding width of this model for an empty video")
+
+
 @torch.no_grad()
 def frame_features(model, frames: torch.Tensor, batch_size: int = 1024, normalize: bool = True) -> torch.Tensor:
     """extract_features.py:52-65 for one video: frames [T,3,S,S] (preprocessed) or uint8 [T,H,W,3] (decoded; resized and
-    cropped on the device) -> [T,E] fp32 on the GPU; ``normalize`` selects the L2-normalised file convention."""
-    if frames.dtype == torch.uint8:
-        size = model.visual.image_size
-        if tuple(frames.shape[1:3]) != (size, size):
-            from .preprocess import FramePreprocessor
-            pre = getattr(model, "_frame_preprocessor", None)
-            if pre is None:
-                pre = FramePreprocessor(size, getattr(model.visual, "image_mean", None), getattr(model.visual, "image_std", None))
-                object.__setattr__(model, "_frame_preprocessor", pre)
-            frames = pre(frames)
+    cropped on the device) -> [T,E] fp32 on the GPU; ``normalize`` selects the L2-normalised file convention.  A video of zero
+    frames gives an empty [0,E] tensor."""
+    if frames.shape[0] == 0:
+        return torch.zeros((0, _embed_dim(model)), dtype=torch.float32, device=frames.device)
+    frames = _prepare_frames(model, frames)
     outs = [model.encode_image(frames[s:s + batch_size]).float() for s in range(0, frames.shape[0], batch_size)]
     feats = torch.cat(outs) if len(outs) > 1 else outs[0]
     if normalize:
@@ -125,24 +154,13 @@ def frame_features_many(model, videos, min_call: int = 256, max_call: int = 1024
     same video whenever both calls take the same kernels (both >= 64 frames), and within the bf16 towers' tolerance otherwise."""
     videos = list(videos)
     out = [None] * len(videos)
-    size = model.visual.image_size
     group, count = [], 0
 
     def flush():
         nonlocal group, count
         if not group:
             return
-        prepared = []
-        for i in group:
-            f = videos[i]
-            if f.dtype == torch.uint8 and tuple(f.shape[1:3]) != (size, size):
-                from .preprocess import FramePreprocessor
-                pre = getattr(model, "_frame_preprocessor", None)
-                if pre is None:
-                    pre = FramePreprocessor(size, getattr(model.visual, "image_mean", None), getattr(model.visual, "image_std", None))
-                    object.__setattr__(model, "_frame_preprocessor", pre)
-                f = pre(f)
-            prepared.append(f)
+        prepared = [_prepare_frames(model, videos[i]) for i in group]
         same = len({(p.dtype, tuple(p.shape[1:])) for p in prepared}) == 1
         if same:
             feats = frame_features(model, torch.cat(prepared) if len(prepared) > 1 else prepared[0], batch_size=max_call, normalize=normalize)
@@ -156,6 +174,9 @@ def frame_features_many(model, videos, min_call: int = 256, max_call: int = 1024
         group, count = [], 0
     for i, f in enumerate(videos):
         n = int(f.shape[0])
+        if n == 0:                               # nothing to encode: an empty [0,E] result, and it must not pad a group
+            out[i] = frame_features(model, f, normalize=normalize)
+            continue
         if group and count + n > max_call:
             flush()
         group.append(i)

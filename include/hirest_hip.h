@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define HIREST_ABI_VERSION 3   /* 3: hirest_gemm_args gained struct_size (first member) and flags */
+#define HIREST_ABI_VERSION 4   /* 3: hirest_gemm_args gained struct_size (first member) and flags; 4 (round 6): hirest_split2_both_bf16 and
+                                 * HIREST_GEMM_KBLOCKED are gone, hirest_gemm_bf16 rejects unknown flag bits, hirest_attention_set_mapping
+                                 * takes 0..2 (default 2), the joint model gained its split-operand (bf16x3) precision */
 
 #define HIREST_E_BADARG   (-1)
 #define HIREST_E_SHAPE    (-2)   /* unsupported shape (see each function) */

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/hirest_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.hirest_abi_version() == 3 == _lib.ABI_VERSION
+    assert lib.hirest_abi_version() == 4 == _lib.ABI_VERSION
     assert b"gfx950" in lib.hirest_build_info()
 
 

@@ -26,8 +26,8 @@ for case in ("c5", "c3"):
     nb = 12
     for graphs in (True, False):
         for ns in (1, 2, 3, 4, 6):
-            model.caption_batches([batch] * max(ns, 2), num_beams=beams, streams=ns, graphs=graphs)
+            model.caption_batches([batch] * max(ns, 2), num_beams=beams, streams=ns, graphs=graphs, merge=False)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            model.caption_batches([batch] * nb, num_beams=beams, streams=ns, graphs=graphs)
+            model.caption_batches([batch] * nb, num_beams=beams, streams=ns, graphs=graphs, merge=False)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / nb
             print(f"beam {beams}  graphs {int(graphs)}  batches in flight {ns}:  {dt * 1e3:6.2f} ms per batch  {B / dt:7.1f} captions/s", flush=True)

@@ -189,8 +189,9 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         per_search = max(1, model.CAPTION_ROWS_IN_FLIGHT // beams // B)                     # loader batches per merged search
         searches = -(-nb // per_search)
         gbs = bytes_per_word * 48 * searches / (dtp * nb) / 1e9
-        rows = per_search * B * beams
-        tfl = 2.0 * (bytes_per_word / 4) * rows * 48 * searches / (dtp * nb) / 1e12
+        # actual rows per search (beam 3: 10 + 2 batches = 150 + 30 rows, not 2 x 150): FLOPs are counted on the rows that exist
+        rows = [min(per_search, nb - i * per_search) * B * beams for i in range(searches)]
+        tfl = 2.0 * (bytes_per_word / 4) * sum(rows) * 48 / (dtp * nb) / 1e12
         out[f"step_captioning_beam{beams}_pipelined"] = {
             "value": B / dtp, "unit": "captions/s", "ms_per_batch": dtp * 1e3, "beam": beams, "max_words": 48, "batches": nb,
             "merged_searches": searches, "beam_rows_per_search": rows, "searches_in_flight": ns,
