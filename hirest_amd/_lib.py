@@ -11,6 +11,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libhirest_hip.so")
+if os.environ.get("HIREST_LIB_VARIANT"):      # A/B builds of tools/build_variant.sh (hirest_amd/lib/libhirest_hip.<tag>.so): measurement only
+    LIB_PATH = os.path.join(HERE, "lib", f"libhirest_hip.{os.environ['HIREST_LIB_VARIANT']}.so")
 
 (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_POS_F32,
  EPI_BIAS_RESID_LNSTATS_F32, EPI_LNFOLD_BF16, EPI_LNFOLD_GELU_BF16, EPI_BIAS_GELU_SPLIT2, EPI_BIAS_RESID2_LNSTATS) = range(11)

@@ -1447,11 +1447,11 @@ __global__ __launch_bounds__(512) void gemm_pp256(GemmP p) { pp256_body<EPI, RD,
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp256x3(GemmP p) { pp256_body<EPI, 1, true>(p); }
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS ? 2 : 1), false, 1>(p); }      // two-phase schedule (PH2); the two-array residual epilogue decodes its loads a pass late: look-ahead 2 (1.258 -> 1.206 ms on proj; 3: 1.27-1.30)      // two-phase schedule (PH2)
+__global__ __launch_bounds__(512) void gemm_pq256(GemmP p) { pp256_body<EPI, (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS ? HIREST_S2_RD : 1), false, 1>(p); }      // two-phase schedule (PH2); the two-array residual epilogue decodes its loads a pass late: look-ahead 2 (1.258 -> 1.206 ms on proj; 3: 1.27-1.30)      // two-phase schedule (PH2)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pq256x3(GemmP p) { pp256_body<EPI, 1, true, 1>(p); }
 template <int EPI>      // the measurement variant of gemm_pq256: same schedule and arithmetic, with the hirest_gemm_debug_mode switches live
-__global__ __launch_bounds__(512) void gemm_pq256_dbg(GemmP p) { pp256_body<EPI, (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS ? 2 : 1), false, 1, true>(p); }
+__global__ __launch_bounds__(512) void gemm_pq256_dbg(GemmP p) { pp256_body<EPI, (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS ? HIREST_S2_RD : 1), false, 1, true>(p); }
 
 
 template <int EPI, int RD = 1, bool X3 = false, int PH2 = 0, bool DBG = false>

@@ -44,10 +44,19 @@ constexpr int Q_WOFF = T_BM * Q_BK * 2;
 #ifndef HIREST_X3_GELU_POLY
 #define HIREST_X3_GELU_POLY 1
 #endif
+#ifndef HIREST_S2_BUFFER_EPILOGUE
+#define HIREST_S2_BUFFER_EPILOGUE 1      // 0: round 5's flat-address form of the two-array residual epilogue (A/B builds)
+#endif
+#ifndef HIREST_S2_RD
+#define HIREST_S2_RD 2                   // residual look-ahead (16-row passes) of the two-array residual epilogue in gemm_pq256
+#endif
 constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128 B
 constexpr bool epi_is_lnfold(int epi) { return epi == HIREST_EPI_LNFOLD_BF16 || epi == HIREST_EPI_LNFOLD_GELU_BF16; }
 // the LN-fold consumers keep the (mean, rstd) pairs of the wave's 128 rows behind their staging area
-constexpr int p_stg_bytes(int epi) { return epi_is_lnfold(epi) ? P_STG + 1024 : P_STG; }
+// (the straight-line two-array residual epilogue stages both 32-column halves of a pass at once: 2 x P_STG, which brings the kernel to 160 KiB)
+constexpr int p_stg_bytes(int epi) {
+    return epi_is_lnfold(epi) ? P_STG + 1024 : (epi == HIREST_EPI_BIAS_RESID2_LNSTATS && HIREST_S2_BUFFER_EPILOGUE) ? 2 * P_STG : P_STG;
+}
 
 // Epilogue of p256: accumulators are 16x16 MFMA tiles, acc[mi][ni][e] = C[mi*16 + (lane&15)][ni*16 + 4*(lane>>4) + e]
 // (operands swapped, so a lane owns 4 consecutive columns of one row).  16 rows at a time go through a wave-private
@@ -73,6 +82,18 @@ __device__ __forceinline__ float sum8(float v) {   // over the 8 lanes lane & ~7
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
     return v;
 }
+// Buffer (range-checked) accesses for the two-array residual epilogue.  Why: with flat global loads / stores every ragged-edge predicate is a
+// branch (s_cbranch_execz around the access), the compiler cannot count vector-memory operations across branches, and it fell back to
+// s_waitcnt vmcnt(0) — the look-ahead ring was drained three times per tile, stores included (round-5 ISA: 3 full HBM round trips per
+// 128 x 64 block).  A raw buffer access with an out-of-range offset is dropped (store) or returns zeros (load) in hardware: the epilogue becomes
+// straight-line code and every wait is a counted vmcnt(n) that leaves the newer loads and the stores in flight.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+constexpr unsigned HX_OOB = 0x80000000u;                            // beyond any num_records used here
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hx_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
 // `jc` = first 16-column MFMA tile of the 64-column group this call handles (a 128-column wave tile calls it twice), Nw its
 // first column.
 // NM = 16-row tiles of the block that hold results (8; 4 for the 64-row blocks of w4's edge tiles).
@@ -210,6 +231,131 @@ __device__ __forceinline__ void epilogue_lnstats(const GemmP& p, f32x4 (&acc)[8]
     }
 }
 
+
+// HIREST_EPI_BIAS_RESID2_LNSTATS, straight-line form (round 6): the arithmetic of epilogue_lnstats<..., S2 = true> above, operation for operation,
+// with every global access a range-checked buffer access (see hx_rsrc): no predicate branches, so the compiler's waits are counted and the
+// residual rows of pass mi + RD really are in flight while pass mi is processed.  Per wave and 64-column group: 8 passes of 16 rows; a pass loads
+// 2 x (hi, lo) x 16 B per lane and stores 2 x (hi', lo') x 16 B + the row partials.
+// Registers are what limits the look-ahead (128 accumulators + the K loop's stream state stay live), so against the flat form: both 32-column
+// halves of a pass go through the staging area at once (4 KiB per wave: the kernel now uses all 160 KiB of the CU) and the 8-row sets of a pass
+// are finished one after the other; the bias is added after the transpose (8 registers instead of 16; (acc + bias) + residual in the same order).
+// Addressing: one descriptor per array for the tile and ONE per-lane offset per array; rows at or past M are cut by selecting an out-of-range
+// per-lane offset.  The 8-row step k is a scalar offset for the LOADS only.  The 16-byte STORES carry it in the per-lane offset with a literal
+// scalar offset of 0: a buffer_store_dwordx4 with an SGPR scalar offset followed directly by a VALU write of its data registers stored the NEW
+// contents of the second data dword on gfx950 (measured round 6: rows of every step k >= 1 wrong in exactly the overwritten register, k = 0 —
+// literal offset, where the compiler pads the documented store-data hazard — right); the compiler's hazard model exempts the SGPR-offset form.
+template <int NI, int NM, int RD, bool DBG = false>
+__device__ __forceinline__ void epilogue_lnstats2(const GemmP& p, f32x4 (&acc)[8][NI], int jc, char* stg, int Mw, int Nw, int lane) {
+    const int epi_dbg = DBG ? p.epi_dbg : 0, sched = DBG ? p.sched : 0;
+    const int srow = lane & 15, kg = lane >> 4, sw = lane & 7;
+    const int rr = lane >> 3, rc = lane & 7;
+    const int G = (p.N + 63) >> 6;
+    const int N = p.N, ldo = (int)p.ldo;
+    int rows = p.M - Mw; rows = rows < NM * 16 ? rows : NM * 16;      // > 0: the caller checked that this wave's block holds rows
+    const __amdgpu_buffer_rsrc_t rs_hi = hx_rsrc(reinterpret_cast<const bf16_t*>(p.aux0) + (int64_t)Mw * N, (unsigned)rows * (unsigned)N * 2u);
+    const __amdgpu_buffer_rsrc_t rs_lo = hx_rsrc(reinterpret_cast<const bf16_t*>(p.out) + (int64_t)Mw * ldo, ((unsigned)(rows - 1) * (unsigned)ldo + (unsigned)N) * 2u);
+    const __amdgpu_buffer_rsrc_t rs_pt = hx_rsrc(reinterpret_cast<const float*>(p.aux1) + ((int64_t)Mw * G + (Nw >> 6)) * 2, ((unsigned)(rows - 1) * (unsigned)G + 1u) * 8u);
+    const __amdgpu_buffer_rsrc_t rs_b = hx_rsrc(p.bias, p.bias ? (unsigned)N * 4u : 0u);
+    const int n0 = Nw + rc * 4, n1 = Nw + 32 + rc * 4;               // this lane's columns in the two 32-column halves (after the transpose)
+    // columns past N (or no bias at all): out of range -> zeros
+    const f32x4 bias0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)n0 * 4u, 0, 0));
+    const f32x4 bias1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)n1 * 4u, 0, 0));
+    // 16 B per lane at the columns the stores use (even lanes: n0 .. n0 + 7, odd lanes: n1 - 4 .. n1 + 3 — a row's 64 columns are one 128-B line
+    // per array); loads and stores of a pass share their offsets
+    const int col = (rc & 1) ? n1 - 4 : n0;
+    const bool col_ok = col + 8 <= N;
+    const unsigned vh0 = col_ok ? (unsigned)(rr * N + col) * 2u : HX_OOB, vl0 = col_ok ? (unsigned)(rr * ldo + col) * 2u : HX_OOB;
+    const unsigned vp0 = (rc == 0 && Nw < N) ? (unsigned)(rr * G) * 8u : HX_OOB;
+    const unsigned sh = 16u * (unsigned)N, sl = 16u * (unsigned)ldo, sp = 64u * (unsigned)G;   // bytes per 8 rows
+    const unsigned vh_ld = (epi_dbg & 1) ? HX_OOB : vh0, vl_ld = (epi_dbg & 1) ? HX_OOB : vl0;
+    const unsigned vh_st = (epi_dbg & 4) ? HX_OOB : vh0, vl_st = (epi_dbg & 2) ? HX_OOB : vl0, vp_st = (epi_dbg & 8) ? HX_OOB : vp0;
+    auto load_res = [&](int mi, u32x4 (&o)[2][2]) {                  // raw bits: decoded when the pass is due, so nothing waits here
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = mi * 2 + it;
+            const bool okm = k * 8 + rr < rows;
+            const unsigned vh = okm ? vh_ld : HX_OOB, vl = okm ? vl_ld : HX_OOB;
+            if (DBG && (sched & 2)) {                                // A/B (hirest_gemm_debug_mode bit 17): cached instead of streaming loads
+                o[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_hi, vh, (unsigned)k * sh, 0);
+                o[1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, vl, (unsigned)k * sl, 0);
+            } else {
+                o[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_hi, vh, (unsigned)k * sh, 2);
+                o[1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, vl, (unsigned)k * sl, 2);
+            }
+        }
+    };
+    u32x4 ring[RD + 1][2][2];                                        // pass mi lives in ring[mi % (RD + 1)]
+#pragma unroll
+    for (int a = 0; a < RD && a < NM; ++a) load_res(a, ring[a]);
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi) {
+        if (mi + RD < NM) load_res(mi + RD, ring[(mi + RD) % (RD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);                           // (free to move, the scheduler issues every pass's loads at once and spills)
+        // ---- both 32-column halves of the pass -> staging (block h = the flat form's 16 x 128-B image of half h)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+                *reinterpret_cast<f32x4*>(stg + h * P_STG + srow * 128 + (((nn * 4 + kg) ^ sw) << 4)) = acc[mi][jc + h * 2 + nn];
+        HX_LDS_ORDER();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = mi * 2 + it;
+            const int r = it * 8 + rr;
+            // residual values at (n0 .. n0 + 3) and (n1 .. n1 + 3) of row r: the stores' DPP exchange run backwards
+            f32x4 oc0, oc1;
+            {
+                union { bf16x8 v; bf16x4 h[2]; float f[4]; } hv, lv;
+                hv.v = __builtin_bit_cast(bf16x8, ring[mi % (RD + 1)][0][it]); lv.v = __builtin_bit_cast(bf16x8, ring[mi % (RD + 1)][1][it]);
+                union { bf16x4 v; float f[2]; } hs, hr, ls, lr;
+                hs.v = (rc & 1) ? hv.h[0] : hv.h[1];
+                ls.v = (rc & 1) ? lv.h[0] : lv.h[1];
+                hr.f[0] = dpp_xor1(hs.f[0]); hr.f[1] = dpp_xor1(hs.f[1]);
+                lr.f[0] = dpp_xor1(ls.f[0]); lr.f[1] = dpp_xor1(ls.f[1]);
+                const bf16x4 h0 = (rc & 1) ? hr.v : hv.h[0], h1 = (rc & 1) ? hv.h[1] : hr.v;
+                const bf16x4 l0 = (rc & 1) ? lr.v : lv.h[0], l1 = (rc & 1) ? lv.h[1] : lr.v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { oc0[e] = (float)h0[e] + (float)l0[e]; oc1[e] = (float)h1[e] + (float)l1[e]; }
+            }
+            const f32x4 wv0 = (*reinterpret_cast<const f32x4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4)) + bias0) + oc0;
+            const f32x4 wv1 = (*reinterpret_cast<const f32x4*>(stg + P_STG + r * 128 + ((rc ^ (r & 7)) << 4)) + bias1) + oc1;
+            const bool okm = k * 8 + rr < rows, ok0 = okm && n0 < N, ok1 = okm && n1 < N;
+            union { bf16x4 v; float f[2]; } b0, b1, snd, rcv;
+            float ps = 0.f, pq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                b0.v[e] = (bf16_t)wv0[e]; b1.v[e] = (bf16_t)wv1[e];
+                const float f0 = ok0 ? (float)b0.v[e] : 0.f, f1 = ok1 ? (float)b1.v[e] : 0.f;
+                ps += f0 + f1; pq = fmaf(f0, f0, fmaf(f1, f1, pq));
+            }
+            snd.v = (rc & 1) ? b0.v : b1.v;                          // odd lanes hand over their left half, even lanes their right half
+            rcv.f[0] = dpp_xor1(snd.f[0]); rcv.f[1] = dpp_xor1(snd.f[1]);
+            union { u32x4 u; float f[4]; } w8;
+            if (rc & 1) { w8.f[0] = rcv.f[0]; w8.f[1] = rcv.f[1]; w8.f[2] = b1.f[0]; w8.f[3] = b1.f[1]; }
+            else        { w8.f[0] = b0.f[0]; w8.f[1] = b0.f[1]; w8.f[2] = rcv.f[0]; w8.f[3] = rcv.f[1]; }
+            __builtin_amdgcn_raw_buffer_store_b128(w8.u, rs_hi, okm ? vh_st + (unsigned)k * sh : HX_OOB, 0, 2);
+            union { bf16x4 v; float f[2]; } l0, l1, ls, lr;          // lo = bf16(x - hi), regrouped like hi: 16 B per lane, whole lines per row
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                l0.v[e] = (bf16_t)(wv0[e] - (float)b0.v[e]);
+                l1.v[e] = (bf16_t)(wv1[e] - (float)b1.v[e]);
+            }
+            ls.v = (rc & 1) ? l0.v : l1.v;
+            lr.f[0] = dpp_xor1(ls.f[0]); lr.f[1] = dpp_xor1(ls.f[1]);
+            union { u32x4 u; float f[4]; } q8;
+            if (rc & 1) { q8.f[0] = lr.f[0]; q8.f[1] = lr.f[1]; q8.f[2] = l1.f[0]; q8.f[3] = l1.f[1]; }
+            else        { q8.f[0] = l0.f[0]; q8.f[1] = l0.f[1]; q8.f[2] = lr.f[0]; q8.f[3] = lr.f[1]; }
+            __builtin_amdgcn_raw_buffer_store_b128(q8.u, rs_lo, okm ? vl_st + (unsigned)k * sl : HX_OOB, 0, 2);
+            ps = sum8(ps); pq = sum8(pq);
+            union { u32x2 u; float f[2]; } st;
+            st.f[0] = ps; st.f[1] = pq;
+            __builtin_amdgcn_raw_buffer_store_b64(st.u, rs_pt, okm ? vp_st + (unsigned)k * sp : HX_OOB, 0, 0);
+        }
+        HX_LDS_ORDER();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // (mean, rstd) of rows Mw + 2*lane and Mw + 2*lane + 1 for the LN-fold consumers (gemm_p256 brings them in by LDS-DMA at
 // the start of a tile instead, so the latency hides behind the K loop)
 __device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane) {
@@ -227,7 +373,10 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
     if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 || EPI == HIREST_EPI_BIAS_RESID2_LNSTATS) {
 #pragma unroll
         for (int jc = 0; jc < NI; jc += 4)                            // one 64-column group at a time
-            if (Nw + jc * 16 < p.N) epilogue_lnstats<NI, NM, RD, EPI == HIREST_EPI_BIAS_RESID2_LNSTATS, DBG>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
+            if (Nw + jc * 16 < p.N) {
+                if constexpr (EPI == HIREST_EPI_BIAS_RESID2_LNSTATS && HIREST_S2_BUFFER_EPILOGUE) epilogue_lnstats2<NI, NM, RD, DBG>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
+                else epilogue_lnstats<NI, NM, RD, EPI == HIREST_EPI_BIAS_RESID2_LNSTATS, DBG>(p, acc, jc, stg, Mw, Nw + jc * 16, lane);
+            }
         return;
     }
     constexpr bool FOLD = epi_is_lnfold(EPI);
