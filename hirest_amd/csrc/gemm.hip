@@ -1338,6 +1338,19 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
         tile_origin(j, M0, N0);
         const bool active = (N0 + wc * 64 < p.N) && (M0 + wr * 128 < p.M);
         if (active) {
+            if constexpr (epi_is_lnfold(EPI)) {
+                // (mean, rstd) of this wave's 128 rows and the bias | column-sum slices of its 64 columns: global -> LDS by DMA, two pieces that
+                // are OLDER than everything the K loop issues, so its counted waits cover them (the second LOAD of step 0 retires them) and the
+                // epilogue starts without a global load (round 5: two exposed round trips per tile, vmcnt(0) each, in front of fc1 / qkv's epilogue)
+                int r0 = M0 + wr * 128 + 2 * lane;
+                const int last = (p.M - 1) & ~1;   // the stats buffer is padded to an even number of rows
+                r0 = r0 < last ? r0 : last;
+                glds16(reinterpret_cast<const float*>(p.aux0) + 2 * (int64_t)r0, stg + P_STG);
+                int c = N0 + wc * 64 + 4 * (lane & 15);
+                c = c < p.N - 4 ? c : p.N - 4;
+                const float* src = ((lane & 16) || !p.bias) ? reinterpret_cast<const float*>(p.aux1) : p.bias;
+                glds16(src + c, stg + P_BCS);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1369,7 +1382,7 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
                 mfma_q(1, 0, W0);
                 bar();
             }
-            epilogue_p<EPI, NI, false, 8, RD, false, DBG>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
+            epilogue_p<EPI, NI, epi_is_lnfold(EPI), 8, RD, false, DBG, epi_is_lnfold(EPI)>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
         } else if (PH2) {
             for (int t = 0; t < nst; ++t, ++g) {             // the same wait / DMA / barrier skeleton for a wave in the padding of an edge tile
                 HX_WAIT_VM(6);
@@ -1419,7 +1432,8 @@ __device__ __forceinline__ void pp256_body(const GemmP& p) {
                 mfma_q(1, 0, W0);
                 bar();
             }
-            epilogue_p<EPI, NI, false, 8, RD, false, DBG>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
+            if constexpr (epi_is_lnfold(EPI)) HX_WAIT_VM(8);      // the tile-start statistics / bias pieces are older than the 8 newest ring pieces (a one-step tile has not retired them yet)
+            epilogue_p<EPI, NI, epi_is_lnfold(EPI), 8, RD, false, DBG, epi_is_lnfold(EPI)>(p, acc, stg, M0 + wr * 128, N0 + wc * 64, lane);
         } else {
             // the same wait / DMA / barrier skeleton for a wave whose output block lies in the padding of a ragged edge tile
             for (int t = 0; t < nst; ++t, ++g) {

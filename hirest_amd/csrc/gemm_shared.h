@@ -52,10 +52,12 @@ constexpr int Q_WOFF = T_BM * Q_BK * 2;
 #endif
 constexpr int P_STG = 2048;    // epilogue staging bytes per wave: 16 rows x 128 B
 constexpr bool epi_is_lnfold(int epi) { return epi == HIREST_EPI_LNFOLD_BF16 || epi == HIREST_EPI_LNFOLD_GELU_BF16; }
-// the LN-fold consumers keep the (mean, rstd) pairs of the wave's 128 rows behind their staging area
+// the LN-fold consumers keep the (mean, rstd) pairs of the wave's 128 rows behind their staging area (1 KiB) and, in the ping-pong kernels, the
+// tile's bias | column-sum slices behind those (P_BCS: 64 + 64 floats, brought in by one LDS-DMA piece at the start of the tile)
+constexpr int P_BCS = P_STG + 1024;
 // (the straight-line two-array residual epilogue stages both 32-column halves of a pass at once: 2 x P_STG, which brings the kernel to 160 KiB)
 constexpr int p_stg_bytes(int epi) {
-    return epi_is_lnfold(epi) ? P_STG + 1024 : (epi == HIREST_EPI_BIAS_RESID2_LNSTATS && HIREST_S2_BUFFER_EPILOGUE) ? 2 * P_STG : P_STG;
+    return epi_is_lnfold(epi) ? P_STG + 2048 : (epi == HIREST_EPI_BIAS_RESID2_LNSTATS && HIREST_S2_BUFFER_EPILOGUE) ? 2 * P_STG : P_STG;
 }
 
 // Epilogue of p256: accumulators are 16x16 MFMA tiles, acc[mi][ni][e] = C[mi*16 + (lane&15)][ni*16 + 4*(lane>>4) + e]
@@ -368,7 +370,9 @@ __device__ __forceinline__ f32x4 load_row_stats(const GemmP& p, int Mw, int lane
 
 // SREG (gemm_d2, whose two workgroups per CU leave no LDS for them): the (mean, rstd) pairs of the lane's NM rows go
 // straight from global memory (L2-resident, written by hirest_ln_stats_finalize) into registers at the start of the epilogue.
-template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1, bool SREG = false, bool DBG = false>   // PRE: the caller has already brought the row statistics into LDS
+// BLDS (with PRE, LN-fold epilogues of 64-column wave tiles): the caller has also brought bias[Nw .. Nw + 63] | colsum[Nw .. Nw + 63] into LDS at
+// stg + P_BCS (columns past N clamped: their results are never stored), so the epilogue starts without a single global load.
+template <int EPI, int NI, bool PRE = false, int NM = 8, int RD = 1, bool SREG = false, bool DBG = false, bool BLDS = false>   // PRE: the caller has already brought the row statistics into LDS
 __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], char* stg, int Mw, int Nw, int lane) {
     if constexpr (EPI == HIREST_EPI_BIAS_RESID_LNSTATS_F32 || EPI == HIREST_EPI_BIAS_RESID2_LNSTATS) {
 #pragma unroll
@@ -403,9 +407,16 @@ __device__ __forceinline__ void epilogue_p(const GemmP& p, f32x4 (&acc)[8][NI], 
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int col = Nw + (jp + n) * 16 + 4 * kg;
-                bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (FOLD)
-                    sv[n] = col < p.N ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux1) + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (FOLD && BLDS) {
+                    static_assert(!BLDS || NI == 4, "one 64-column group per wave");
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(stg + P_BCS + (n * 16 + 4 * kg) * 4);
+                    bv[n] = p.bias ? b : f32x4{0.f, 0.f, 0.f, 0.f};
+                    sv[n] = *reinterpret_cast<const f32x4*>(stg + P_BCS + 256 + (n * 16 + 4 * kg) * 4);
+                } else {
+                    bv[n] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FOLD)
+                        sv[n] = col < p.N ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux1) + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
             f32x2 mr_next = {0.f, 1.f};
             if constexpr (FOLD && !SREG) mr_next = *reinterpret_cast<const f32x2*>(stg + P_STG + srow * 8);
