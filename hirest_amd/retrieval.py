@@ -176,6 +176,40 @@ class FrameSource:
         return torch.cat(rows) if len(rows) != 1 else rows[0]
 
 
+def _id_runs(ids: Sequence[int]) -> List[Tuple[int, int]]:
+    """Sorted video ids -> maximal runs [(lo, hi), ...] of consecutive ids (so a streaming source is asked for few ranges)."""
+    runs: List[Tuple[int, int]] = []
+    for v in ids:
+        v = int(v)
+        if runs and runs[-1][1] == v:
+            runs[-1] = (runs[-1][0], v + 1)
+        else:
+            runs.append((v, v + 1))
+    return runs
+
+
+def _frame_source_rows_of(self, model, ids: Sequence[int], n_model_frames: Optional[int], device) -> torch.Tensor:
+    """Pooled rows of an arbitrary (sorted) set of videos, ``videos_per_call`` of them per tower call whatever their positions in the
+    corpus — the second pass of the margin-guarded re-rank (``run_corpus(rank_exact_k=...)``) re-encodes scattered videos and must not
+    fall back to one small tower call per video."""
+    rows = []
+    ids = [int(v) for v in ids]
+    for s in range(0, len(ids), self.videos_per_call):
+        parts = [self._block(lo, hi, device) for lo, hi in _id_runs(ids[s:s + self.videos_per_call])]
+        blk = torch.cat(parts) if len(parts) != 1 else parts[0]
+        if n_model_frames is not None and n_model_frames > 0 and blk.shape[1] != n_model_frames:
+            sel = torch.from_numpy(subsample_ids(blk.shape[1], n_model_frames)).to(device)
+            blk = blk.index_select(1, sel)
+        rows.append(encode_videos(model, blk))
+    if not rows:
+        E = getattr(model, "embed_dim", None) or model.visual.embed_dim
+        return torch.zeros((0, E), dtype=torch.float32, device=device)
+    return torch.cat(rows) if len(rows) != 1 else rows[0]
+
+
+FrameSource.pooled_rows_of = _frame_source_rows_of
+
+
 class FeatureFileSource:
     """A corpus of per-video feature files ``<feature_dir>/<video_id>.pt`` (``[T, E]``; the default branch,
     inference_video_retrieval.py:290-329, and what ``features.FeatureWriter`` / ``extract_features.py`` write): each file is
@@ -282,9 +316,121 @@ def score_corpus(text_rows: torch.Tensor, video_rows: torch.Tensor, video_ids: S
     return res
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Margin-guarded re-rank (round 6): reference ranks at (nearly) the bf16 towers' speed
+# ------------------------------------------------------------------------------------------------------------------
+# The bf16 vision tower encodes 2.6x faster than the rank-exact one (bf16x3) but perturbs a score by up to eps ~ 1e-3, which flips the
+# order of videos whose reference scores are closer than that.  Only THOSE videos need the precise tower: with every score known to
+# within eps, the order of two videos is certain when their fast scores differ by more than 2 eps.  So: encode the corpus fast, find
+# per query the videos whose place in the top k is not certain, re-encode the union precisely, and score again.  The top-k lists are
+# then the precise tower's (evaluate.py:58-69 ranks by (score, name); R@k only looks at the top k).
+
+def ambiguous_columns(top_val: np.ndarray, top_idx: np.ndarray, k: int, eps: float) -> np.ndarray:
+    """Host logic on the per-query sorted score window ``top_val`` / ``top_idx`` [Q, W] (W > k, descending): the ids of the videos whose
+    membership or position in some query's top k could change when every score moves by at most ``eps``.
+
+    For a query, cand = window entries with score >= s_k - 2 eps (s_k = the k-th score): anything below cannot reach the top k.  Inside
+    cand an entry is certain when both neighbouring gaps exceed 2 eps — its rank among the exact scores is its rank here — and
+    ambiguous otherwise.  (A candidate beyond rank k is within 2 eps of the k-th entry by definition, so both are ambiguous.)
+    The caller must pass a window that reaches below every query's threshold (``window_covers``)."""
+    Q, W = top_val.shape
+    if Q == 0 or W == 0:
+        return np.zeros((0,), dtype=np.int64)
+    k = min(k, W)
+    thr = top_val[:, k - 1:k] - 2.0 * eps
+    cand = top_val >= thr
+    close_next = np.zeros((Q, W), dtype=bool)
+    close_next[:, :-1] = (top_val[:, :-1] - top_val[:, 1:]) <= 2.0 * eps
+    close_next[:, :-1] &= cand[:, 1:]
+    close_prev = np.zeros((Q, W), dtype=bool)
+    close_prev[:, 1:] = close_next[:, :-1]
+    amb = cand & (close_next | close_prev)
+    return np.unique(top_idx[amb].astype(np.int64))
+
+
+def window_covers(top_val: np.ndarray, k: int, eps: float, n_videos: int) -> bool:
+    """True when the sorted window [Q, W] reaches below s_k - 2 eps for every query (or holds the whole corpus)."""
+    W = top_val.shape[1]
+    if W >= n_videos or top_val.shape[0] == 0:
+        return True
+    return bool((top_val[:, -1] < top_val[:, min(k, W) - 1] - 2.0 * eps).all())
+
+
+def _split_ids(ids: Sequence[int], rank: int, world: int) -> List[int]:
+    per = (len(ids) + world - 1) // world
+    return list(ids[rank * per:(rank + 1) * per])
+
+
+def _rows_of(model, source, ids: Sequence[int], n_model_frames, device, group, gather) -> torch.Tensor:
+    """Pooled rows of the videos ``ids`` (sorted), the work split over the ranks of ``group`` in contiguous chunks and merged with one
+    all-gather: [len(ids), E] on every rank, in ``ids`` order."""
+    rank, world = _rank_world(group)
+    if not hasattr(source, "pooled_rows_of"):
+        raise TypeError(f"{type(source).__name__} cannot re-encode single videos (rank_exact_k needs a FrameSource-like source)")
+    local = source.pooled_rows_of(model, _split_ids(ids, rank, world), n_model_frames, device)
+    if world == 1:
+        return local
+    return (gather or RowGather(group))(local, len(ids)).clone()
+
+
+@torch.no_grad()
+def rerank_exact(model, source, text_rows: torch.Tensor, video_rows: torch.Tensor, k: int, n_model_frames=None, group=None, device=None,
+                 exact_precision: str = "bf16x3", eps: Optional[float] = None, sample: int = 64, safety: float = 2.0,
+                 gather: Optional[RowGather] = None) -> Tuple[torch.Tensor, Dict[str, object]]:
+    """Second pass of ``run_corpus(rank_exact_k=k)``: ``video_rows`` [V, E] from the fast tower, ``text_rows`` [Q, E] from the exact
+    text tower -> (rows with every rank-ambiguous video re-encoded at ``exact_precision``, report).
+
+    ``eps`` (bound of |fast score - exact score|): measured here when None — ``sample`` videos spread over the corpus are encoded at
+    both precisions, eps = ``safety`` x the largest score difference over all queries x sampled videos.  The sampled videos are part
+    of the re-encoded set, so measuring costs nothing extra.  Identical on every rank (all inputs are replicated)."""
+    device = torch.device(device) if device is not None else video_rows.device
+    V, Q = video_rows.shape[0], text_rows.shape[0]
+    names = list(source.video_ids)
+    report: Dict[str, object] = {"k": int(k), "videos": V, "queries": Q, "exact_precision": exact_precision}
+    if V == 0 or Q == 0 or k <= 0:
+        report.update({"reencoded": 0, "reencoded_fraction": 0.0, "eps": float(eps or 0.0)})
+        return video_rows, report
+    fast_precision = model.visual.precision
+    out = video_rows.clone()
+    done = np.zeros((0,), dtype=np.int64)
+    try:
+        model.visual.precision = exact_precision
+        if eps is None:
+            sample_ids = np.unique(np.linspace(0, V - 1, min(sample, V)).astype(np.int64))
+            exact_s = _rows_of(model, source, sample_ids.tolist(), n_model_frames, device, group, gather)
+            sel = torch.from_numpy(sample_ids).to(device)
+            diff = ops.similarity(text_rows.contiguous(), video_rows.index_select(0, sel).contiguous()) - \
+                ops.similarity(text_rows.contiguous(), exact_s.contiguous())
+            measured = float(diff.abs().max().item())
+            eps = safety * measured
+            out.index_copy_(0, sel, exact_s)
+            done = sample_ids
+            report.update({"eps_measured_on": int(sample_ids.size), "max_abs_score_error_on_sample": measured, "safety": safety})
+        tie = tie_rank_from_names(names, device)
+        scores = ops.similarity(text_rows.contiguous(), video_rows.contiguous())
+        W = min(V, max(2 * k, k + 32))
+        while True:
+            val, idx = ops.topk(scores, W, tie)
+            val_h, idx_h = val.cpu().numpy(), idx.cpu().numpy()
+            if window_covers(val_h, k, eps, V):
+                break
+            W = min(V, 2 * W)
+        amb = ambiguous_columns(val_h, idx_h, k, eps)
+        todo = np.setdiff1d(amb, done)
+        if todo.size:
+            rows = _rows_of(model, source, todo.tolist(), n_model_frames, device, group, gather)
+            out.index_copy_(0, torch.from_numpy(todo).to(device), rows)
+        n_re = int(np.union1d(amb, done).size)
+        report.update({"eps": float(eps), "ambiguous": int(amb.size), "reencoded": n_re, "reencoded_fraction": n_re / V, "window": int(W)})
+    finally:
+        model.visual.precision = fast_precision
+    return out, report
+
+
 @torch.no_grad()
 def run_corpus(model, source, prompts: Sequence[str], n_model_frames: Optional[int] = None, group=None,
-               device=None, gather: Optional[RowGather] = None, tokenizer=None) -> RetrievalResult:
+               device=None, gather: Optional[RowGather] = None, tokenizer=None, rank_exact_k: int = 0,
+               rank_exact_options: Optional[Dict[str, object]] = None) -> RetrievalResult:
     """BASELINE configs[2] in one call: the body of inference_video_retrieval.py:203-355 for one rank of N.
 
     Every rank encodes the contiguous block of videos ``shard_range`` gives it (``source``: a ``FrameSource`` or a
@@ -296,7 +442,10 @@ def run_corpus(model, source, prompts: Sequence[str], n_model_frames: Optional[i
     video alone, so the scores agree for every N to the kernels' tolerance; they are BIT-identical across N when every rank's
     block is a whole number of ``videos_per_call`` groups of >= 64 frames (4096 videos on 1 / 2 / 4 / 8 ranks at 32 per call):
     a remainder call of fewer than 64 frames takes the unfolded-LayerNorm / per-head attention kernels, whose bits differ from
-    the folded path's (tools/c3_run.py compares digests only for such shard sizes)."""
+    the folded path's (tools/c3_run.py compares digests only for such shard sizes).
+
+    ``rank_exact_k`` > 0 (round 6) turns on the margin-guarded re-rank: see ``rerank_exact``; the result carries ``rank_exact`` (eps,
+    how many videos were encoded twice)."""
     device = torch.device(device) if device is not None else next(model.parameters()).device
     rank, world = _rank_world(group)
     local = corpus_block_rows(model, source, rank, world, n_model_frames, device)
@@ -305,8 +454,25 @@ def run_corpus(model, source, prompts: Sequence[str], n_model_frames: Optional[i
         video_rows = (gather or RowGather(group))(local, V)
     else:
         video_rows = local
-    text_rows = encode_prompts(model, prompts, device, tokenizer=tokenizer)
-    return score_corpus(text_rows, video_rows, source.video_ids, prompts)
+    if rank_exact_k <= 0:
+        text_rows = encode_prompts(model, prompts, device, tokenizer=tokenizer)
+        return score_corpus(text_rows, video_rows, source.video_ids, prompts)
+    # rank_exact_k = k: the top-k lists of the PRECISE towers at close to the fast tower's speed — the text tower runs exact (2 % of the work),
+    # the corpus fast, and only the videos whose place in some query's top k is within twice the measured score error are encoded again
+    # precisely (rerank_exact).  Every rank computes the same set and re-encodes its share of it; one more all-gather merges the rows.
+    text_precision = model.text.precision
+    try:
+        model.text.precision = "fp32"
+        text_rows = encode_prompts(model, prompts, device, tokenizer=tokenizer)
+    finally:
+        model.text.precision = text_precision
+    if world > 1:
+        video_rows = video_rows.clone()                    # (the gather buffer is reused by the second pass)
+    rows, report = rerank_exact(model, source, text_rows, video_rows, rank_exact_k, n_model_frames, group, device,
+                                gather=gather, **(rank_exact_options or {}))
+    res = score_corpus(text_rows, rows, source.video_ids, prompts)
+    res.rank_exact = report
+    return res
 
 
 def corpus_digest(video_rows: torch.Tensor, topk_idx: torch.Tensor) -> Dict[str, str]:

@@ -38,6 +38,9 @@ def main():
                     "device_count; needs --backend gloo: RCCL refuses two ranks on one device).  Exercises the multi-process driver — launcher, "
                     "shard, gather, replicated ranking, digest check — on a one-GPU box; its frames/s is not an N-GPU result and is labelled so")
     ap.add_argument("--model", default="g14", choices=("g14", "tiny"), help="tiny = the 2-layer test config (functional runs)")
+    ap.add_argument("--rank-exact-k", type=int, default=0, help="margin-guarded re-rank (retrieval.run_corpus(rank_exact_k=k)): the corpus on the "
+                    "--precision tower, the videos whose place in a top k is uncertain again on bf16x3; reports the re-encoded fraction")
+    ap.add_argument("--verify-rank-exact", action="store_true", help="also run the whole corpus at bf16x3 and compare the top-k lists (1 rank)")
     a = ap.parse_args()
     import torch
     if a.share_gpu and a.backend != "gloo":
@@ -65,10 +68,24 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    res = retrieval.run_corpus(model, src, prompts, a.frames, gather=gather)
+    res = retrieval.run_corpus(model, src, prompts, a.frames, gather=gather, rank_exact_k=a.rank_exact_k)
     val, idx = res.topk(10)
     sync()
     elapsed = time.perf_counter() - t0
+    rank_exact = dict(getattr(res, "rank_exact", {}) or {})
+    if a.rank_exact_k > 0:
+        rank_exact["effective_frames_per_s"] = a.videos * a.frames / elapsed
+        if a.verify_rank_exact and world == 1:
+            model.set_precision("bf16x3")
+            t1 = time.perf_counter()
+            full = retrieval.run_corpus(model, src, prompts, a.frames, gather=gather)
+            torch.cuda.synchronize(dev)
+            rank_exact["all_bf16x3_seconds"] = time.perf_counter() - t1
+            rank_exact["all_bf16x3_frames_per_s"] = a.videos * a.frames / rank_exact["all_bf16x3_seconds"]
+            kk = min(a.rank_exact_k, a.videos)
+            rank_exact["topk_lists_equal_all_bf16x3"] = bool(torch.equal(full.topk(kk)[1], res.topk(kk)[1]))
+            rank_exact["top1_flips_vs_all_bf16x3"] = int((full.topk(1)[1] != res.topk(1)[1]).sum())
+            model.set_precision(a.precision)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -110,6 +127,9 @@ def main():
             "result_dict": {"prompts": len(res), "videos_per_prompt": len(res[prompts[0]]["videos"]),
                             "layout": "inference_video_retrieval.py:337-346"},
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+        if a.rank_exact_k > 0:
+            report["rank_exact"] = rank_exact
+            report["equals_committed_1rank_digest"] = None           # (re-encoded rows differ from the all-bf16 digest by construction)
     if a.rank_blocks > 1 and world == 1:
         t1 = time.perf_counter()
         parts = [retrieval.corpus_block_rows(model, src, r, a.rank_blocks, a.frames) for r in range(a.rank_blocks)]
@@ -131,7 +151,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and (not ranks_agree or report.get("equals_committed_1rank_digest") is False
-                      or report.get("pooled_rows_bit_identical") is False or report.get("top10_identical") is False):
+                      or report.get("pooled_rows_bit_identical") is False or report.get("top10_identical") is False
+                      or report.get("rank_exact", {}).get("topk_lists_equal_all_bf16x3") is False):
         raise SystemExit(1)
 
 
