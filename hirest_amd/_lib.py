@@ -22,6 +22,7 @@ TOWER_NO_PRUNE = 2
 TOWER_F32_RESIDUAL = 4
 GEMM_REVERSE = 1
 GEMM_X3 = 2
+GEMM_X3_T128 = 4
 ABI_VERSION = 4   # HIREST_ABI_VERSION of include/hirest_hip.h this binding mirrors
 
 ERRORS = {-1: "HIREST_E_BADARG", -2: "HIREST_E_SHAPE (unsupported shape)", -3: "HIREST_E_WORKSPACE (workspace too small)"}
@@ -96,6 +97,18 @@ class CaptionDecoder(C.Structure):
                [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "emb_ln_g", "emb_ln_b")] + \
                [("layer", C.POINTER(CaptionLayer))] + \
                [(n, C.c_void_p) for n in ("tr_w", "tr_b", "tr_ln_g", "tr_ln_b", "lm_w", "lm_b")]
+
+
+class JointLayerX3(C.Structure):
+    """hirest_joint_layer_x3 (include/hirest_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w2", "qkv_b", "ao_w2", "ao_b", "ln1_g", "ln1_b", "fc1_w2", "fc1_b", "fc2_w2", "fc2_b", "ln2_g", "ln2_b")]
+
+
+class JointEncoderX3(C.Structure):
+    """hirest_joint_encoder_x3 (include/hirest_hip.h)."""
+    _fields_ = [("struct_size", C.c_uint64)] + [(n, C.c_int32) for n in ("layers", "heads", "width", "mlp_dim", "in_dim", "max_pos")] + \
+               [("ln_eps", C.c_float), ("attn_shift", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("emb_w2", "emb_b", "pos", "emb_ln_g", "emb_ln_b")] + [("layer", C.POINTER(JointLayerX3))]
 
 
 class ColsumItem(C.Structure):
@@ -267,6 +280,11 @@ _SIGNATURES = {
     "hirest_vision_guard_offset": (C.c_size_t, [C.POINTER(VisionTower), C.c_int32]),
     "hirest_vision_workspace_bytes_f32": (C.c_size_t, [C.POINTER(VisionTowerF32), C.c_int32]),
     "hirest_vision_embed_f32": (C.c_int, [C.POINTER(VisionTowerF32), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hirest_joint_encoder_x3_workspace_bytes": (C.c_size_t, [C.POINTER(JointEncoderX3), C.c_int32, C.c_int32]),
+    "hirest_joint_encoder_x3_forward": (C.c_int, [C.POINTER(JointEncoderX3), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p]),
+    "hirest_layernorm_f32_split2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_split2_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_layernorm_split2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int32,
                                           C.c_int32, C.c_void_p]),

@@ -48,6 +48,23 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, int m, int n, f32
         *reinterpret_cast<f32x4*>(o) = r + v;
     } else if constexpr (EPI == HIREST_EPI_BIAS_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = v;
+    } else if constexpr (EPI == HIREST_EPI_BIAS_GELU_SPLIT2) {
+        // GELU (erf form, the epilogue_p form's arithmetic) stored as bf16 hi | lo in the split operand format: the 4 columns lie in one 32-column
+        // block (n % 4 == 0), whose hi half starts at 64 (n / 32) and whose lo half 32 elements further
+#if HIREST_X3_GELU_POLY
+        const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+        const f32x4 gv = {g0[0], g0[1], g1[0], g1[1]};
+#else
+        f32x4 gv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gv[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f));
+#endif
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { hi[i] = (bf16_t)gv[i]; lo[i] = (bf16_t)(gv[i] - (float)hi[i]); }
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (int64_t)m * p.ldo + (n >> 5) * 64 + (n & 31);
+        *reinterpret_cast<bf16x4*>(o) = hi;
+        *reinterpret_cast<bf16x4*>(o + 32) = lo;
     } else {  // HIREST_EPI_PATCH_POS_F32
         const int b = m / p.P, pp = m - b * p.P;
         const int64_t orow = (int64_t)b * (p.P + 1) + 1 + pp;
@@ -177,13 +194,27 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave >> 2, w4 = wave & 3;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
-    const int p_lo = xcd * p.ppx;
-    int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
-    if (np <= 0 || j >= np * p.nbn) return;
-    const int grp = j / (GROUP_M * p.nbn);
-    const int r = j - grp * GROUP_M * p.nbn;
-    int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
-    const int nt = r / gcount, mt = p_lo + grp * GROUP_M + (r - nt * gcount);
+    int nt, mt, slice = 0;
+    if (p.flat) {
+        // few row panels (the joint model: 12 at 1 500 rows): the panel split above gives 6 of the 8 XCDs two panels each and the other two nothing
+        // (qkv: 36 tiles on the 32 CUs of six XCDs = two rounds, 64 CUs idle).  Flat split instead: the tile list in (column outer, panel inner)
+        // order cut into 8 equal contiguous chunks, one per XCD — each XCD streams every A panel and its own few W panels.
+        // With p.ksplit = S > 1 an item is (tile, K slice): slice s multiplies steps [s nk / S, (s + 1) nk / S) and stores its raw partial tile
+        // to p.part [S][M][N]; splitk_reduce_kernel adds the slices in slice order, then bias and residual (deterministic).
+        const int ntile = p.nbm * p.nbn * p.ksplit, per = (ntile + 7) >> 3, item = xcd * per + j;
+        if (j >= per || item >= ntile) return;
+        const int tile = item / p.ksplit;
+        slice = item - tile * p.ksplit;
+        nt = tile / p.nbm; mt = tile - nt * p.nbm;
+    } else {
+        const int p_lo = xcd * p.ppx;
+        int np = p.nbm - p_lo; np = np > p.ppx ? p.ppx : np;
+        if (np <= 0 || j >= np * p.nbn) return;
+        const int grp = j / (GROUP_M * p.nbn);
+        const int r = j - grp * GROUP_M * p.nbn;
+        int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
+        nt = r / gcount; mt = p_lo + grp * GROUP_M + (r - nt * gcount);
+    }
     const int M0 = mt * BM, N0 = nt * BN;
 
     // staging: waves 0-3 bring the 16 A pieces (8 rows x 128 B each), waves 4-7 the 16 W pieces
@@ -194,6 +225,7 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         if (kg == 0) { int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1; src[q] = p.A + (int64_t)gm * p.lda + chunk * 8; }
         else { int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1; src[q] = p.W + (int64_t)gn * p.ldw + chunk * 8; }
+        src[q] += (int64_t)slice * ((p.K / BK) / p.ksplit) * BK;
     }
     const int64_t kstep = BK;
     auto stage = [&](int slot, int kt) {
@@ -213,7 +245,7 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
-    const int nk = p.K / BK;
+    const int nk = (p.K / BK) / p.ksplit;
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i) if (i < nk) stage(i, i);
     // One barrier per step; both groups read their fragments, then multiply.  (A ping-pong form — two barriers per step, group 1 half a
@@ -280,9 +312,27 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
                 const int n = N0 + wn * 64 + jn * 32 + 8 * g + 4 * (lane >> 5);
                 if (n >= p.N) continue;
                 f32x4 v = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
-                epilogue_store<EPI>(p, m, n, v);
+                if (p.ksplit > 1) *reinterpret_cast<f32x4*>(p.part + ((int64_t)slice * p.M + m) * p.N + n) = v;
+                else epilogue_store<EPI>(p, m, n, v);
             }
         }
+    }
+}
+
+
+// out[m][n] += (part[0][m][n] + part[1][m][n] + ...) + bias[n]   (the split-K form of HIREST_EPI_BIAS_RESID_F32; N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, const float* __restrict__ bias, float* __restrict__ out,
+                                                           int64_t ldo, int M, int N) {
+    const int nq = N >> 2;
+    const int64_t total = (int64_t)M * nq, plane = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / nq;
+        const int n = (int)(i - m * nq) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + m * N + n);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(part + s * plane + m * N + n);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        float* o = out + m * ldo + n;
+        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(o) + v;
     }
 }
 
@@ -1558,11 +1608,28 @@ int g_gemm_dbg = 0;
 namespace {
 
 template <int EPI>
-int launch_t128x3(const GemmP& p, hipStream_t s) {
+int launch_t128x3(const GemmP& p0, hipStream_t s) {
     static HirestDevCfg cfg;
     auto kern = gemm_t128x3<EPI>;
     if (int e = hirest_configure(kern, 4 * STAGE_BYTES, cfg)) return e;
-    hipLaunchKernelGGL(kern, dim3(8 * p.ppx * p.nbn), dim3(512), 4 * STAGE_BYTES, s, p);
+    GemmP p = p0;
+    p.flat = p.nbm < 32 ? 1 : 0;                                  // (same tiles, same arithmetic per tile: the mapping does not change a bit of the result)
+    // Split-K (HIREST_EPI_BIAS_RESID_F32 with a scratch buffer in aux0): a 768-wide layer over 1 500 rows is 72 tiles for 256 CUs and the 3072-deep
+    // one of them (output.dense) runs 96 steps per tile — S slices of the K range per tile fill the chip; the slices are added in a fixed order.
+    p.ksplit = 1;
+    if (EPI == HIREST_EPI_BIAS_RESID_F32 && p.flat && p.aux0 && !p.aux1) {
+        const int ntile = p.nbm * p.nbn, nk = p.K / BK;
+        for (int S = 4; S >= 2; --S)
+            if (nk % S == 0 && nk / S >= 8 && ntile * S <= 256) { p.ksplit = S; break; }
+        p.part = reinterpret_cast<float*>(p.aux0);
+    }
+    const int grid = p.flat ? 8 * ((p.nbm * p.nbn * p.ksplit + 7) / 8) : 8 * p.ppx * p.nbn;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 4 * STAGE_BYTES, s, p);
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)p.M * (p.N / 4);
+        int blocks = (int)((total + 255) / 256); blocks = blocks > 2048 ? 2048 : blocks;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.part, p.ksplit, p.bias, reinterpret_cast<float*>(p.out), p.ldo, p.M, p.N);
+    }
     return hirest_launch_status();
 }
 static inline bool x3_small(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) < 256; }
@@ -1631,7 +1698,7 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (epi < 0 || epi > HIREST_EPI_BIAS_RESID2_LNSTATS) return HIREST_E_BADARG;
     if (a->flags & HIREST_GEMM_X3) {
         if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32 && epi != HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
-        if (x3_small(a->M, a->N) && epi != HIREST_EPI_BIAS_GELU_SPLIT2) {
+        if (((a->flags & HIREST_GEMM_X3_T128) || x3_small(a->M, a->N)) && (epi != HIREST_EPI_BIAS_GELU_SPLIT2 || (a->flags & HIREST_GEMM_X3_T128))) {
             snprintf(out, out_len, "gemm_t128x3<%d>", epi);
             return 0;
         }
@@ -1662,7 +1729,8 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
 extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     if (!a || a->struct_size != sizeof(hirest_gemm_args) || !a->A || !a->W || !a->out) return HIREST_E_BADARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return HIREST_E_BADARG;
-    if (a->flags & ~(HIREST_GEMM_REVERSE | HIREST_GEMM_X3)) return HIREST_E_BADARG;      // (a retired flag, e.g. round 4's K-blocked operands, must not be read as row-major)
+    if (a->flags & ~(HIREST_GEMM_REVERSE | HIREST_GEMM_X3 | HIREST_GEMM_X3_T128)) return HIREST_E_BADARG;
+    if ((a->flags & HIREST_GEMM_X3_T128) && !(a->flags & HIREST_GEMM_X3)) return HIREST_E_BADARG;      // (a retired flag, e.g. round 4's K-blocked operands, must not be read as row-major)
     if (a->K % BK != 0 || a->K % T_BK != 0 || a->N % 4 != 0 || a->lda % 8 != 0 || a->ldw % 8 != 0) return HIREST_E_SHAPE;
     GemmP p;
     p.A = reinterpret_cast<const bf16_t*>(a->A); p.lda = a->lda;
@@ -1682,9 +1750,13 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     HirestProfScope prof(HIREST_PROF_GEMM, a->epilogue, a->M, a->N, a->K, s);
     if (a->flags & HIREST_GEMM_X3) {                  // split-operand products: the ping-pong kernel's X3 form, fp32 outputs only
         // fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (2 workgroups per CU)
-        const bool small = x3_small(a->M, a->N);
+        const bool small = x3_small(a->M, a->N) || (a->flags & HIREST_GEMM_X3_T128);
         if (small && a->epilogue == HIREST_EPI_BIAS_F32) return launch_t128x3<HIREST_EPI_BIAS_F32>(p, s);
         if (small && a->epilogue == HIREST_EPI_BIAS_RESID_F32) return launch_t128x3<HIREST_EPI_BIAS_RESID_F32>(p, s);
+        if ((a->flags & HIREST_GEMM_X3_T128) && a->epilogue == HIREST_EPI_BIAS_GELU_SPLIT2) {      // (the towers keep the 256 x 256 kernel for this epilogue at every size)
+            if (a->N % 32 != 0 || a->ldo < 2 * (int64_t)a->N || a->ldo % 8 != 0) return HIREST_E_SHAPE;
+            return launch_t128x3<HIREST_EPI_BIAS_GELU_SPLIT2>(p, s);
+        }
         switch (a->epilogue) {
             case HIREST_EPI_BIAS_F32:
                 return g_force_kernel == 9 ? launch_pp256<HIREST_EPI_BIAS_F32, 1, true, 1>(p, s) : launch_pp256<HIREST_EPI_BIAS_F32, 1, true>(p, s);

@@ -20,6 +20,9 @@ struct GemmP {
     int stagger;         // timing experiment (hirest_gemm_debug_mode bits 10-11): staggered start of the CUs
     int sched;           // A/B switches of the tile schedule (hirest_gemm_debug_mode bit 16): uneven XCD split (ceil(nbm / 8) panels each)
     int dbg;             // timing experiments only (hirest_gemm_debug_mode): bit0 skip loop DMA, bit1 skip loop barrier+waits
+    int flat = 0;        // gemm_t128x3: flat tile list cut into 8 per-XCD chunks instead of the row-panel split (few row panels)
+    int ksplit = 1;      // gemm_t128x3: K slices per tile (flat mapping only); > 1: raw partial tiles to `part`, splitk_reduce_kernel finishes
+    float* part = nullptr;
 };
 
 constexpr int GROUP_M = 8;                        // M-panels walked together inside one XCD

@@ -147,6 +147,21 @@ class MomentModel(nn.Module):
         self.heads = 12
         self.caption_kv_cache = True   # step captioning keeps the decoder's self-attention K / V per beam (False: full-prefix recompute)
         self._cache = None
+        # 'fp32' (default: the reference's own arithmetic, modeling.py:120 / run.py without --fp16) or 'bf16x3': the encoder's linear layers on
+        # split operands (csrc/joint_x3.hip) — the counterpart of the reference's reduced-precision mode (torch.cuda.amp.autocast() under
+        # --fp16, run.py:549-551), at 16 significand bits per product so that indices / boundaries / token ids stay the fp32 run's
+        self.precision = "fp32"
+        if os.environ.get("HIREST_JOINT_PRECISION"):
+            self.set_precision(os.environ["HIREST_JOINT_PRECISION"])
+
+    def set_precision(self, precision: str):
+        """'fp32': every product exact fp32 (v_mfma_f32_*_f32).  'bf16x3': the VisualModel encoder's weight GEMMs (moment retrieval, the 20
+        segmentation passes, the captioning encoder pass) as three bf16 MFMAs on hi + lo splits of both fp32 operands; attention, LayerNorm,
+        GELU, residuals, fusion, heads and the caption decoder stay fp32."""
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"MomentModel precision must be 'fp32' or 'bf16x3', got {precision!r}")
+        self.precision = precision
+        return self
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def _apply(self, fn, *a, **k):
@@ -238,6 +253,59 @@ class MomentModel(nn.Module):
         self._cache = c
         return c
 
+    def _x3(self):
+        """Split-operand weights + the C-side descriptor of the encoder (hirest_joint_encoder_x3), built once per parameter version: every
+        [N, K] fp32 weight becomes [N, 2K] bf16 (hirest_split2_bf16: per 32 k, hi | lo).  Lives in the weight cache, so an optimizer step or a
+        load_state_dict rebuilds it with the rest."""
+        c, lib = self._w(), _lib.load()
+        if "x3" in c:
+            return c["x3"]
+        dev = c["dev"]
+
+        def split(w):
+            w = w.contiguous()
+            out = torch.empty((w.shape[0], 2 * w.shape[1]), dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.hirest_split2_bf16(w.data_ptr(), w.shape[1], out.data_ptr(), 2 * w.shape[1], w.shape[0], w.shape[1], 0,
+                                              ops.stream_ptr()), "hirest_split2_bf16")
+            return out
+        V = "clip4cap_model.visual."
+        nl = len(self.clip4cap_model.visual.encoder.layer)
+        keep, layers = [], (_lib.JointLayerX3 * nl)()
+        for i in range(nl):
+            p = V + f"encoder.layer.{i}."
+            w2 = [split(c[f"qkv_w.{i}"]), split(c[p + "attention.output.dense.weight"]), split(c[p + "intermediate.dense.weight"]),
+                  split(c[p + "output.dense.weight"])]
+            keep += w2
+            layers[i] = _lib.JointLayerX3(
+                w2[0].data_ptr(), c[f"qkv_b.{i}"].data_ptr(), w2[1].data_ptr(), c[p + "attention.output.dense.bias"].data_ptr(),
+                c[p + "attention.output.LayerNorm.weight"].data_ptr(), c[p + "attention.output.LayerNorm.bias"].data_ptr(),
+                w2[2].data_ptr(), c[p + "intermediate.dense.bias"].data_ptr(), w2[3].data_ptr(), c[p + "output.dense.bias"].data_ptr(),
+                c[p + "output.LayerNorm.weight"].data_ptr(), c[p + "output.LayerNorm.bias"].data_ptr())
+        emb = split(c[V + "embeddings.word_embeddings.weight"])
+        keep.append(emb)
+        H = c[V + "embeddings.LayerNorm.weight"].shape[0]
+        pos = c[V + "embeddings.position_embeddings.weight"]
+        desc = _lib.JointEncoderX3(C.sizeof(_lib.JointEncoderX3), nl, self.heads, H, c[V + "encoder.layer.0.intermediate.dense.weight"].shape[0],
+                                   c[V + "embeddings.word_embeddings.weight"].shape[1], pos.shape[0], 1e-12, -10000.0,
+                                   emb.data_ptr(), c[V + "embeddings.word_embeddings.bias"].data_ptr(), pos.data_ptr(),
+                                   c[V + "embeddings.LayerNorm.weight"].data_ptr(), c[V + "embeddings.LayerNorm.bias"].data_ptr(), layers)
+        c["x3"] = {"desc": desc, "layers": layers, "keep": keep, "width": H}
+        return c["x3"]
+
+    def _encoder_x3(self, f2d: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """VisualModel.forward on split operands: ONE C call (csrc/joint_x3.hip) issues the embeddings and both blocks."""
+        x3, lib = self._x3(), _lib.load()
+        need = lib.hirest_joint_encoder_x3_workspace_bytes(C.byref(x3["desc"]), B, T)
+        if need == 0:
+            raise RuntimeError("hirest_joint_encoder_x3: unsupported encoder shape")
+        ws = x3.get("ws")
+        if ws is None or ws.numel() < need or ws.device != f2d.device:
+            ws = x3["ws"] = torch.empty((need,), dtype=torch.uint8, device=f2d.device)
+        out = torch.empty((B * T, x3["width"]), dtype=torch.float32, device=f2d.device)
+        _lib.check(lib.hirest_joint_encoder_x3_forward(C.byref(x3["desc"]), f2d.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                       ops.stream_ptr()), "hirest_joint_encoder_x3_forward")
+        return out
+
     # ------------------------------------------------------------------ kernels
     @staticmethod
     def _gemm(a, w, bias, out=None, resid=None, periodic=None, period=0, act=0):
@@ -311,7 +379,7 @@ class MomentModel(nn.Module):
                                              boundary_mask_i32.data_ptr() if boundary_mask_i32 is not None else None,
                                              c["mask_embed.weight"].data_ptr(), c["boundary_embed.weight"].data_ptr(),
                                              f.data_ptr(), B * T, 512, ops.stream_ptr()), "hirest_joint_mask_add")
-        return self._encoder(f, B, T)
+        return self._encoder_x3(f, B, T) if self.precision == "bf16x3" else self._encoder(f, B, T)
 
     def _heads(self, feats, which: List[str]) -> torch.Tensor:
         c, lib = self._w(), _lib.load()

@@ -104,11 +104,16 @@ typedef struct hirest_gemm_args {
                                              output, and the next qkv reads fc2's) */
 } hirest_gemm_args;
 enum { HIREST_GEMM_REVERSE = 1,
-       HIREST_GEMM_X3 = 2      /* "bf16x3": A and W are fp32 matrices split by hirest_split2_bf16 ([rows, 2K] bf16, each block of 64 columns
+       HIREST_GEMM_X3 = 2,     /* "bf16x3": A and W are fp32 matrices split by hirest_split2_bf16 ([rows, 2K] bf16, each block of 64 columns
                                 * = hi parts of 32 consecutive k | their lo parts), K = 2 x the real depth; the kernel adds W_hi A_lo + W_lo A_hi
                                 * + W_hi A_hi per 32 k in fp32 (products carry ~16 mantissa bits at 3 bf16 MFMAs each).  Epilogues
                                 * HIREST_EPI_BIAS_F32 / HIREST_EPI_BIAS_RESID_F32 (+ GELU_SPLIT2); the persistent ping-pong kernel, or — for
                                 * problems of fewer than 256 tiles of 256 x 256 — an 8-wave 128 x 128 kernel (gemm_t128x3). */
+       HIREST_GEMM_X3_T128 = 4 /* with HIREST_GEMM_X3: the 128 x 128 kernel at every size and for HIREST_EPI_BIAS_GELU_SPLIT2 as well — the joint
+                                * model's products (1 500 ... 10 000 rows, 768 ... 3 072 wide) are a few hundred such tiles, which fill the 256
+                                * CUs better than 256 x 256 tiles do (hirest_joint_encoder_x3_forward).  With HIREST_EPI_BIAS_RESID_F32, fewer
+                                * than 32 row panels and aux0 != NULL (aux1 NULL), aux0 is fp32 scratch of >= 4 M N floats and the K range of a
+                                * tile may be cut into up to 4 slices that run on different CUs (partial tiles added in slice order). */
      };
 
 int hirest_gemm_bf16(const hirest_gemm_args* args, void* stream);
@@ -782,6 +787,42 @@ typedef struct hirest_prof_record {
 } hirest_prof_record;
 int hirest_profile_enable(int32_t on);                 /* also discards pending records */
 int hirest_profile_collect(hirest_prof_record* out, int32_t max_records); /* returns count (<0 on error) */
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Joint model, second precision (round 6): the VisualModel encoder of modeling.py:196-211 / module_visual.py:104-264,396-424 with every
+ * linear layer's product on split operands (HIREST_GEMM_X3: bf16 hi + lo of both fp32 operands, three bf16 MFMAs per product, fp32
+ * accumulation — ~16-bit products), everything else as the fp32 path runs it: exact-fp32 attention with the reference's uniform -10000
+ * shift, fp32 LayerNorm (TF style, eps inside the root), erf-GELU in fp32, fp32 residual adds.  The reference's own reduced-precision mode
+ * is torch.cuda.amp.autocast() under --fp16 (run.py:549-551); this one keeps 16 significand bits in the products, so indices, boundary
+ * lists and token ids stay those of the fp32 run (tests/test_gpu_joint.py gates them on every real-reference golden).
+ * Weights are split once per checkpoint with hirest_split2_bf16 ([N, K] fp32 -> [N, 2K] bf16); activations are split by the kernel that
+ * produces them (LayerNorm writes fp32 + split, the GELU epilogue writes split only), the attention output by one extra pass.
+ * One C call = embeddings GEMM + position rows + LayerNorm + `layers` post-LN blocks (8 launches per block) on rows = B * T. */
+typedef struct hirest_joint_layer_x3 {
+    const hirest_bf16* qkv_w2; const float* qkv_b;        /* [3 width, 2 width] split (query | key | value rows), bias [3 width]            */
+    const hirest_bf16* ao_w2;  const float* ao_b;         /* attention.output.dense [width, 2 width]                                       */
+    const float* ln1_g; const float* ln1_b;               /* attention.output.LayerNorm                                                    */
+    const hirest_bf16* fc1_w2; const float* fc1_b;        /* intermediate.dense [mlp_dim, 2 width] (+ erf-GELU)                            */
+    const hirest_bf16* fc2_w2; const float* fc2_b;        /* output.dense [width, 2 mlp_dim]                                               */
+    const float* ln2_g; const float* ln2_b;               /* output.LayerNorm                                                              */
+} hirest_joint_layer_x3;
+typedef struct hirest_joint_encoder_x3 {
+    uint64_t struct_size;
+    int32_t layers, heads, width, mlp_dim, in_dim, max_pos;
+    float ln_eps, attn_shift;                             /* 1e-12, -10000 (module_visual.py:404-406: the all-ones mask's uniform shift)    */
+    const hirest_bf16* emb_w2; const float* emb_b;        /* embeddings.word_embeddings (a Linear) [width, 2 in_dim]                       */
+    const float* pos;                                     /* embeddings.position_embeddings [max_pos, width]                               */
+    const float* emb_ln_g; const float* emb_ln_b;
+    const hirest_joint_layer_x3* layer;                   /* HOST array [layers]                                                           */
+} hirest_joint_encoder_x3;
+size_t hirest_joint_encoder_x3_workspace_bytes(const hirest_joint_encoder_x3* e, int32_t B, int32_t T);
+/* f fp32 [B*T, in_dim] (hirest_joint_mask_add's output) -> out fp32 [B*T, width] */
+int hirest_joint_encoder_x3_forward(const hirest_joint_encoder_x3* e, const float* f, int32_t B, int32_t T, float* out,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+/* LayerNorm over the last dim (hirest_layernorm's arithmetic) of x[r] (+ add[r % period] when add != NULL) written as fp32 (out32, may be
+ * NULL) and / or in the split operand format (out2 [rows, >= 2 D] bf16, may be NULL). */
+int hirest_layernorm_f32_split2(const float* x, int64_t ldx, const float* add, int32_t period, const float* gamma, const float* beta, float eps,
+                                float* out32, int64_t ldo32, hirest_bf16* out2, int64_t ldo2, int32_t rows, int32_t D, void* stream);
 
 #ifdef __cplusplus
 }

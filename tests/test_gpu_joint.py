@@ -191,8 +191,11 @@ def _case(golden_dir, case):
 
 
 # c*: SURVEY 8d C4 sizes (B = 5; c300 = the notebook's own operating point), d300: args.py:27's default eval batch of 32; real-reference goldens
+# precision: 'bf16x3' = the encoder's linear layers on split operands (csrc/joint_x3.hip, MomentModel.set_precision) — the same gates: logits
+# within 2e-3, frame indices and boundary lists EXACT on every real-reference golden
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", ["a", "b", "c120", "c300", "c571", "c1855", "d300"])
-def test_moment_model_vs_reference(dev, golden_dir, case):
+def test_moment_model_vs_reference(dev, golden_dir, case, precision):
     import hirest_amd
     shapes, pred, g, (vis, asr, text, vis_mask, moment_mask, bounds) = _case(golden_dir, case)
     sd = synth.joint_state_dict(shapes, 31)
@@ -204,7 +207,7 @@ def test_moment_model_vs_reference(dev, golden_dir, case):
     model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=Args(), clip_model=None)
     res = model.load_state_dict(sd, strict=False)
     assert not res.missing_keys                                   # every parameter we own is in the reference schema
-    model = model.to(dev).eval()
+    model = model.to(dev).eval().set_precision(precision)
     B, T = pred["B"], pred["T"]
     out = model.forward_moment_retrieval(vis.to(dev), text.to(dev), vis_mask.to(dev), moment_mask.to(dev), asr.to(dev))
     rows = list(g["rows"])
@@ -227,8 +230,9 @@ def test_moment_model_vs_reference(dev, golden_dir, case):
 
 # c3 / c5: BASELINE configs[4]'s own operating point (B = 5, beam 3 / 5); d3 / d5: the reference's default evaluation batch
 # (args.py:27 --eval_batch_size 32: 96 / 160 beam rows per word, all three trim branches in one batch)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", ["a", "b", "c3", "c5", "d3", "d5"])
-def test_step_captioning_vs_reference(dev, golden_dir, case):
+def test_step_captioning_vs_reference(dev, golden_dir, case, precision):
     """BASELINE configs[4] in miniature: trim_feats + encoder + beam-searched decoder; token ids exact vs the
     REAL reference MomentModel.test_step (tests/golden/caption_predictions.json)."""
     import hirest_amd
@@ -245,7 +249,7 @@ def test_step_captioning_vs_reference(dev, golden_dir, case):
         moment_mask[b, 5 + b:5 + b + pred["lens"][b]] = 1
     model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
     model.load_state_dict(sd, strict=False)
-    model = model.to(dev).eval()
+    model = model.to(dev).eval().set_precision(precision)
     trimmed = model._trim(vis.to(dev), moment_mask.to(dev), 20)
     assert np.array_equal(trimmed[:, [0, 7, 19]].cpu().numpy(), g["trimmed_rows"])
     batch = {"tasks": ["step_captioning"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask,

@@ -12,7 +12,9 @@ dev = torch.device("cuda:0")
 model = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
 model.load_state_dict(sd, strict=False)
 model = model.to(dev).eval()
-B, T = 5, 300
+if os.environ.get("JOINT_PRECISION"):
+    model.set_precision(os.environ["JOINT_PRECISION"])
+B, T = int(os.environ.get("JOINT_B", "5")), 300
 vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs(f"jb.{T}", B, T, 43)
 task = sys.argv[1] if len(sys.argv) > 1 else "moment_segmentation"
 batch = {"tasks": [task], "vis_feats": vis.to(dev), "vis_mask": vis_mask.to(dev), "asr_feats": asr.to(dev), "text_feat": text.to(dev),

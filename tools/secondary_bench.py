@@ -133,6 +133,28 @@ def measure(dev=None, cpu=True, log=lambda m: None):
                                       "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                    "frac": flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_batch": flops}}
 
+    # ---- the same four figures with the encoder's linear layers on split operands (MomentModel.set_precision('bf16x3'), csrc/joint_x3.hip:
+    # three bf16 MFMAs per product; the reference's counterpart is autocast under --fp16, run.py:549-551).  Rooflines against the dense bf16
+    # peak / 3 on the same ALGORITHMIC flops; indices / boundary lists compared with the real reference's.
+    log("secondary: moment retrieval / segmentation, bf16x3 encoder")
+    model.set_precision("bf16x3")
+    try:
+        for key, batch, n, reps, gold, iters in (
+                ("moment_retrieval", bmr, B, 20, jgold5["pred_moment_retrieval"], 1),
+                ("moment_segmentation", bsg, B, 5, jgold5["pred_segmentation"], 20),
+                ("moment_retrieval_b32", dict(c32, tasks=["moment_retrieval"], moment_mask=g(dmm)), B32, 10, jgold["pred_moment_retrieval"], 1),
+                ("moment_segmentation_b32", dict(c32, tasks=["moment_segmentation"], moment_bound_frames=dbounds), B32, 3, jgold["pred_segmentation"], 20)):
+            dt, pred = _timeit(lambda: model.test_step(batch)["prediction"], reps, sync)
+            flops = n * T * (fusion_flops_per_token() + iters * (encoder_flops_per_token(T) + (2 * 2 * H if iters == 1 else 2 * H)))
+            out[key + "_bf16x3"] = {"value": n / dt, "unit": "videos/s", "ms_per_batch": dt * 1e3, "batch": n, "iterations": iters,
+                                    "speedup_vs_fp32": (n / dt) / out[key]["value"],
+                                    "predictions_equal_real_reference": bool(pred == gold),
+                                    "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 2500.0 / 3, "unit": "TFLOP/s",
+                                                 "frac": flops / dt / 1e12 / (2500.0 / 3), "algorithmic_flops_per_batch": flops,
+                                                 "note": "peak = dense bf16 MFMA peak / 3: every product of the encoder's linear layers costs three bf16 MFMAs"}}
+    finally:
+        model.set_precision("fp32")
+
     # ---- step captioning (BASELINE configs[4]; modeling.py:556-632) at its own operating point: B = 5, 15-frame
     # moments -> 20 trimmed frames, 48 words, on the inputs of the real-reference goldens tests/golden/caption_predictions.json
     # cases c3 / c5 (make_golden.py gen_caption: the REAL MomentModel.test_step), so ALL FIVE captions of the timed batch are
