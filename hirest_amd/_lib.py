@@ -96,7 +96,7 @@ class CaptionDecoder(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("layers", "heads", "hidden", "inter", "vocab_padded", "max_pos")] + \
                [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "emb_ln_g", "emb_ln_b")] + \
                [("layer", C.POINTER(CaptionLayer))] + \
-               [(n, C.c_void_p) for n in ("tr_w", "tr_b", "tr_ln_g", "tr_ln_b", "lm_w", "lm_b")]
+               [(n, C.c_void_p) for n in ("tr_w", "tr_b", "tr_ln_g", "tr_ln_b", "lm_w", "lm_b", "lm_w2")]
 
 
 class JointLayerX3(C.Structure):

@@ -362,7 +362,18 @@ static int decode_step(const hirest_caption_decoder* d, int32_t R, int32_t posit
                               D, 1, stream));
         // LM head with the transform's LayerNorm as its prologue (persistent blocks: the rows are normalised once per CU); for the
         // one-call beam step it also leaves the maxima of its 16-column tiles for the tail
-        if (R > 32 && d->vocab_padded >= 8192) {
+        if (R >= 64 && d->vocab_padded >= 8192 && d->lm_w2 && D % 32 == 0) {
+            // split-operand LM head (MomentModel.set_precision('bf16x3')): LayerNorm straight into the split format (the dead `mid` rows hold
+            // it), then the 128 x 128 split-operand GEMM over [R, vocab]; the tail scans the rows itself (no tile maxima from this kernel)
+            hirest_bf16* b2 = reinterpret_cast<hirest_bf16*>(mid);
+            CK(hirest_layernorm_f32_split2(x, D, nullptr, 0, d->tr_ln_g, d->tr_ln_b, eps, nullptr, 0, b2, 2 * D, R, D, stream));
+            hirest_gemm_args g;
+            g.struct_size = sizeof(g);
+            g.A = b2; g.lda = 2 * D; g.W = d->lm_w2; g.ldw = 2 * D; g.bias = d->lm_b; g.out = logits; g.ldo = d->vocab_padded;
+            g.M = R; g.N = d->vocab_padded; g.K = 2 * D; g.epilogue = HIREST_EPI_BIAS_F32; g.pos = nullptr; g.patches_per_frame = 0;
+            g.aux0 = g.aux1 = nullptr; g.flags = HIREST_GEMM_X3 | HIREST_GEMM_X3_T128;
+            CK(hirest_gemm_bf16(&g, stream));
+        } else if (R > 32 && d->vocab_padded >= 8192) {
             // a merged search (60 - 160 beam rows): by now a compute problem — LayerNorm once, then the row-group streaming product
             // with five row tiles per wave (its LayerNorm-prologue form holds three), which also leaves the tile maxima for the tail
             CK(hirest_layernorm(x, D, nullptr, d->tr_ln_g, d->tr_ln_b, eps, b, D, 1, R, D, stream));

@@ -239,7 +239,7 @@ class MomentModel(nn.Module):
             c[Dp + "embeddings.LayerNorm.weight"].data_ptr(), c[Dp + "embeddings.LayerNorm.bias"].data_ptr(), layers,
             c[cp + "transform.dense.weight"].data_ptr(), c[cp + "transform.dense.bias"].data_ptr(),
             c[cp + "transform.LayerNorm.weight"].data_ptr(), c[cp + "transform.LayerNorm.bias"].data_ptr(),
-            c["lm_w"].data_ptr(), c["lm_b"].data_ptr())
+            c["lm_w"].data_ptr(), c["lm_b"].data_ptr(), None)
         c["head_bias"] = torch.cat([f(getattr(m, "0").bias) for m in
                                     (self.start_predictor, self.end_predictor, self.segment_predictor)]).contiguous()
         for lay in self.clip4cap_model.visual.encoder.layer:
@@ -289,8 +289,17 @@ class MomentModel(nn.Module):
                                    c[V + "embeddings.word_embeddings.weight"].shape[1], pos.shape[0], 1e-12, -10000.0,
                                    emb.data_ptr(), c[V + "embeddings.word_embeddings.bias"].data_ptr(), pos.data_ptr(),
                                    c[V + "embeddings.LayerNorm.weight"].data_ptr(), c[V + "embeddings.LayerNorm.bias"].data_ptr(), layers)
-        c["x3"] = {"desc": desc, "layers": layers, "keep": keep, "width": H}
+        # the caption decoder's descriptor with the LM head's weights in the split format as well (csrc/caption.hip takes them at >= 64 rows)
+        lm2 = split(c["lm_w"])
+        keep.append(lm2)
+        d0 = c["dec_desc"]
+        dec = _lib.CaptionDecoder(*[getattr(d0, n) for n, _ in _lib.CaptionDecoder._fields_[:-1]], lm2.data_ptr())
+        c["x3"] = {"desc": desc, "layers": layers, "keep": keep, "width": H, "dec_desc": dec}
         return c["x3"]
+
+    def _dec_desc(self):
+        """The C-side decoder descriptor of the current precision ('bf16x3': with the split LM head)."""
+        return self._x3()["dec_desc"] if self.precision == "bf16x3" else self._w()["dec_desc"]
 
     def _encoder_x3(self, f2d: torch.Tensor, B: int, T: int) -> torch.Tensor:
         """VisualModel.forward on split operands: ONE C call (csrc/joint_x3.hip) issues the embeddings and both blocks."""
@@ -608,7 +617,7 @@ class MomentModel(nn.Module):
         dev = c["dev"]
         B, F = enc_kv_all[0].shape[0], enc_kv_all[0].shape[1]
         R, nl, Dm = B * num_beams, len(enc_kv_all), 768
-        desc = c["dec_desc"]
+        desc = self._dec_desc()
         Vp = desc.vocab_padded
         enc = [kv.repeat_interleave(num_beams, 0).contiguous() for kv in enc_kv_all]             # [R, F, 1536], loop invariant
         enc_ptrs = (C.c_void_p * nl)(*[e.data_ptr() for e in enc])
@@ -701,11 +710,11 @@ class MomentModel(nn.Module):
         from .beam import BOS_ID
         c, lib = self._w(), _lib.load()
         ctxs = c.setdefault("caption_graphs", {})           # lives and dies with the weight cache: the graphs hold its pointers
-        key = (B, num_beams, max_words, F, nl, slot)
+        key = (B, num_beams, max_words, F, nl, slot, self.precision)      # (a captured graph holds the descriptor of its precision)
         ctx = ctxs.get(key)
         if ctx is not None:
             return ctx
-        dev, desc = c["dev"], c["dec_desc"]
+        dev, desc = c["dev"], self._dec_desc()
         R, Dm, Vp = B * num_beams, 768, desc.vocab_padded
         nt = B * max_words * num_beams
         add0 = torch.full((B, num_beams), -3.0e38, dtype=torch.float32)
@@ -739,7 +748,7 @@ class MomentModel(nn.Module):
         ids, parents = ibuf[2 * nt + 2 * B:2 * nt + 2 * B + R], ibuf[2 * nt + 2 * B + R:]
         add, scores = fbuf[:R], fbuf[R:]
         _lib.check(lib.hirest_caption_beam_step(
-            C.byref(c["dec_desc"]), B, num_beams, t - 1, ids.data_ptr(), parents.data_ptr(), ctx["ptrs"][t & 1] if t > 1 else None,
+            C.byref(self._dec_desc()), B, num_beams, t - 1, ids.data_ptr(), parents.data_ptr(), ctx["ptrs"][t & 1] if t > 1 else None,
             ctx["ptrs"][(t + 1) & 1], ctx["enc_ptrs"], F, add.data_ptr(), ctx["logp"].data_ptr(), max_words, EOS_ID, scores.data_ptr(),
             tokens.data_ptr(), backptr.data_ptr(), n_steps.data_ptr(), done.data_ptr(), ctx["done_rows"][t - 1].data_ptr(),
             ctx["ws"].data_ptr(), ctx["ws"].numel(), ctx["tail_ws"].data_ptr(), ctx["tail_ws"].numel(), st), "hirest_caption_beam_step")

@@ -556,6 +556,11 @@ typedef struct hirest_caption_decoder {
     const hirest_caption_layer* layer;                              /* HOST array [layers] */
     const float* tr_w; const float* tr_b; const float* tr_ln_g; const float* tr_ln_b;     /* cls.predictions.transform */
     const float* lm_w; const float* lm_b;                           /* [vocab_padded, D] (tied to word_emb), [vocab_padded] */
+    const hirest_bf16* lm_w2;                                       /* optional (ABI 4): lm_w in the split operand format [vocab_padded, 2 D]
+                                                                     * (hirest_split2_bf16).  When set, steps of >= 64 rows run the LM head on
+                                                                     * split operands (three bf16 MFMAs per product: 84.8 us of a 329-us word were
+                                                                     * on the 1/16-rate fp32 MFMA at 160 rows); below that the product is bound by
+                                                                     * the weight stream and stays exact fp32.  NULL: exact fp32 at every size. */
 } hirest_caption_decoder;
 size_t hirest_caption_step_workspace_bytes(const hirest_caption_decoder* d, int32_t R);
 /* R beams (rows).  position = index of the newest token (0 for [CLS]).  kv_in / kv_out: HOST arrays of 2 * layers device buffers

@@ -249,6 +249,17 @@ def measure(dev=None, cpu=True, log=lambda m: None):
                                  "enough to stop the search); the word is matrix-pipe time at this size: see mfma_f32",
                          "mfma_f32": {"achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MFMA_PEAK_TFLOPS,
                                       "note": "2 x weights x beam rows per word (attention and the tail not counted), exact-fp32 MFMA"}}}
+        # the same B = 32 batch with the encoder pass and the LM head (>= 64 beam rows) on split operands (MomentModel.set_precision('bf16x3'))
+        model.set_precision("bf16x3")
+        try:
+            dtx, rx = _timeit(lambda: model.test_step(bd, num_beams=beams, return_ids=True), 3, sync)
+        finally:
+            model.set_precision("fp32")
+        out[f"step_captioning_beam{beams}_b32_bf16x3"] = {
+            "value": dB / dtx, "unit": "captions/s", "ms_per_batch": dtx * 1e3, "beam": beams, "max_words": 48, "batch": dB, "beam_rows": dB * beams,
+            "speedup_vs_fp32": dtd / dtx,
+            "how": "as step_captioning_beamN_b32, LM head of every word (and the encoder pass) as three bf16 MFMAs per product; decoder layers exact fp32",
+            "token_ids_equal_real_reference": f"{sum(int(list(a) == b) for a, b in zip(rx['token_ids'], wantd))} of {len(wantd)} captions"}
     with torch.no_grad():
         sep_bias.copy_(sep_saved)
 
