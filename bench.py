@@ -215,6 +215,47 @@ def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def _cpu_probe_child(threads: int, frames: int = 2, layers: int = 2):
+    """Child process of cpu_baseline's pinned probes (python bench.py --cpu-probe N, started with OMP_NUM_THREADS=N OMP_PROC_BIND=close
+    OMP_PLACES=cores): the oracle's tower on `layers` of the 40 identical blocks, random weights (the time does not depend on the values),
+    extrapolated to 40 blocks.  Prints one JSON line."""
+    import copy
+    from oracle import ref_cpu
+    from hirest_amd import synth
+    torch.set_num_threads(threads)
+    cfg = copy.deepcopy(synth.EVA_CLIP_G_14)
+    L = cfg["vision_cfg"]["layers"]
+    cfg["vision_cfg"]["layers"] = layers
+    sd = synth.eva_clip_state_dict(cfg, 3, towers=("visual",))
+    x = torch.randn(frames, 3, 224, 224)
+    with torch.no_grad():
+        ref_cpu.eva_encode_image(sd, x[:1], cfg)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ref_cpu.eva_encode_image(sd, x, cfg)
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    print(json.dumps({"threads": threads, "frames_per_s": frames / (dt * L / layers), "seconds_for_the_probe": sum(times),
+                      "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "omp_places": os.environ.get("OMP_PLACES")}), flush=True)
+
+
+def _pinned_probe(threads: int, timeout_s: float = 150.0):
+    """cpu_baseline at `threads` OpenMP threads bound close to each other (one per core): a 2-block probe in a fresh process, because the
+    binding has to be in the environment before the OpenMP runtime starts."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(threads)], capture_output=True, text=True,
+                           timeout=timeout_s, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if r.returncode == 0 and line else {"threads": threads, "error": (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"threads": threads, "error": f"timed out after {timeout_s:.0f} s"}
+
+
 def cpu_baseline(model, frames, cfg, n):
     """The fp32 CPU oracle (oracle/ref_cpu.py, torch CPU; kind "port") on the first n frames of the same batch.
     Reported at three thread counts: 32, os.cpu_count() and 1.  Only the 32-thread figure is a full measurement
@@ -272,6 +313,15 @@ def cpu_baseline(model, frames, cfg, n):
         _log("cpu baseline: probing 1 thread on 2 blocks")
         one = probe(1)
         by_threads["1"] = {"frames_per_s": one, "how": "extrapolated from a 2-block probe of one frame"}
+        # 64 / 128 threads with OMP_PROC_BIND=close OMP_PLACES=cores: fresh processes, 2-block probes.  `value` stays
+        # the best FULL measurement; a pinned probe that beats it is reported beside it, labelled as what it is.
+        for t in (64, 128):
+            if t < ncpu:
+                _log(f"cpu baseline: {t} threads pinned (OMP_PROC_BIND=close), 2-block probe in a child process")
+                pr = _pinned_probe(t)
+                by_threads[f"{t}_pinned"] = ({"frames_per_s": pr["frames_per_s"], "how": "extrapolated from a 2-block probe (2 frames, 3 passes, median) in a "
+                                              "child process with OMP_PROC_BIND=close OMP_PLACES=cores", "beats_the_32_thread_measurement": pr["frames_per_s"] > rate32}
+                                             if "frames_per_s" in pr else {"error": pr.get("error")})
     torch.set_num_threads(base_threads)
     # same kernels as the timed path: tower calls of >= 64 frames fold the LayerNorms into the GEMMs, so encode 64+ and keep n
     gpu_out = model.encode_image(frames.reshape(-1, 3, 224, 224)[:max(n, 64)])[:n].float().cpu()
@@ -287,6 +337,7 @@ def cpu_baseline(model, frames, cfg, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cpu-probe", type=int, default=0, help="internal: child process of cpu_baseline's pinned thread-count probes")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
@@ -305,6 +356,9 @@ def main():
                     "so the N-rank code path — launcher, timing protocol, gather, rank-0 report — runs on a one-GPU box.  The line is marked INVALID")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="hirest_gemm_debug_mode bits: TIMING EXPERIMENTS ONLY, the line is not a valid result")
     args = ap.parse_args()
+    if args.cpu_probe > 0:
+        _cpu_probe_child(args.cpu_probe)
+        return
 
     if args.frames % FRAMES_PER_VIDEO != 0:
         raise SystemExit(f"--frames must be a multiple of {FRAMES_PER_VIDEO} (whole videos): a remainder would be counted "

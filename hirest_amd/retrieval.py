@@ -155,10 +155,23 @@ class FrameSource:
     corpus larger than memory (4096 x 32 frames = 39 GB in bf16) is streamed: ``videos_per_call`` videos are requested,
     encoded in one tower call and pooled before the next block is produced."""
 
-    def __init__(self, video_ids: Sequence[str], frames, videos_per_call: int = 32):
+    def __init__(self, video_ids: Sequence[str], frames, videos_per_call: int = 32, min_frames_per_call: int = 256):
         self.video_ids = list(video_ids)
         self.frames = frames
         self.videos_per_call = max(1, int(videos_per_call))
+        # a tower call of a few dozen frames loses up to a fifth of its throughput to tile quantisation (bench `tower_small_calls`: 64 frames
+        # 1780, 256 frames 1970 frames/s), so short videos are grouped until a call holds at least this many frames (0: exactly videos_per_call)
+        self.min_frames_per_call = max(0, int(min_frames_per_call))
+        self._frames_per_video = None
+
+    def _per_call(self, n_model_frames: Optional[int], device) -> int:
+        """Videos per tower call: videos_per_call, raised so that a call holds >= min_frames_per_call frames."""
+        if self.min_frames_per_call <= 0 or not self.video_ids:
+            return self.videos_per_call
+        F = n_model_frames if (n_model_frames is not None and n_model_frames > 0) else self._frames_per_video
+        if F is None:
+            F = self._frames_per_video = int(self._block(0, 1, device).shape[1])
+        return max(self.videos_per_call, -(-self.min_frames_per_call // max(1, int(F))))
 
     def _block(self, lo, hi, device):
         blk = self.frames(lo, hi) if callable(self.frames) else self.frames[lo:hi]
@@ -166,8 +179,9 @@ class FrameSource:
 
     def pooled_rows(self, model, lo: int, hi: int, n_model_frames: Optional[int], device) -> torch.Tensor:
         rows = []
-        for s in range(lo, hi, self.videos_per_call):
-            blk = self._block(s, min(hi, s + self.videos_per_call), device)
+        per = self._per_call(n_model_frames, device)
+        for s in range(lo, hi, per):
+            blk = self._block(s, min(hi, s + per), device)
             if n_model_frames is not None and n_model_frames > 0 and blk.shape[1] != n_model_frames:
                 # VideoFramesDataset.__getitem__ subsamples the decoded frames to n_model_frames (:36-44)
                 ids = torch.from_numpy(subsample_ids(blk.shape[1], n_model_frames)).to(device)
@@ -194,8 +208,9 @@ def _frame_source_rows_of(self, model, ids: Sequence[int], n_model_frames: Optio
     fall back to one small tower call per video."""
     rows = []
     ids = [int(v) for v in ids]
-    for s in range(0, len(ids), self.videos_per_call):
-        parts = [self._block(lo, hi, device) for lo, hi in _id_runs(ids[s:s + self.videos_per_call])]
+    per = self._per_call(n_model_frames, device)
+    for s in range(0, len(ids), per):
+        parts = [self._block(lo, hi, device) for lo, hi in _id_runs(ids[s:s + per])]
         blk = torch.cat(parts) if len(parts) != 1 else parts[0]
         if n_model_frames is not None and n_model_frames > 0 and blk.shape[1] != n_model_frames:
             sel = torch.from_numpy(subsample_ids(blk.shape[1], n_model_frames)).to(device)

@@ -162,8 +162,15 @@ def test_frame_source_subsamples_like_the_frame_dataset():
     orig = retrieval.encode_videos
     try:
         retrieval.encode_videos = lambda model, blk: (calls.append(blk.clone()), blk[:, :, 0, 0, 0].mean(1, keepdim=True).expand(-1, 4))[1]
-        src = retrieval.FrameSource([f"v{i}" for i in range(6)], lambda lo, hi: frames[lo:hi], videos_per_call=4)
+        src = retrieval.FrameSource([f"v{i}" for i in range(6)], lambda lo, hi: frames[lo:hi], videos_per_call=4, min_frames_per_call=0)
         rows = retrieval.corpus_block_rows(M(), src, 0, 1, n_model_frames=4, device="cpu")
+        # default: short videos are grouped until a tower call holds >= 256 frames (here: all 6 videos x 4 frames in one call)
+        grouped = retrieval.FrameSource([f"v{i}" for i in range(6)], lambda lo, hi: frames[lo:hi], videos_per_call=4)
+        assert grouped._per_call(4, "cpu") == 64 and grouped._per_call(None, "cpu") == 26      # ceil(256 / 4), ceil(256 / 10 decoded frames)
+        n_before = len(calls)
+        rows_g = retrieval.corpus_block_rows(M(), grouped, 0, 1, n_model_frames=4, device="cpu")
+        assert [c.shape[0] for c in calls[n_before:]] == [6] and torch.equal(rows_g, rows)
+        calls = calls[:n_before]
     finally:
         retrieval.encode_videos = orig
     assert [c.shape[0] for c in calls] == [4, 2] and all(c.shape[1] == 4 for c in calls)
@@ -246,7 +253,11 @@ def test_gpu_c3_eight_rank_blocks_equal_the_single_sweep():
     blocks = [retrieval.corpus_block_rows(model, src, r, 8, F) for r in range(8)]
     assert [b.shape[0] for b in blocks] == [64] * 8
     rows8 = torch.cat(blocks)
-    assert torch.equal(rows8, one.video_rows)
+    if not torch.equal(rows8, one.video_rows):                       # say WHICH videos (a call holds 32) and by how much before failing
+        bad = (rows8 != one.video_rows).any(dim=1).nonzero().flatten().tolist()
+        again = torch.cat([retrieval.corpus_block_rows(model, src, r, 8, F) for r in range(8)])
+        pytest.fail(f"rank blocks != single sweep in {len(bad)} videos {bad[:24]}, max |d| {(rows8 - one.video_rows).abs().max().item():.3e}; "
+                    f"a third sweep equals the second: {torch.equal(again, rows8)}, the first: {torch.equal(again, one.video_rows)}")
     eight = retrieval.score_corpus(one.text_rows, rows8, ids, prompts)
     assert torch.equal(eight.scores, one.scores) and dict(eight) == dict(one)
     _, i1 = one.topk(10)
