@@ -186,12 +186,19 @@ __global__ __launch_bounds__(256, 2) void gemm_t128(GemmP p) { t128_body<EPI>(p)
 // out = (sum over chunk-0 terms) + (sum over chunk-1 terms), a fixed order.
 // (Round 4 also had a K-step-blocked operand layout for this kernel, HIREST_GEMM_KBLOCKED, for the training step's split-operand path; both
 // were measured slower end to end and removed in round 5: profiles/r04/train_x3_ab.txt.)
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
+// WM = wave rows of a group: 2 -> 128 x 128 tiles (8 waves), 3 -> 192 x 128 tiles (12 waves, 160 KiB of ring) for the shapes whose 128-row
+// panels waste a round: the 160 beam rows of a B = 32 beam-5 LM head (2 x 239 tiles = two rounds, 37 % of them padding -> 239 tiles, one round)
+// and the joint encoder's 3072-wide layer at 1 500 rows (288 tiles -> 192).  Same arithmetic per output element: the tile height does not enter
+// the k order.
+template <int EPI, int WM = 2>
+__global__ __launch_bounds__(256 * WM) void gemm_t128x3(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = 4;
+    constexpr int BMX = 64 * WM, NWG = 2 * WM;                    // tile rows; waves per K group
+    constexpr int STAGE = (BMX + BN) * BK * 2;                    // 32 / 40 KiB per ring slot
+    constexpr int NPIECE = (BMX + BN) / 8;                        // 1-KiB LDS-DMA pieces per step: A first, then W; piece j belongs to wave j / 4
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave >> 2, w4 = wave & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave / NWG, w4 = wave - kg * NWG;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
     int nt, mt, slice = 0;
@@ -215,23 +222,27 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
         int gcount = np - grp * GROUP_M; gcount = gcount > GROUP_M ? GROUP_M : gcount;
         nt = r / gcount; mt = p_lo + grp * GROUP_M + (r - nt * gcount);
     }
-    const int M0 = mt * BM, N0 = nt * BN;
+    const int M0 = mt * BMX, N0 = nt * BN;
 
-    // staging: waves 0-3 bring the 16 A pieces (8 rows x 128 B each), waves 4-7 the 16 W pieces
+    // staging: piece j = 4 wave + q (8 rows x 128 B): the first BMX / 8 pieces are A rows, the rest W rows; waves past the last piece (WM = 3:
+    // waves 10, 11) bring nothing — a wave's counted wait covers its own pieces, the barrier everybody's
     const bf16_t* src[4];
+    const bool stager = wave * 4 < NPIECE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int row = (w4 * 4 + q) * 8 + (lane >> 3);
+        const int pj = wave * 4 + q, row = (pj < BMX / 8 ? pj : pj - BMX / 8) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        if (kg == 0) { int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1; src[q] = p.A + (int64_t)gm * p.lda + chunk * 8; }
+        if (pj < BMX / 8) { int gm = M0 + row; gm = gm < p.M ? gm : p.M - 1; src[q] = p.A + (int64_t)gm * p.lda + chunk * 8; }
         else { int gn = N0 + row; gn = gn < p.N ? gn : p.N - 1; src[q] = p.W + (int64_t)gn * p.ldw + chunk * 8; }
         src[q] += (int64_t)slice * ((p.K / BK) / p.ksplit) * BK;
     }
+    static_assert(NPIECE % 4 == 0, "whole waves of four pieces");
     const int64_t kstep = BK;
     auto stage = [&](int slot, int kt) {
-        char* dst = smem + slot * STAGE_BYTES + (kg ? BM * BK * 2 : 0);
+        if (!stager) return;
+        char* dst = smem + slot * STAGE;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(src[q] + (int64_t)kt * kstep, dst + (w4 * 4 + q) * 1024);
+        for (int q = 0; q < 4; ++q) glds16(src[q] + (int64_t)kt * kstep, dst + (wave * 4 + q) * 1024);
     };
     const int wm = w4 >> 1, wn = w4 & 1;
     const int frow = lane & 31, fsw = (frow >> 1) & 7, khalf = lane >> 5;
@@ -258,8 +269,8 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // step kt landed everywhere; everyone is done reading step kt - 1
         if (kt + NST - 1 < nk && !(p.dbg & 1)) stage((kt + NST - 1) % NST, kt + NST - 1);
-        const char* As = smem + (kt % NST) * STAGE_BYTES;
-        const char* Ws = As + BM * BK * 2;
+        const char* As = smem + (kt % NST) * STAGE;
+        const char* Ws = As + BMX * BK * 2;
         bf16x8 af[2][2], wf[2][2];                             // [tile][0 hi, 1 lo]
         if (!(p.dbg & 8)) {
 #pragma unroll
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(512) void gemm_t128x3(GemmP p) {
             __builtin_amdgcn_s_setprio(0);
         }
     }
-    // ---- group 1 -> group 0 through LDS: [w4][tile][reg][lane] fp32 = 64 KiB
+    // ---- group 1 -> group 0 through LDS: [w4][tile][reg][lane] fp32 = 16 KiB per wave of the group
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem) + w4 * (4 * 16 * 64);
     if (kg == 1) {
@@ -1607,12 +1618,15 @@ int launch256(GemmP p, hipStream_t s) {
 int g_gemm_dbg = 0;
 namespace {
 
-template <int EPI>
-int launch_t128x3(const GemmP& p0, hipStream_t s) {
+template <int EPI, int WM>
+int launch_t128x3_impl(const GemmP& p0, hipStream_t s) {
     static HirestDevCfg cfg;
-    auto kern = gemm_t128x3<EPI>;
-    if (int e = hirest_configure(kern, 4 * STAGE_BYTES, cfg)) return e;
+    auto kern = gemm_t128x3<EPI, WM>;
+    constexpr int LDS = 4 * (64 * WM + BN) * BK * 2;
+    if (int e = hirest_configure(kern, LDS, cfg)) return e;
     GemmP p = p0;
+    p.nbm = (p.M + 64 * WM - 1) / (64 * WM);
+    p.ppx = (p.nbm + 7) / 8;
     p.flat = p.nbm < 32 ? 1 : 0;                                  // (same tiles, same arithmetic per tile: the mapping does not change a bit of the result)
     // Split-K (HIREST_EPI_BIAS_RESID_F32 with a scratch buffer in aux0): a 768-wide layer over 1 500 rows is 72 tiles for 256 CUs and the 3072-deep
     // one of them (output.dense) runs 96 steps per tile — S slices of the K range per tile fill the chip; the slices are added in a fixed order.
@@ -1624,13 +1638,25 @@ int launch_t128x3(const GemmP& p0, hipStream_t s) {
         p.part = reinterpret_cast<float*>(p.aux0);
     }
     const int grid = p.flat ? 8 * ((p.nbm * p.nbn * p.ksplit + 7) / 8) : 8 * p.ppx * p.nbn;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 4 * STAGE_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WM), LDS, s, p);
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)p.M * (p.N / 4);
         int blocks = (int)((total + 255) / 256); blocks = blocks > 2048 ? 2048 : blocks;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.part, p.ksplit, p.bias, reinterpret_cast<float*>(p.out), p.ldo, p.M, p.N);
     }
     return hirest_launch_status();
+}
+// 192-row tiles (WM = 3) when they save rounds over the 256 CUs: cost of a tiling = rounds x tile height.  Taken only under HIREST_GEMM_X3_T128
+// (the joint model's calls): the towers' small split-operand calls keep the 128 x 128 tiles they have always had.
+static inline bool t128x3_tall(const GemmP& p, bool allow) {
+    if (!allow) return false;
+    const int64_t n2 = (int64_t)((p.M + 127) / 128) * p.nbn, n3 = (int64_t)((p.M + 191) / 192) * p.nbn;
+    const int64_t c2 = ((n2 + 255) / 256) * 2, c3 = ((n3 + 255) / 256) * 3;
+    return 4 * c3 <= 3 * c2;                                      // (a 6 % saving on paper measured 2 % slower at B = 32: take it from a quarter on)
+}
+template <int EPI>
+int launch_t128x3(const GemmP& p, hipStream_t s, bool allow_tall = false) {
+    return t128x3_tall(p, allow_tall) ? launch_t128x3_impl<EPI, 3>(p, s) : launch_t128x3_impl<EPI, 2>(p, s);
 }
 static inline bool x3_small(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) < 256; }
 int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
@@ -1699,7 +1725,8 @@ extern "C" int hirest_gemm_dispatch_name(const hirest_gemm_args* a, char* out, i
     if (a->flags & HIREST_GEMM_X3) {
         if (epi != HIREST_EPI_BIAS_F32 && epi != HIREST_EPI_BIAS_RESID_F32 && epi != HIREST_EPI_BIAS_GELU_SPLIT2) return HIREST_E_BADARG;
         if (((a->flags & HIREST_GEMM_X3_T128) || x3_small(a->M, a->N)) && (epi != HIREST_EPI_BIAS_GELU_SPLIT2 || (a->flags & HIREST_GEMM_X3_T128))) {
-            snprintf(out, out_len, "gemm_t128x3<%d>", epi);
+            GemmP q; q.M = a->M; q.nbn = (a->N + BN - 1) / BN;
+            snprintf(out, out_len, t128x3_tall(q, (a->flags & HIREST_GEMM_X3_T128) != 0) ? "gemm_t128x3<%d, 3>" : "gemm_t128x3<%d, 2>", epi);
             return 0;
         }
         snprintf(out, out_len, g_force_kernel == 9 ? "gemm_pq256x3<%d>" : "gemm_pp256x3<%d>", epi);
@@ -1751,11 +1778,12 @@ extern "C" int hirest_gemm_bf16(const hirest_gemm_args* a, void* stream) {
     if (a->flags & HIREST_GEMM_X3) {                  // split-operand products: the ping-pong kernel's X3 form, fp32 outputs only
         // fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (2 workgroups per CU)
         const bool small = x3_small(a->M, a->N) || (a->flags & HIREST_GEMM_X3_T128);
-        if (small && a->epilogue == HIREST_EPI_BIAS_F32) return launch_t128x3<HIREST_EPI_BIAS_F32>(p, s);
-        if (small && a->epilogue == HIREST_EPI_BIAS_RESID_F32) return launch_t128x3<HIREST_EPI_BIAS_RESID_F32>(p, s);
+        const bool tall = (a->flags & HIREST_GEMM_X3_T128) != 0;
+        if (small && a->epilogue == HIREST_EPI_BIAS_F32) return launch_t128x3<HIREST_EPI_BIAS_F32>(p, s, tall);
+        if (small && a->epilogue == HIREST_EPI_BIAS_RESID_F32) return launch_t128x3<HIREST_EPI_BIAS_RESID_F32>(p, s, tall);
         if ((a->flags & HIREST_GEMM_X3_T128) && a->epilogue == HIREST_EPI_BIAS_GELU_SPLIT2) {      // (the towers keep the 256 x 256 kernel for this epilogue at every size)
             if (a->N % 32 != 0 || a->ldo < 2 * (int64_t)a->N || a->ldo % 8 != 0) return HIREST_E_SHAPE;
-            return launch_t128x3<HIREST_EPI_BIAS_GELU_SPLIT2>(p, s);
+            return launch_t128x3<HIREST_EPI_BIAS_GELU_SPLIT2>(p, s, true);
         }
         switch (a->epilogue) {
             case HIREST_EPI_BIAS_F32:

@@ -1795,8 +1795,11 @@ extern "C" int hirest_gemm_f32(const float* A, int64_t lda, const float* W, int6
 // 512 .. 2048 for K and 400 .. 1200 tiles measure the same: the gain is the K = 3072 layer)
 static bool splits(int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
-    // (round 5: from K = 512 — 1500 x 768 x 768, 288 tiles: 38.4 -> 33.6 us; HIREST_F32_SPLIT_MIN_K = A/B of the threshold)
-    static const int min_k = [] { const char* e = getenv("HIREST_F32_SPLIT_MIN_K"); return e ? atoi(e) : 512; }();
+    // (round 5 lowered the threshold to K = 512 — 1500 x 768 x 768, 288 tiles: 38.4 -> 33.6 us, ~1 % of an inference batch — and that is what took
+    //  the training step from 3.07 to 3.45 ms between the round-4 and round-5 bench lines: its dX / dW products at K = 768 each gained a reduce
+    //  launch on a launch-bound step.  Same box, same build, round 6: 3.23 / 3.57 ms at 512 against 3.05 / 3.25 at 1024
+    //  (profiles/r06/train_bisect.txt).  Back to 1024; HIREST_F32_SPLIT_MIN_K = A/B of the threshold.)
+    static const int min_k = [] { const char* e = getenv("HIREST_F32_SPLIT_MIN_K"); return e ? atoi(e) : 1024; }();
     return g_f32_kernel == 0 && M > 256 && tiles <= 512 && K >= min_k;
 }
 extern "C" size_t hirest_gemm_f32_workspace_bytes(int32_t M, int32_t N, int32_t K) {
