@@ -45,7 +45,7 @@ GFLOP_PER_FRAME = 534.06        # algorithmic work of the vision towe
 _D, _DM, _T, _H, _DH = 1408, 6144, 257, 16, 88
 GFLOP_PRUNED_PER_FRAME = (2.0 * (_T - 1) * _D * _D + 2 * 2.0 * (_T - 1) * _D * _DM + 4.0 * (_T - 16) * _T * _DH * _H) / 1e9
 GFLOP_EXECUTED_PER_FRAME = GFLOP_PER_FRAME - GFLOP_PRUNED_PER_FRAME
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # newest first: where roofline.traffic is looked up
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")  # newest first: where roofline.traffic is looked up
 
 
 def small_calls(model, frames):
