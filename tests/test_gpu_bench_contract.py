@@ -89,6 +89,14 @@ def test_bench_line_contract():
         assert b32["token_ids_equal_real_reference"] == "32 of 32 captions" and b32["beam_rows"] == 32 * beams
         assert b32["value"] > 1.5 * sec[f"step_captioning_beam{beams}"]["value"] and 0 < b32["roofline"]["mfma_f32"]["frac"] < 1
     assert sec["moment_retrieval"]["value"] > 38 and sec["moment_segmentation"]["value"] > 8 and sec["step_captioning_beam3"]["value"] > 48
+    # the joint model's split-operand precision (MomentModel.set_precision('bf16x3'), round 6): the real reference's indices / boundary lists /
+    # token ids, faster than the fp32 path on the same batch
+    for k in ("moment_retrieval", "moment_segmentation", "moment_retrieval_b32", "moment_segmentation_b32"):
+        x = sec[k + "_bf16x3"]
+        assert x["predictions_equal_real_reference"] is True and x["value"] > sec[k]["value"] and abs(x["roofline"]["peak"] - 2500.0 / 3) < 1e-6, k
+    for beams in (3, 5):
+        x = sec[f"step_captioning_beam{beams}_b32_bf16x3"]
+        assert x["token_ids_equal_real_reference"] == "32 of 32 captions" and x["value"] > sec[f"step_captioning_beam{beams}_b32"]["value"]
 
 
 def test_bench_gpus_flag_is_binding():
