@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 6): this script measured the build that had the ragged column's own kernel (gemm_pq256r; removed again — it lost, see
+# profiles/r06/ragged_column_kernel_ab.txt and DESIGN 4.1i).  On the current tree debug bit 20 means nothing and both arms run the same code.
 # Round 6: the ragged column's own kernel (gemm_pq256r) — parity, race screens, then A/B against one launch (hirest_gemm_debug_mode bit 20) on the same box
 mkdir -p gpurun_out
 {
