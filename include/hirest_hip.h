@@ -825,7 +825,7 @@ size_t hirest_joint_encoder_x3_workspace_bytes(const hirest_joint_encoder_x3* e,
 int hirest_joint_encoder_x3_forward(const hirest_joint_encoder_x3* e, const float* f, int32_t B, int32_t T, float* out,
                                     void* workspace, size_t workspace_bytes, void* stream);
 /* LayerNorm over the last dim (hirest_layernorm's arithmetic) of x[r] (+ add[r % period] when add != NULL) written as fp32 (out32, may be
- * NULL) and / or in the split operand format (out2 [rows, >= 2 D] bf16, may be NULL). */
+ * NULL) and / or in the split operand format (out2 [rows, >= 2 D] bf16, may be NULL).  D % 32 == 0, D <= 2048 (else HIREST_E_SHAPE). */
 int hirest_layernorm_f32_split2(const float* x, int64_t ldx, const float* add, int32_t period, const float* gamma, const float* beta, float eps,
                                 float* out32, int64_t ldo32, hirest_bf16* out2, int64_t ldo2, int32_t rows, int32_t D, void* stream);
 

@@ -1,0 +1,229 @@
+"""Unit tests of the joint model's bf16x3 kernels (csrc/joint_x3.hip, gemm_t128x3<EPI, WM> under HIREST_GEMM_X3_T128): the pieces the
+golden tests of tests/test_gpu_joint.py only see end to end.
+
+  * hirest_layernorm_f32_split2 — fp32 LayerNorm (+ periodic position rows) with fp32 and / or split outputs;
+  * hirest_gemm_bf16 with HIREST_GEMM_X3 | HIREST_GEMM_X3_T128 — 128- and 192-row tiles, the flat per-XCD tile split below 32 row panels,
+    split-K with a caller scratch (RESID_F32), the GELU + split epilogue — against fp64 at the sizes the encoder calls them with and at
+    ragged ones;
+  * hirest_joint_encoder_x3_forward and the fp32 encoder (MomentModel._encoder) against an fp64 torch forward on seeded inputs.
+
+Bars: a split product carries ~16 mantissa bits -> |err| <= 2^-16 x sum|a||w| per element; results of one row do not depend on the other
+rows, on the tile height or on the K split (up to the fp32 order of the slice sums, bounded the same way)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from hirest_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _gemm_t128(a2, w2, bias, epi, out, scratch=None):
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    M, K2 = a2.shape
+    N = w2.shape[0]
+    args = _lib.GemmArgs.make(a2.data_ptr(), K2, w2.data_ptr(), K2, None if bias is None else bias.data_ptr(), out.data_ptr(), out.shape[1],
+                              M, N, K2, epi, None, 0, None if scratch is None else scratch.data_ptr(), None,
+                              _lib.GEMM_X3 | _lib.GEMM_X3_T128)
+    _lib.check(lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr()), "hirest_gemm_bf16 (x3, t128)")
+    return out
+
+
+def _dispatch(M, N, K2, epi, flags):
+    from hirest_amd import _lib
+    lib = _lib.load()
+    args = _lib.GemmArgs.make(None, K2, None, K2, None, None, N, M, N, K2, epi, None, 0, None, None, flags)
+    buf = C.create_string_buffer(128)
+    lib.hirest_gemm_dispatch_name(C.byref(args), buf, 128)
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("rows,D,period", [(1500, 768, 300), (5, 768, 5), (333, 1024, 37), (64, 32, 0), (2049, 2048, 0)])
+def test_layernorm_f32_split2(dev, rows, D, period):
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    x = synth.tensor(f"jx3.ln.{rows}.{D}", (rows, D), 2.0, 21, mean=0.3).to(dev)
+    g = synth.tensor(f"jx3.ln.g.{D}", (D,), 0.2, 22, mean=1.0).to(dev)
+    b = synth.tensor(f"jx3.ln.b.{D}", (D,), 0.2, 23).to(dev)
+    add = synth.tensor(f"jx3.ln.add.{period}.{D}", (period, D), 0.5, 24).to(dev) if period else None
+    eps = 1e-12
+    xin = x if add is None else x + add.repeat((rows + period - 1) // period, 1)[:rows]
+    want = torch.empty_like(x)
+    ops.layernorm(xin.contiguous(), g, b, eps, want)                          # hirest_layernorm: the arithmetic the header promises
+    ref = torch.nn.functional.layer_norm(xin.double(), (D,), g.double(), b.double(), eps)
+    assert (want.double() - ref).abs().max().item() < 1e-5
+
+    def run(o32, o2):
+        _lib.check(lib.hirest_layernorm_f32_split2(x.data_ptr(), D, None if add is None else add.data_ptr(), period, g.data_ptr(), b.data_ptr(), eps,
+                                                   None if o32 is None else o32.data_ptr(), D, None if o2 is None else o2.data_ptr(), 2 * D,
+                                                   rows, D, ops.stream_ptr()), "hirest_layernorm_f32_split2")
+    o32 = torch.full_like(x, float("nan"))
+    o2 = torch.zeros((rows, 2 * D), dtype=torch.bfloat16, device=dev)
+    run(o32, o2)
+    assert (o32.double() - ref).abs().max().item() < 1e-5
+    # x + add is formed inside the kernel in fp32 exactly as the host sum above: the same rows go through the same reduction
+    assert (o32 - want).abs().max().item() <= 2e-6
+    assert torch.equal(o2.view(torch.int16), ops.split2(o32).view(torch.int16))      # the split of what the fp32 output holds, bit for bit
+    only32 = torch.empty_like(x)
+    run(only32, None)
+    only2 = torch.zeros_like(o2)
+    run(None, only2)
+    assert torch.equal(only32, o32) and torch.equal(only2.view(torch.int16), o2.view(torch.int16))
+    if rows == 64:                                                            # D % 32 == 0 and D <= 2048, one output at least
+        E_SHAPE, E_BADARG = -2, -1
+        call = lambda D_, o: lib.hirest_layernorm_f32_split2(x.data_ptr(), D_, None, 0, g.data_ptr(), b.data_ptr(), eps, o, D_, None, 0, 1, D_, ops.stream_ptr())
+        assert call(3072, o32.data_ptr()) == E_SHAPE and call(48, o32.data_ptr()) == E_SHAPE and call(32, None) == E_BADARG
+
+
+# (M, N, K): the encoder's calls at B = 5 / B = 32 (rows = B * T) and ragged ones; K is the real depth (operands are [*, 2K])
+SHAPES = [(1500, 2304, 768), (1500, 768, 768), (1500, 3072, 768), (1500, 768, 3072), (1500, 768, 2048), (9600, 768, 768), (9600, 3072, 768),
+          (300, 768, 3072), (1, 768, 768), (100, 2304, 768), (191, 96, 64), (193, 160, 96), (4100, 768, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_x3_t128_bias_and_resid(dev, M, N, K):
+    from hirest_amd import _lib, ops
+    g = torch.Generator(device="cpu"); g.manual_seed(7 * M + 3 * N + K)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    a2, w2 = ops.split2(a), ops.split2(w)
+    prod = a.double() @ w.double().t()
+    scale = a.double().abs() @ w.double().abs().t() + 1.0
+    name = _dispatch(M, N, 2 * K, _lib.EPI_BIAS_F32, _lib.GEMM_X3 | _lib.GEMM_X3_T128)
+    assert name.startswith("gemm_t128x3<"), name
+    out = _gemm_t128(a2, w2, bias, _lib.EPI_BIAS_F32, torch.full((M, N), float("nan"), device=dev))
+    err = ((out.double() - prod - bias.double()).abs() / scale).max().item()
+    assert err < 2.0 ** -16, (name, err)
+    # the towers' kernel choice (no T128 flag) computes the same sums per element in the same k order up to the tile's wave split
+    plain = ops.gemm_x3(a2, w2, bias)
+    assert ((plain.double() - out.double()).abs() / scale).max().item() < 2.0 ** -17
+    if M > 200:                                                              # a row's result does not depend on its neighbours or the tile height
+        part = _gemm_t128(a2[70:200].contiguous(), w2, bias, _lib.EPI_BIAS_F32, torch.empty((130, N), device=dev))
+        assert ((part.double() - out[70:200].double()).abs() / scale[70:200]).max().item() < 2.0 ** -17
+    # accumulate-into, without and with the split-K scratch
+    x = torch.randn(M, N, generator=g).to(dev)
+    want = x.double() + prod + bias.double()
+    r1 = _gemm_t128(a2, w2, bias, _lib.EPI_BIAS_RESID_F32, x.clone())
+    assert ((r1.double() - want).abs() / (scale + x.abs().double())).max().item() < 2.0 ** -16
+    scratch = torch.full((4 * M * N,), float("nan"), device=dev)
+    r2 = _gemm_t128(a2, w2, bias, _lib.EPI_BIAS_RESID_F32, x.clone(), scratch=scratch)
+    assert ((r2.double() - want).abs() / (scale + x.abs().double())).max().item() < 2.0 ** -16
+    r3 = _gemm_t128(a2, w2, bias, _lib.EPI_BIAS_RESID_F32, x.clone(), scratch=scratch)
+    assert torch.equal(r2, r3)                                               # slices are added in a fixed order: run to run identical
+    nb = _gemm_t128(a2, w2, None, _lib.EPI_BIAS_RESID_F32, x.clone(), scratch=scratch)
+    assert ((nb.double() - (want - bias.double())).abs() / (scale + x.abs().double())).max().item() < 2.0 ** -16
+
+
+@pytest.mark.parametrize("M,N,K", [(1500, 3072, 768), (9600, 3072, 768), (100, 3072, 768), (1, 64, 64), (333, 160, 96)])
+def test_gemm_x3_t128_gelu_split(dev, M, N, K):
+    from hirest_amd import _lib, ops
+    g = torch.Generator(device="cpu"); g.manual_seed(M + N + K + 1)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    a2, w2 = ops.split2(a), ops.split2(w)
+    fused = _gemm_t128(a2, w2, bias, _lib.EPI_BIAS_GELU_SPLIT2, torch.zeros((M, 2 * N), dtype=torch.bfloat16, device=dev))
+    pre = _gemm_t128(a2, w2, bias, _lib.EPI_BIAS_F32, torch.empty((M, N), device=dev))
+    back = lambda t: t.reshape(M, N // 32, 2, 32).double().sum(dim=2).reshape(M, N)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double())
+    scale = a.double().abs() @ w.double().abs().t() + 1.0
+    assert ((back(fused) - ref).abs() / scale).max().item() < 2.0 ** -15      # product error + the 16-bit split of the result
+    sep = ops.split2(pre, gelu=True)                                          # the separate pass on the same fp32 sums
+    assert (back(fused) - back(sep)).abs().max().item() <= 2.0 ** -15 * max(1.0, back(sep).abs().max().item())
+    # hi parts are bf16(value): the lo part is a correct residual of it
+    hi = fused.reshape(M, N // 32, 2, 32)[:, :, 0].float().reshape(M, N)
+    assert torch.equal(hi.to(torch.bfloat16).float(), hi) and (hi.double() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_x3_t128_rejects_bad_arguments(dev):
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    a2 = torch.zeros((64, 128), dtype=torch.bfloat16, device=dev)
+    w2 = torch.zeros((64, 128), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((64, 64), device=dev)
+
+    def call(epi, flags, ldo=64, N=64):
+        args = _lib.GemmArgs.make(a2.data_ptr(), 128, w2.data_ptr(), 128, None, out.data_ptr(), ldo, 64, N, 128, epi, None, 0, None, None, flags)
+        return lib.hirest_gemm_bf16(C.byref(args), ops.stream_ptr())
+    assert call(_lib.EPI_BIAS_F32, _lib.GEMM_X3 | _lib.GEMM_X3_T128) == 0
+    assert call(_lib.EPI_BIAS_F32, _lib.GEMM_X3_T128) != 0                    # the tile flag without the operand format flag
+    assert call(_lib.EPI_BIAS_F32, _lib.GEMM_X3 | 8) != 0                     # unknown flag bits
+    assert call(_lib.EPI_BIAS_GELU_SPLIT2, _lib.GEMM_X3 | _lib.GEMM_X3_T128, ldo=64) != 0     # split output needs ldo >= 2 N
+    assert call(_lib.EPI_BIAS_BF16, _lib.GEMM_X3 | _lib.GEMM_X3_T128) != 0    # bf16 outputs are not a split-operand epilogue
+    torch.cuda.synchronize()
+
+
+def _encoder_fp64(m, f, B, T):
+    """VisualModel.forward (module_visual.py:396-424) in plain fp64 torch: embeddings (Linear + position rows + LayerNorm) and the post-LN
+    blocks.  modeling.py:208 hands the encoder an all-ZERO mask, so module_visual.py:414 adds -10000 to EVERY score: in exact arithmetic the
+    shift cancels in the softmax, in the reference's fp32 it rounds each score to the 2^-10 grid of [8192, 16384) first.  That rounding is
+    part of the reference's result (both device paths reproduce it) and is applied here in fp32, the rest stays fp64."""
+    sd = {k: v.double() for k, v in m.state_dict().items()}
+    V = "clip4cap_model.visual."
+    ln = lambda x, p: torch.nn.functional.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-12)
+    lin = lambda x, p: x @ sd[p + ".weight"].t() + sd[p + ".bias"]
+    x = lin(f.double(), V + "embeddings.word_embeddings").reshape(B, T, -1) + sd[V + "embeddings.position_embeddings.weight"][:T]
+    x = ln(x, V + "embeddings.LayerNorm")
+    H, D = m.heads, x.shape[-1]
+    for i in range(len(m.clip4cap_model.visual.encoder.layer)):
+        p = V + f"encoder.layer.{i}."
+        heads = lambda t: t.reshape(B, T, H, D // H).transpose(1, 2)
+        q, k, v = (heads(lin(x, p + "attention.self." + n)) for n in ("query", "key", "value"))
+        sc = (q @ k.transpose(-1, -2) * (D // H) ** -0.5).float() + torch.tensor(-10000.0, dtype=torch.float32, device=f.device)
+        att = torch.softmax(sc.double(), dim=-1)
+        ctx = (att @ v).transpose(1, 2).reshape(B, T, D)
+        a = ln(lin(ctx, p + "attention.output.dense") + x, p + "attention.output.LayerNorm")
+        h = torch.nn.functional.gelu(lin(a, p + "intermediate.dense"))
+        x = ln(lin(h, p + "output.dense") + a, p + "output.LayerNorm")
+    return x.reshape(B * T, D)
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 7), (5, 300), (3, 77), (32, 300), (2, 512)])
+def test_encoder_x3_against_fp64(dev, B, T):
+    """Both encoders against the fp64 forward: the fp32 path rounds at 24 bits, the split one carries ~16 bits per product — its outputs
+    (O(1) after the last LayerNorm) stay within 1.5e-3 (rms 1.5e-4), inside the golden tests' logit bars (2e-3)."""
+    m = _model(dev)
+    g = torch.Generator(device="cpu"); g.manual_seed(100 * B + T)
+    f = torch.randn(B * T, 512, generator=g).to(dev)                          # hirest_joint_mask_add's output: [B*T, 512]
+    ref = _encoder_fp64(m, f, B, T)
+    want = m._encoder(f, B, T)
+    got = m._encoder_x3(f, B, T)
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    e32, ex3 = (want.double() - ref).abs().max().item(), (got.double() - ref).abs().max().item()
+    r32, rx3 = (want.double() - ref).pow(2).mean().sqrt().item(), (got.double() - ref).pow(2).mean().sqrt().item()
+    print(f"encoder B={B} T={T}: vs fp64 max |err| (rms): fp32 path {e32:.2e} ({r32:.2e}), bf16x3 path {ex3:.2e} ({rx3:.2e}); |out| max {ref.abs().max().item():.2f}")
+    # A score that lands within its own rounding error (~3e-6) of a 2^-10 grid midpoint takes the other neighbour in a second correct
+    # implementation: about one key per 300-key row, worth p_j x 1e-3 in that row's output — the few-1e-4 maxima both paths show from T ~ 77 on
+    # (T = 7: 3e-6 for the fp32 path).  The rms is what separates 24-bit from 16-bit products.
+    assert e32 < (1e-5 if T <= 7 else 1.5e-3) and r32 < 3e-5
+    assert ex3 < 1.5e-3 and rx3 < 1.5e-4
+    again = m._encoder_x3(f, B, T)
+    assert torch.equal(got, again)
+    if B > 1:                                                                 # videos are independent: a batch row equals the single-video call
+        one = m._encoder_x3(f[T:2 * T].contiguous(), 1, T)                    # (other tile heights / K slices: the same sums in another fp32 order)
+        d = (one - got[T:2 * T]).double()                                     # ... whose score flips (above) show here too
+        assert d.abs().max().item() < 1.5e-3 and d.pow(2).mean().sqrt().item() < 5e-5
+
+
+_MODEL = {}
+
+
+def _model(dev):
+    """A seeded joint model of the reference's shape (2 post-LN layers, 768 wide, 12 heads, 3072 MLP; modeling.py:60-112), built once."""
+    if "m" not in _MODEL:
+        import hirest_amd
+        m = hirest_amd.MomentModel(n_frames=-1, asr_dim=384, args=None, clip_model=None)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert not m.load_state_dict(synth.joint_state_dict(shapes, 47), strict=False).missing_keys
+        _MODEL["m"] = m.to(dev).eval()
+    return _MODEL["m"]
