@@ -120,6 +120,24 @@ class ColsumItem(C.Structure):
 COLSUM_GROUP_MAX = 40
 
 
+class TrainBlock(C.Structure):
+    """hirest_train_block (include/hirest_hip.h): one post-LN encoder block in train mode, forward + what its backward needs."""
+    _fields_ = [("struct_size", C.c_uint64)] + [(n, C.c_int32) for n in ("B", "T", "heads", "width", "mlp", "precision")] + \
+               [("ln_eps", C.c_float), ("drop", C.c_float)] + [(n, C.c_uint32) for n in ("seed_attn", "seed_ao", "seed_out", "reserved")] + \
+               [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b", "x",
+                                          "qkv", "P", "cx", "a_pre", "aa", "hpre", "hh", "x_pre", "out", "ws")] + [("ws_bytes", C.c_size_t)]
+
+
+class TrainBlockGrads(C.Structure):
+    """hirest_train_block_grads (include/hirest_hip.h)."""
+    _fields_ = [("struct_size", C.c_uint64)] + \
+               [(n, C.c_void_p) for n in ("dout", "dx", "g_wqkv", "g_wo", "g_w1", "g_w2", "g_bqkv", "g_bo", "g_b1", "g_b2", "g_ln1_g", "g_ln1_b",
+                                          "g_ln2_g", "g_ln2_b")] + \
+               [("items", C.POINTER(ColsumItem)), ("n_items", C.POINTER(C.c_int32)), ("max_items", C.c_int32), ("reserved", C.c_int32),
+                ("side_stream", C.c_void_p), ("side_ws", C.c_void_p), ("side_ws_bytes", C.c_size_t), ("scratch", C.c_void_p),
+                ("scratch_bytes", C.c_size_t)]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("kind", C.c_int32), ("tag", C.c_int32), ("d0", C.c_int64), ("d1", C.c_int64), ("d2", C.c_int64),
                 ("ms", C.c_float)]
@@ -229,6 +247,10 @@ _SIGNATURES = {
                                         C.c_int32, C.c_void_p]),
     "hirest_transpose_pad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "hirest_weighted_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "hirest_train_block_forward_scratch_bytes": (C.c_size_t, [C.POINTER(TrainBlock)]),
+    "hirest_train_block_forward": (C.c_int, [C.POINTER(TrainBlock), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hirest_train_block_backward_scratch_bytes": (C.c_size_t, [C.POINTER(TrainBlock)]),
+    "hirest_train_block_backward": (C.c_int, [C.POINTER(TrainBlock), C.POINTER(TrainBlockGrads), C.c_void_p]),
     "hirest_weighted_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "hirest_scale_by_device_scalar_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hirest_act_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),

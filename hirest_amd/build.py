@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhirest_hip.so")
-SOURCES = ["gemm.hip", "joint_x3.hip", "attention.hip", "elementwise.hip", "score.hip", "tower.hip", "tower_f32.hip", "tower_x3.hip", "attention_x3.hip", "profile.hip", "joint.hip", "train.hip", "caption.hip", "preprocess.hip", "eval.hip"]
+SOURCES = ["gemm.hip", "joint_x3.hip", "attention.hip", "elementwise.hip", "score.hip", "tower.hip", "tower_f32.hip", "tower_x3.hip", "attention_x3.hip", "profile.hip", "joint.hip", "train.hip", "train_block.hip", "caption.hip", "preprocess.hip", "eval.hip"]
 ARCH = "gfx950"
 # attention's softmax only ever sees finite values (masked scores are -3e38, not -inf): dropping NaN handling removes
 # the canonicalising v_max the compiler otherwise puts in front of every fmaxf on an MFMA result

@@ -1,0 +1,161 @@
+// One post-LN block of the clip4caption VisualModel in train mode, forward and backward, as ONE host call per direction
+// (include/hirest_hip.h: hirest_train_block; module_visual.py:132-264 under modeling.py:196-211 / run.py:238-295).
+//
+// No kernel lives here: the file issues the library's own entry points (hirest_gemm_f32_ws / _layouts, hirest_attention_train_*,
+// hirest_dropout_add_f32, hirest_layernorm, hirest_act_*, hirest_layernorm_bwd_f32) in the order hirest_amd/train.py issued them one
+// by one — same operands, same order, same bits — because at B = 5, T = 300 the training step was paced by the host: ~150 launches
+// per step at 15-20 us each through the host language against 2.8 ms of kernels (profiles/r06/train_step_context.txt,
+// tools/r06_train_graph.py).  From here a launch costs the ~3 us of hipLaunchKernel.
+//
+// Weight-gradient products (dW = dY^T X) go to the caller's side stream behind an event recorded when their dY is complete, as
+// train.py's _K.grad_weight did; the column sums (bias / LayerNorm gradients) are appended to the caller's item table and run as
+// one grouped launch after the whole backward.
+#include "common.h"
+#include <math.h>
+#include <mutex>
+
+namespace {
+
+#define CHECK(expr) do { int _e = (expr); if (_e != 0) return _e; } while (0)
+inline size_t al(size_t floats) { return (floats + 63) & ~(size_t)63; }           // 256-B aligned slices of the scratch
+
+struct Shape {
+    int64_t R, W, M3, mlp, PT;                                                   // rows, width, 3 width, mlp, B H T T
+    explicit Shape(const hirest_train_block* b)
+        : R((int64_t)b->B * b->T), W(b->width), M3(3 * (int64_t)b->width), mlp(b->mlp), PT((int64_t)b->B * b->heads * b->T * b->T) {}
+};
+
+inline bool block_ok(const hirest_train_block* b) {
+    return b && b->struct_size == sizeof(*b) && b->B > 0 && b->T > 0 && b->heads > 0 && b->width > 0 && b->width % b->heads == 0 &&
+           b->width % 16 == 0 && b->mlp > 0 && b->mlp % 16 == 0 && (b->precision == 0 || b->precision == 1);
+}
+
+// the fp32 GEMM with its split form when the caller's scratch holds it (same bits either way)
+int gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, float* out, int M, int N, int K, void* ws, size_t wsb,
+         hipStream_t s) {
+    const size_t need = hirest_gemm_f32_workspace_bytes(M, N, K);
+    const bool use = need && ws && need <= wsb;
+    return hirest_gemm_f32_ws(A, lda, Wt, ldw, bias, nullptr, N, nullptr, 0, out, N, M, N, K, 0, use ? ws : nullptr, use ? wsb : 0, s);
+}
+int gemm_layouts(const float* A, int64_t lda, int akm, const float* Wt, int64_t ldw, int wkm, const float* resid, int64_t ldr, float* out, int M, int N,
+                 int K, void* ws, size_t wsb, hipStream_t s) {
+    const size_t need = hirest_gemm_f32_layouts_workspace_bytes(M, N, K);
+    const bool use = need && ws && need <= wsb;
+    return hirest_gemm_f32_layouts(A, lda, akm, Wt, ldw, wkm, nullptr, resid, resid ? ldr : 0, out, N, M, N, K, 0, use ? ws : nullptr, use ? wsb : 0, s);
+}
+
+// "dY is complete on the main stream" markers for the side stream: a small ring of events (a wait captures the record that precedes it,
+// so reusing an event later does not disturb the waits already enqueued)
+hipEvent_t next_event() {
+    static std::mutex mu;
+    static hipEvent_t ring[64];
+    static int n = 0, at = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (n < 64) {
+        if (hipEventCreateWithFlags(&ring[n], hipEventDisableTiming) != hipSuccess) return nullptr;
+        return ring[n++];
+    }
+    at = (at + 1) & 63;
+    return ring[at];
+}
+
+// dW = dY^T X: A(m = o, k = r) = dY[r][o], B(n = i, k = r) = X[r][i] — both k-major, read in place
+int grad_weight(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* out, int O, int I, int R, const hirest_train_block* b,
+                const hirest_train_block_grads* g, hipStream_t main) {
+    if (!g->side_stream) return gemm_layouts(dy, ldy, 1, x, ldx, 1, nullptr, 0, out, O, I, R, b->ws, b->ws_bytes, main);
+    hipStream_t side = reinterpret_cast<hipStream_t>(g->side_stream);
+    hipEvent_t ev = next_event();
+    if (!ev) return (int)hipErrorOutOfMemory;
+    if (hipError_t e = hipEventRecord(ev, main)) return (int)e;
+    if (hipError_t e = hipStreamWaitEvent(side, ev, 0)) return (int)e;
+    return gemm_layouts(dy, ldy, 1, x, ldx, 1, nullptr, 0, out, O, I, R, g->side_ws, g->side_ws_bytes, side);
+}
+
+int colsum_item(const hirest_train_block_grads* g, const float* x, int64_t ldx, int R, int C, float* out) {
+    if (!g->items || !g->n_items || *g->n_items >= g->max_items) return HIREST_E_BADARG;
+    hirest_colsum_item& it = g->items[(*g->n_items)++];
+    it.x = x; it.row_weight = nullptr; it.row_select = nullptr; it.out = out; it.ldx = ldx; it.R = R; it.C = C; it.select_value = 0; it.reserved = 0;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t hirest_train_block_forward_scratch_bytes(const hirest_train_block* b) {
+    if (!block_ok(b)) return 0;
+    const Shape d(b);
+    return al(d.R * d.W) * sizeof(float);                                        // o / y: the dense outputs in front of their dropout + add
+}
+
+extern "C" int hirest_train_block_forward(const hirest_train_block* b, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!block_ok(b) || !scratch || scratch_bytes < hirest_train_block_forward_scratch_bytes(b)) return HIREST_E_BADARG;
+    if (b->precision != 0) return HIREST_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const Shape d(b);
+    const int R = (int)d.R, W = (int)d.W, M3 = (int)d.M3, mlp = (int)d.mlp, dh = W / b->heads;
+    const float scale = (float)pow((double)dh, -0.5);
+    float* o = reinterpret_cast<float*>(scratch);
+    CHECK(gemm(b->x, W, b->wqkv, W, b->bqkv, b->qkv, R, M3, W, b->ws, b->ws_bytes, s));
+    CHECK(hirest_attention_train_fwd_f32(b->qkv, b->P, b->cx, b->B, b->T, b->heads, dh, scale, -10000.0f, b->drop, b->seed_attn, s));
+    CHECK(gemm(b->cx, W, b->wo, W, b->bo, o, R, W, W, b->ws, b->ws_bytes, s));
+    CHECK(hirest_dropout_add_f32(o, b->x, b->a_pre, d.R * d.W, b->drop, b->seed_ao, s));
+    CHECK(hirest_layernorm(b->a_pre, W, nullptr, b->ln1_g, b->ln1_b, b->ln_eps, b->aa, W, 1, R, W, s));
+    CHECK(gemm(b->aa, W, b->w1, W, b->b1, b->hpre, R, mlp, W, b->ws, b->ws_bytes, s));
+    CHECK(hirest_act_f32(b->hpre, b->hh, d.R * d.mlp, 1, s));
+    CHECK(gemm(b->hh, mlp, b->w2, mlp, b->b2, o, R, W, mlp, b->ws, b->ws_bytes, s));
+    CHECK(hirest_dropout_add_f32(o, b->aa, b->x_pre, d.R * d.W, b->drop, b->seed_out, s));
+    CHECK(hirest_layernorm(b->x_pre, W, nullptr, b->ln2_g, b->ln2_b, b->ln_eps, b->out, W, 1, R, W, s));
+    return 0;
+}
+
+extern "C" size_t hirest_train_block_backward_scratch_bytes(const hirest_train_block* b) {
+    if (!block_ok(b)) return 0;
+    const Shape d(b);
+    // dxp, dyx2, dy, da, dap, dyx1, do, dcx: [R, W] each;  dh, dhp: [R, mlp];  dS: [B, H, T, T];  dqkv: [R, 3 W]
+    return (8 * al(d.R * d.W) + 2 * al(d.R * d.mlp) + al(d.PT) + al(d.R * d.M3)) * sizeof(float);
+}
+
+extern "C" int hirest_train_block_backward(const hirest_train_block* b, const hirest_train_block_grads* g, void* stream) {
+    if (!block_ok(b) || !g || g->struct_size != sizeof(*g) || !g->dout || !g->dx || !g->scratch ||
+        g->scratch_bytes < hirest_train_block_backward_scratch_bytes(b))
+        return HIREST_E_BADARG;
+    if (b->precision != 0) return HIREST_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const Shape d(b);
+    const int R = (int)d.R, W = (int)d.W, M3 = (int)d.M3, mlp = (int)d.mlp, dh = W / b->heads;
+    const float scale = (float)pow((double)dh, -0.5);
+    float* p = reinterpret_cast<float*>(g->scratch);
+    auto take = [&p](int64_t n) { float* q = p; p += al((size_t)n); return q; };
+    float *dxp = take(d.R * d.W), *dyx2 = take(d.R * d.W), *dyb = take(d.R * d.W), *da = take(d.R * d.W), *dap = take(d.R * d.W),
+          *dyx1 = take(d.R * d.W), *dob = take(d.R * d.W), *dcx = take(d.R * d.W), *dhid = take(d.R * d.mlp), *dhp = take(d.R * d.mlp),
+          *dS = take(d.PT), *dqkv = take(d.R * d.M3);
+    const bool drop = b->drop != 0.0f;
+
+    // output.LayerNorm, dropout(output.dense(...)) + aa
+    CHECK(hirest_layernorm_bwd_f32(b->x_pre, g->dout, b->ln2_g, b->ln_eps, dxp, dyx2, R, W, s));
+    CHECK(colsum_item(g, dyx2, W, R, W, g->g_ln2_g));
+    CHECK(colsum_item(g, g->dout, W, R, W, g->g_ln2_b));
+    const float* dy = dxp;                                                       // through dropout(y); the residual branch gets dxp as is
+    if (drop) { CHECK(hirest_dropout_add_f32(dxp, nullptr, dyb, d.R * d.W, b->drop, b->seed_out, s)); dy = dyb; }
+    CHECK(grad_weight(dy, W, b->hh, mlp, g->g_w2, W, mlp, R, b, g, s));
+    CHECK(colsum_item(g, dy, W, R, W, g->g_b2));
+    CHECK(gemm_layouts(dy, W, 0, b->w2, mlp, 1, nullptr, 0, dhid, R, mlp, W, b->ws, b->ws_bytes, s));          // dX = dY W: B(n = i, k = o) = W[o][i]
+    CHECK(hirest_act_bwd_f32(b->hpre, dhid, dhp, d.R * d.mlp, 1, s));
+    CHECK(grad_weight(dhp, mlp, b->aa, W, g->g_w1, mlp, W, R, b, g, s));
+    CHECK(colsum_item(g, dhp, mlp, R, mlp, g->g_b1));
+    CHECK(gemm_layouts(dhp, mlp, 0, b->w1, W, 1, dxp, W, da, R, W, mlp, b->ws, b->ws_bytes, s));                // + the residual path
+    // attention.output.LayerNorm, dropout(attention.output.dense(cx)) + x
+    CHECK(hirest_layernorm_bwd_f32(b->a_pre, da, b->ln1_g, b->ln_eps, dap, dyx1, R, W, s));
+    CHECK(colsum_item(g, dyx1, W, R, W, g->g_ln1_g));
+    CHECK(colsum_item(g, da, W, R, W, g->g_ln1_b));
+    const float* dO = dap;
+    if (drop) { CHECK(hirest_dropout_add_f32(dap, nullptr, dob, d.R * d.W, b->drop, b->seed_ao, s)); dO = dob; }
+    CHECK(grad_weight(dO, W, b->cx, W, g->g_wo, W, W, R, b, g, s));
+    CHECK(colsum_item(g, dO, W, R, W, g->g_bo));
+    CHECK(gemm_layouts(dO, W, 0, b->wo, W, 1, nullptr, 0, dcx, R, W, W, b->ws, b->ws_bytes, s));
+    // self-attention
+    CHECK(hirest_attention_train_bwd_f32(b->qkv, b->P, dcx, dS, dqkv, b->B, b->T, b->heads, dh, scale, b->drop, b->seed_attn, s));
+    CHECK(grad_weight(dqkv, M3, b->x, W, g->g_wqkv, M3, W, R, b, g, s));
+    CHECK(colsum_item(g, dqkv, M3, R, M3, g->g_bqkv));
+    CHECK(gemm_layouts(dqkv, M3, 0, b->wqkv, W, 1, dap, W, g->dx, R, W, M3, b->ws, b->ws_bytes, s));            // + the residual path
+    return 0;
+}

@@ -46,6 +46,9 @@ def _chk(code, what):
 # (Round 4 built the step's Linear-layer products as split-operand bf16x3 GEMMs as well — 3.3 vs 2.8 ms per step: slower, the ~50 extra split
 # launches cost more than the faster products return — and round 5 removed that opt-in path again: profiles/r04/train_x3_ab.txt)
 SIDE_STREAM_DW = True      # weight-gradient GEMMs of a backward on a second stream (_K.side_open)
+# One C call per encoder block and direction (csrc/train_block.hip: the same entry points in the same order, issued from C — the step was
+# paced by ~150 launches per step through Python at 15-20 us each).  False / HIREST_TRAIN_C_BLOCKS=0: the per-kernel calls below (A/B, tests).
+C_BLOCKS = os.environ.get("HIREST_TRAIN_C_BLOCKS", "1") != "0"
 _SIDE = {}
 
 
@@ -106,13 +109,13 @@ class _K:
         st = _SIDE.get(device.index)
         if st is None:
             st = _SIDE[device.index] = {"stream": torch.cuda.Stream(device=device), "events": [], "keep": [], "used": 0}
-        st["used"] = 0
+        st["used"], st["c_used"] = 0, False
         _K._side = st
 
     @staticmethod
     def side_join():
         st, _K._side = _K._side, None
-        if st is not None and st["used"]:
+        if st is not None and (st["used"] or st.get("c_used")):
             torch.cuda.current_stream().wait_stream(st["stream"])
             st["keep"].clear()
 
@@ -160,22 +163,35 @@ class _K:
     # (bias, LayerNorm and embedding gradients), each a few blocks.  Their results are only read after the backward returns.
     _pending = None
 
+    _c_items = None          # (ColsumItem * 64)() the C block backward appends to, its counter, and the tensors those items point into
+    _c_count = None
+    _c_keep: list = []
+
     @staticmethod
     def open_colsums():
         _K._pending = []
+        if _K._c_items is None:
+            _K._c_items, _K._c_count = (_lib.ColsumItem * 64)(), C.c_int32(0)
+        _K._c_count.value = 0
+        _K._c_keep = []
 
     @staticmethod
     def flush_colsums():
         items, _K._pending = _K._pending, None
-        if not items:
+        nc = _K._c_count.value if _K._c_count is not None else 0
+        if not items and not nc:
             return
-        arr = (_lib.ColsumItem * len(items))()
+        arr = (_lib.ColsumItem * (len(items) + nc))()
         for slot, (x, weight, select, value, out) in zip(arr, items):
             slot.x, slot.ldx, slot.R, slot.C = x.data_ptr(), x.stride(0), x.shape[0], x.shape[1]
             slot.row_weight = weight.data_ptr() if weight is not None else None
             slot.row_select = select.data_ptr() if select is not None else None
             slot.select_value, slot.out = value, out.data_ptr()
-        _chk(_lib.load().hirest_weighted_colsum_grouped_f32(arr, len(items), ops.stream_ptr()), "colsum_grouped")
+        if nc:                                                               # the block backwards' own sums (csrc/train_block.hip), same launch
+            C.memmove(C.byref(arr, len(items) * C.sizeof(_lib.ColsumItem)), _K._c_items, nc * C.sizeof(_lib.ColsumItem))
+            _K._c_count.value = 0
+        _chk(_lib.load().hirest_weighted_colsum_grouped_f32(arr, len(items) + nc, ops.stream_ptr()), "colsum_grouped")
+        _K._c_keep = []
         # (`items` kept the operands alive up to here; the caching allocator orders their reuse after this launch on the stream)
 
     @staticmethod
@@ -300,6 +316,102 @@ def task_param_names(model, task: str) -> List[str]:
     return names
 
 
+def _block_workspaces(dev, R, Hd, mlp, side_stream):
+    """Split-form scratch of the fp32 GEMMs of one block (ops.f32_gemm_workspace: one buffer per stream), sized for the largest problem."""
+    lib = _lib.load()
+    fwd = max(lib.hirest_gemm_f32_workspace_bytes(R, n, k) for n, k in ((3 * Hd, Hd), (Hd, Hd), (mlp, Hd), (Hd, mlp)))
+    bwd = max(lib.hirest_gemm_f32_layouts_workspace_bytes(R, n, k) for n, k in ((mlp, Hd), (Hd, mlp), (Hd, Hd), (Hd, 3 * Hd)))
+    main = ops.f32_gemm_workspace(dev, max(fwd, bwd, 1))
+    if side_stream is None:
+        return main, (None, 0)
+    dw = max(lib.hirest_gemm_f32_layouts_workspace_bytes(m, n, R) for m, n in ((Hd, mlp), (mlp, Hd), (Hd, Hd), (3 * Hd, Hd)))
+    return main, ops.f32_gemm_workspace(dev, max(dw, 1), 1, side_stream)
+
+
+def _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed):
+    """One encoder block through hirest_train_block_forward (csrc/train_block.hip); keeps the descriptor and the activations for the backward."""
+    lib = _lib.load()
+    dev = x.device
+    R, Hd = x.shape
+    mlp = P[p + "intermediate.dense.weight"].shape[0]
+    al = lambda n: (n + 63) // 64 * 64
+    sizes = [("qkv", R * 3 * Hd), ("P", B * heads * T * T), ("cx", R * Hd), ("a_pre", R * Hd), ("aa", R * Hd), ("hpre", R * mlp), ("hh", R * mlp),
+             ("x_pre", R * Hd), ("out", R * Hd)]
+    flat = torch.empty((sum(al(n) for _, n in sizes),), dtype=torch.float32, device=dev)
+    act, off = {}, 0
+    for name, n in sizes:
+        act[name] = flat[off:off + n]
+        off += al(n)
+    (ws, wsb), _ = _block_workspaces(dev, R, Hd, mlp, None)
+    d = _lib.TrainBlock()
+    d.struct_size = C.sizeof(_lib.TrainBlock)
+    d.B, d.T, d.heads, d.width, d.mlp, d.precision = B, T, heads, Hd, mlp, 0
+    d.ln_eps, d.drop = 1e-12, float(drop)
+    d.seed_attn, d.seed_ao, d.seed_out = (seed + 10 + 4 * i) & 0xFFFFFFFF, (seed + 11 + 4 * i) & 0xFFFFFFFF, (seed + 12 + 4 * i) & 0xFFFFFFFF
+    for field, t in (("wqkv", wqkv), ("bqkv", bqkv), ("wo", P[p + "attention.output.dense.weight"]), ("bo", P[p + "attention.output.dense.bias"]),
+                     ("ln1_g", P[p + "attention.output.LayerNorm.weight"]), ("ln1_b", P[p + "attention.output.LayerNorm.bias"]),
+                     ("w1", P[p + "intermediate.dense.weight"]), ("b1", P[p + "intermediate.dense.bias"]),
+                     ("w2", P[p + "output.dense.weight"]), ("b2", P[p + "output.dense.bias"]),
+                     ("ln2_g", P[p + "output.LayerNorm.weight"]), ("ln2_b", P[p + "output.LayerNorm.bias"]), ("x", x)):
+        setattr(d, field, t.data_ptr())
+    for name, _n in sizes:
+        setattr(d, name, act[name].data_ptr())
+    d.ws, d.ws_bytes = ws, wsb
+    need = lib.hirest_train_block_forward_scratch_bytes(C.byref(d))
+    scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+    _chk(lib.hirest_train_block_forward(C.byref(d), scratch.data_ptr(), need, ops.stream_ptr()), "train_block_forward")
+    return dict(desc=d, flat=flat, x=x, wqkv=wqkv, bqkv=bqkv, out=act["out"].reshape(R, Hd), dims=(R, Hd, mlp))
+
+
+def _block_backward(P, p, Ly, dout, G):
+    """Backward of _block_forward through hirest_train_block_backward: dX products on the current stream, dW on the open side stream, the
+    twelve column sums appended to the open batch.  Returns d loss / d (block input)."""
+    lib = _lib.load()
+    d = Ly["desc"]
+    R, Hd, mlp = Ly["dims"]
+    dev = dout.device
+    st = _K._side
+    side = st["stream"].cuda_stream if st is not None else None
+    (ws, wsb), (sws, swsb) = _block_workspaces(dev, R, Hd, mlp, side)
+    d.ws, d.ws_bytes = ws, wsb
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    dwqkv, dbqkv = f32(3 * Hd, Hd), f32(3 * Hd)
+    g = _lib.TrainBlockGrads()
+    g.struct_size = C.sizeof(_lib.TrainBlockGrads)
+    dout = dout.contiguous()
+    dx = f32(R, Hd)
+    g.dout, g.dx = dout.data_ptr(), dx.data_ptr()
+    out = {"attention.output.dense.weight": f32(Hd, Hd), "intermediate.dense.weight": f32(mlp, Hd), "output.dense.weight": f32(Hd, mlp),
+           "attention.output.dense.bias": f32(Hd), "intermediate.dense.bias": f32(mlp), "output.dense.bias": f32(Hd),
+           "attention.output.LayerNorm.weight": f32(Hd), "attention.output.LayerNorm.bias": f32(Hd),
+           "output.LayerNorm.weight": f32(Hd), "output.LayerNorm.bias": f32(Hd)}
+    g.g_wqkv, g.g_bqkv = dwqkv.data_ptr(), dbqkv.data_ptr()
+    for field, name in (("g_wo", "attention.output.dense.weight"), ("g_w1", "intermediate.dense.weight"), ("g_w2", "output.dense.weight"),
+                        ("g_bo", "attention.output.dense.bias"), ("g_b1", "intermediate.dense.bias"), ("g_b2", "output.dense.bias"),
+                        ("g_ln1_g", "attention.output.LayerNorm.weight"), ("g_ln1_b", "attention.output.LayerNorm.bias"),
+                        ("g_ln2_g", "output.LayerNorm.weight"), ("g_ln2_b", "output.LayerNorm.bias")):
+        setattr(g, field, out[name].data_ptr())
+    if _K._pending is None:
+        raise RuntimeError("hirest_amd.train: the block backward runs inside an open column-sum batch (_colsum_batched)")
+    g.items, g.n_items, g.max_items = _K._c_items, C.pointer(_K._c_count), 64
+    g.side_stream, g.side_ws, g.side_ws_bytes = side, sws, swsb
+    need = lib.hirest_train_block_backward_scratch_bytes(C.byref(d))
+    scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+    g.scratch, g.scratch_bytes = scratch.data_ptr(), need
+    _chk(lib.hirest_train_block_backward(C.byref(d), C.byref(g), ops.stream_ptr()), "train_block_backward")
+    _K._c_keep.append((scratch, dout, Ly))                     # read by the grouped column sums (and the side stream) after this call returns
+    if st is not None:
+        st["c_used"] = True                                    # side_join waits for the side stream
+        st["keep"].append((scratch, dout, Ly))
+    for name, t in out.items():
+        G[p + name] = t
+    for k, nm in enumerate(("query", "key", "value")):
+        G[p + f"attention.self.{nm}.weight"] = dwqkv[k * Hd:(k + 1) * Hd]
+        G[p + f"attention.self.{nm}.bias"] = dbqkv[k * Hd:(k + 1) * Hd]
+    return dx
+
+
+
 def _encoder_forward(model, P, inp, S):
     """Fusion + VisualModel (modeling.py:155-210) keeping what the backward needs in S.  Returns feats [B*T, 768]."""
     lib = _lib.load()
@@ -348,6 +460,11 @@ def _encoder_forward(model, P, inp, S):
         p = _V + f"encoder.layer.{i}."
         wqkv = torch.cat([P[p + "attention.self.query.weight"], P[p + "attention.self.key.weight"], P[p + "attention.self.value.weight"]], 0).contiguous()
         bqkv = torch.cat([P[p + "attention.self.query.bias"], P[p + "attention.self.key.bias"], P[p + "attention.self.value.bias"]], 0).contiguous()
+        if C_BLOCKS and LAYOUT_GEMM and not STRIDED_GEMM:
+            Ly = _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed)
+            layers.append(Ly)
+            x = Ly["out"]
+            continue
         qkv = _K.gemm(x, wqkv, bqkv)
         Pm = torch.empty((B, heads, T, T), dtype=torch.float32, device=vis.device)
         cx = torch.empty((R, Hd), dtype=torch.float32, device=vis.device)
@@ -379,6 +496,9 @@ def _encoder_backward(model, P, S, dx, G):
     for i in reversed(range(len(S["layers"]))):
         p = _V + f"encoder.layer.{i}."
         Ly = S["layers"][i]
+        if "desc" in Ly:
+            dx = _block_backward(P, p, Ly, dx, G)
+            continue
         dxp, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = _K.layernorm_bwd(Ly["x_pre"], dx, P[p + "output.LayerNorm.weight"], 1e-12)
         dy = _K.dropout_add(dxp, None, drop, seed + 12 + 4 * i)           # through dropout(y); the residual branch gets dxp as is
         G[p + "output.dense.weight"] = _K.grad_weight(dy, Ly["hh"])
@@ -463,6 +583,9 @@ def _colsum_batched(backward):
             return out
         finally:
             _K._pending = None
+            if _K._c_count is not None:
+                _K._c_count.value = 0
+            _K._c_keep = []
             _K.side_join()
     return wrapped
 

@@ -829,6 +829,50 @@ int hirest_joint_encoder_x3_forward(const hirest_joint_encoder_x3* e, const floa
 int hirest_layernorm_f32_split2(const float* x, int64_t ldx, const float* add, int32_t period, const float* gamma, const float* beta, float eps,
                                 float* out32, int64_t ldo32, hirest_bf16* out2, int64_t ldo2, int32_t rows, int32_t D, void* stream);
 
+
+/* ------------------------------------------------------------------------------------
+ * One post-LN block of the clip4caption VisualModel in TRAIN mode (module_visual.py:132-264; modeling.py:196-211 under
+ * MomentModel.train_step, run.py:238-295) issued by one C call per direction: the same kernels, operands and order as the
+ * per-kernel calls above (hirest_gemm_f32_ws, hirest_attention_train_*, hirest_dropout_add_f32, hirest_layernorm,
+ * hirest_act_*, hirest_layernorm_bwd_f32, hirest_gemm_f32_layouts) — bit-identical results — without ~37 trips through the
+ * host language per block: at B = 5, T = 300 the step is paced by the host's enqueue rate, not by a kernel.
+ *   forward:  qkv = x Wqkv^T + b;  (P, cx) = attention(qkv);  a_pre = x + drop(cx Wo^T + bo);  aa = LN1(a_pre);
+ *             hpre = aa W1^T + b1;  hh = gelu(hpre);  x_pre = aa + drop(hh W2^T + b2);  out = LN2(x_pre)
+ *   backward: dX products on `stream`; the four weight-gradient products dW = dY^T X on `side_stream` (NULL: on `stream`)
+ *             behind an event that marks their dY complete — the caller joins the side stream before reading g_w*; the
+ *             twelve column sums (bias and LayerNorm gradients) are APPENDED to `items` for one
+ *             hirest_weighted_colsum_grouped_f32 by the caller once the whole backward is enqueued.
+ * precision 0: exact fp32 products (hirest_gemm_f32*).  precision 1 ("bf16x3"): the forward products and the dX products on
+ * split operands (HIREST_GEMM_X3 | HIREST_GEMM_X3_T128; weights split per call into `scratch`), dW stays fp32.
+ * All buffers fp32, caller-allocated; `scratch` of *_scratch_bytes() must stay alive and untouched until the grouped column
+ * sums and the side stream's products have executed. */
+typedef struct hirest_train_block {
+    uint64_t struct_size;
+    int32_t B, T, heads, width, mlp, precision;
+    float ln_eps, drop;
+    uint32_t seed_attn, seed_ao, seed_out, reserved;      /* dropout counters: attention probabilities, attention.output, output */
+    const float *wqkv, *bqkv;                             /* [3 width, width] (query | key | value rows), [3 width]             */
+    const float *wo, *bo, *ln1_g, *ln1_b;                 /* attention.output.dense / LayerNorm                                 */
+    const float *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;       /* intermediate.dense [mlp, width], output.dense [width, mlp], output.LayerNorm */
+    const float* x;                                       /* block input [B T, width]                                           */
+    float *qkv, *P, *cx, *a_pre, *aa, *hpre, *hh, *x_pre, *out;   /* kept for the backward: [R,3W] [B,H,T,T] [R,W] [R,W] [R,W] [R,mlp] [R,mlp] [R,W]; out [R,W] */
+    void* ws; size_t ws_bytes;                            /* split-form scratch of the fp32 GEMMs on `stream` (hirest_gemm_f32_workspace_bytes) */
+} hirest_train_block;
+typedef struct hirest_train_block_grads {
+    uint64_t struct_size;
+    const float* dout;                                    /* d loss / d out [R, W]                                              */
+    float* dx;                                            /* d loss / d x   [R, W]                                              */
+    float *g_wqkv, *g_wo, *g_w1, *g_w2;                   /* [3W, W] [W, W] [mlp, W] [W, mlp]                                   */
+    float *g_bqkv, *g_bo, *g_b1, *g_b2, *g_ln1_g, *g_ln1_b, *g_ln2_g, *g_ln2_b;
+    hirest_colsum_item* items; int32_t* n_items; int32_t max_items, reserved;
+    void* side_stream; void* side_ws; size_t side_ws_bytes;
+    void* scratch; size_t scratch_bytes;
+} hirest_train_block_grads;
+size_t hirest_train_block_forward_scratch_bytes(const hirest_train_block* b);
+int hirest_train_block_forward(const hirest_train_block* b, void* scratch, size_t scratch_bytes, void* stream);
+size_t hirest_train_block_backward_scratch_bytes(const hirest_train_block* b);
+int hirest_train_block_backward(const hirest_train_block* b, const hirest_train_block_grads* g, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,6 +297,38 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_backward(de
         train.SIDE_STREAM_DW = True
 
 
+def test_encoder_blocks_issued_from_c_equal_the_per_kernel_calls(dev, golden_dir):
+    """train.C_BLOCKS: one C call per encoder block and direction (csrc/train_block.hip) issues the same entry points on the same operands
+    in the same order as the per-kernel Python calls — loss and every gradient equal bit for bit, in train mode (same seed, same dropout
+    masks) and in eval mode, with and without the side stream, retrieval and segmentation."""
+    from hirest_amd import train
+    model, batch, seg_batch, _, _ = _setup(golden_dir, "a", dev)
+
+    def grads(b, c_blocks, side, seed):
+        train.C_BLOCKS, train.SIDE_STREAM_DW = c_blocks, side
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(seed)
+        loss = model.train_step(b)["loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    try:
+        for mode in ("train", "eval"):
+            getattr(model, mode)()
+            for b in (batch, seg_batch):
+                for side in (True, False):
+                    lw, want = grads(b, False, side, 23)
+                    for rep in range(3):
+                        lg, got = grads(b, True, side, 23)
+                        assert torch.equal(lw, lg), (mode, b["tasks"][0], side, rep)
+                        assert got.keys() == want.keys()
+                        for n in want:
+                            assert torch.equal(got[n], want[n]), (mode, b["tasks"][0], side, n, rep)
+    finally:
+        train.C_BLOCKS, train.SIDE_STREAM_DW = True, True
+
+
 def test_backward_refuses_parameters_updated_in_place_after_the_forward(dev, golden_dir):
     """The forward keeps fp32 parameters by reference and the backward multiplies by them again: forward A, forward B, backward A,
     optimizer.step(), backward B would back-propagate B through the updated weights.  The version counters recorded in the forward
