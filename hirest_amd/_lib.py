@@ -120,12 +120,19 @@ class ColsumItem(C.Structure):
 COLSUM_GROUP_MAX = 40
 
 
+class SplitItem(C.Structure):
+    """hirest_split_item (include/hirest_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("ldx", C.c_int64), ("ldo", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("transposed", C.c_int32), ("reserved", C.c_int32)]
+
+
 class TrainBlock(C.Structure):
     """hirest_train_block (include/hirest_hip.h): one post-LN encoder block in train mode, forward + what its backward needs."""
     _fields_ = [("struct_size", C.c_uint64)] + [(n, C.c_int32) for n in ("B", "T", "heads", "width", "mlp", "precision")] + \
                [("ln_eps", C.c_float), ("drop", C.c_float)] + [(n, C.c_uint32) for n in ("seed_attn", "seed_ao", "seed_out", "reserved")] + \
                [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b", "x",
-                                          "qkv", "P", "cx", "a_pre", "aa", "hpre", "hh", "x_pre", "out", "ws")] + [("ws_bytes", C.c_size_t)]
+                                          "qkv", "P", "cx", "a_pre", "aa", "hpre", "hh", "x_pre", "out", "x2", "out2",
+                                          "wqkv2", "wo2", "w12", "w22", "wqkvT2", "woT2", "w1T2", "w2T2", "ws")] + [("ws_bytes", C.c_size_t)]
 
 
 class TrainBlockGrads(C.Structure):
@@ -308,6 +315,8 @@ _SIGNATURES = {
     "hirest_layernorm_f32_split2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_split2_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "hirest_split2_grouped_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "hirest_split2_transposed_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "hirest_layernorm_split2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int32,
                                           C.c_int32, C.c_void_p]),
     "hirest_attention_x3_qkv": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

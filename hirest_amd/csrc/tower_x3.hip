@@ -76,6 +76,95 @@ __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x
 
 
 
+// out[c] = split(x[:, c]): the split operand of a product that contracts over the ROWS of a row-major fp32 matrix (dX = dY W: W^T as the GEMM's
+// B operand) without a transposed fp32 copy.  One block per 32 rows x 64 columns: coalesced row reads, an LDS transpose, 128-B stores.
+__global__ __launch_bounds__(256) void split2_transposed_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo,
+                                                               int rows, int cols) {
+    __shared__ float tile[32][65];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 64, t = threadIdx.x;
+    {
+        const int r = t >> 3, c = (t & 7) * 8;
+        const float* src = x + (int64_t)(r0 + r) * ldx + c0 + c;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c0 + c + 4 * h + 3 < cols) v = *reinterpret_cast<const f32x4*>(src + 4 * h);
+            else
+                for (int e = 0; e < 4; ++e) if (c0 + c + 4 * h + e < cols) v[e] = src[4 * h + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][c + 4 * h + e] = v[e];
+        }
+    }
+    __syncthreads();
+    const int c = t >> 2, part = (t & 3) * 8;
+    if (c0 + c >= cols) return;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = tile[part + e][c];
+        hi[e] = (bf16_t)v; lo[e] = (bf16_t)(v - (float)hi[e]);
+    }
+    bf16_t* o = out + (int64_t)(c0 + c) * ldo + (r0 >> 5) * 64 + part;
+    *reinterpret_cast<bf16x8*>(o) = hi;
+    *reinterpret_cast<bf16x8*>(o + 32) = lo;
+}
+
+// Several matrices split in ONE launch (hirest_split2_grouped_bf16): a training step splits the four weights of every encoder block both ways
+// (forward: W as the B operand; backward: W^T) — sixteen launches of 5 - 17 us for 2 blocks, against ~25 us of traffic.  One block per 32 x 64
+// input tile; the item table travels in the kernel arguments and a block finds its item by comparing against the running tile counts.
+struct SplitItems { hirest_split_item it[HIREST_SPLIT_GROUP_MAX]; int first[HIREST_SPLIT_GROUP_MAX + 1]; int count; };
+__global__ __launch_bounds__(256) void split2_grouped_kernel(const SplitItems g) {
+    __shared__ float tile[32][65];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < HIREST_SPLIT_GROUP_MAX; ++i) k += (i < g.count && (int)blockIdx.x >= g.first[i]) ? 1 : 0;
+    const hirest_split_item& it = g.it[k];
+    const int local = blockIdx.x - g.first[k], tiles_c = (it.cols + 63) / 64;
+    const int r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 64, t = threadIdx.x;
+    const int r = t >> 3, c = (t & 7) * 8;
+    f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (r0 + r < it.rows) {
+        const float* src = it.x + (int64_t)(r0 + r) * it.ldx + c0 + c;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (c0 + c + 4 * h + 3 < it.cols) v[h] = *reinterpret_cast<const f32x4*>(src + 4 * h);
+            else
+                for (int e = 0; e < 4; ++e) if (c0 + c + 4 * h + e < it.cols) v[h][e] = src[4 * h + e];
+        }
+    }
+    bf16_t* out = reinterpret_cast<bf16_t*>(it.out);
+    if (!it.transposed) {                                                        // (wave-uniform: one item per block)
+        if (r0 + r >= it.rows || c0 + c >= it.cols) return;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (bf16_t)v[0][e]; lo[e] = (bf16_t)(v[0][e] - (float)hi[e]);
+            hi[4 + e] = (bf16_t)v[1][e]; lo[4 + e] = (bf16_t)(v[1][e] - (float)hi[4 + e]);
+        }
+        const int col = c0 + c;
+        bf16_t* o = out + (int64_t)(r0 + r) * it.ldo + (col >> 5) * 64 + (col & 31);
+        *reinterpret_cast<bf16x8*>(o) = hi;
+        *reinterpret_cast<bf16x8*>(o + 32) = lo;
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][c + 4 * h + e] = v[h][e];
+    __syncthreads();
+    const int cc = t >> 2, part = (t & 3) * 8;
+    if (c0 + cc >= it.cols) return;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float w = tile[part + e][cc];                                      // rows past it.rows were loaded as zeros
+        hi[e] = (bf16_t)w; lo[e] = (bf16_t)(w - (float)hi[e]);
+    }
+    bf16_t* o = out + (int64_t)(c0 + cc) * it.ldo + (r0 >> 5) * 64 + part;
+    *reinterpret_cast<bf16x8*>(o) = hi;
+    *reinterpret_cast<bf16x8*>(o + 32) = lo;
+}
+
 // LayerNorm (layernorm_rows' arithmetic: ln_wave_stats / ln_apply) with the split as its store: one wave per row
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_split2_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
@@ -132,6 +221,38 @@ extern "C" int hirest_split2_bf16(const float* x, int64_t ldx, hirest_bf16* out,
     bf16_t* o = reinterpret_cast<bf16_t*>(out);
     if (act == 1) hipLaunchKernelGGL(split2_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, o, ldo, rows, D);
     else hipLaunchKernelGGL(split2_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, o, ldo, rows, D);
+    return hirest_launch_status();
+}
+
+
+extern "C" int hirest_split2_transposed_bf16(const float* x, int64_t ldx, hirest_bf16* out, int64_t ldo, int32_t rows, int32_t cols, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return HIREST_E_BADARG;
+    if (rows % 32 != 0 || ldx % 4 != 0 || ldo % 8 != 0 || ldo < 2 * (int64_t)rows) return HIREST_E_SHAPE;
+    hipLaunchKernelGGL(split2_transposed_kernel, dim3((cols + 63) / 64, rows / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                       reinterpret_cast<bf16_t*>(out), ldo, rows, cols);
+    return hirest_launch_status();
+}
+
+
+extern "C" int hirest_split2_grouped_bf16(const hirest_split_item* items, int32_t count, void* stream) {
+    if (!items || count <= 0) return HIREST_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int base = 0; base < count; base += HIREST_SPLIT_GROUP_MAX) {
+        SplitItems g;
+        g.count = count - base < HIREST_SPLIT_GROUP_MAX ? count - base : HIREST_SPLIT_GROUP_MAX;
+        int total = 0;
+        for (int i = 0; i < g.count; ++i) {
+            const hirest_split_item& it = items[base + i];
+            if (!it.x || !it.out || it.rows <= 0 || it.cols <= 0) return HIREST_E_BADARG;
+            const int64_t k = it.transposed ? it.rows : it.cols;                   // the contracted dimension: whole 32-blocks (rows: zero filled)
+            if (it.ldx % 4 != 0 || it.ldo % 8 != 0 || (!it.transposed && it.cols % 32 != 0) || it.ldo < 2 * ((k + 31) / 32 * 32)) return HIREST_E_SHAPE;
+            g.it[i] = it;
+            g.first[i] = total;
+            total += ((it.rows + 31) / 32) * ((it.cols + 63) / 64);
+        }
+        for (int i = g.count; i <= HIREST_SPLIT_GROUP_MAX; ++i) g.first[i] = total;
+        hipLaunchKernelGGL(split2_grouped_kernel, dim3(total), dim3(256), 0, s, g);
+    }
     return hirest_launch_status();
 }
 

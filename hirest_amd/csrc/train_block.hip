@@ -71,6 +71,40 @@ int grad_weight(const float* dy, int64_t ldy, const float* x, int64_t ldx, float
     return gemm_layouts(dy, ldy, 1, x, ldx, 1, nullptr, 0, out, O, I, R, g->side_ws, g->side_ws_bytes, side);
 }
 
+// ---- precision 1: forward and dX products on split operands (three bf16 MFMAs per product, gemm_t128x3) ----
+int gemm_x3(const hirest_bf16* A2, const hirest_bf16* W2, const float* bias, float* out, int M, int N, int K, int epi, void* part, hipStream_t s) {
+    hirest_gemm_args a;
+    a.struct_size = sizeof(a);
+    a.A = A2; a.lda = 2 * (int64_t)K; a.W = W2; a.ldw = 2 * (int64_t)K; a.bias = bias; a.out = out; a.ldo = N;
+    a.M = M; a.N = N; a.K = 2 * K; a.epilogue = epi; a.pos = nullptr; a.patches_per_frame = 0; a.aux0 = part; a.aux1 = nullptr;
+    a.flags = HIREST_GEMM_X3 | HIREST_GEMM_X3_T128;
+    return hirest_gemm_bf16(&a, s);
+}
+inline size_t alb(size_t bf16s) { return (bf16s + 127) & ~(size_t)127; }         // 256-B aligned bf16 slices
+
+struct FwdX3 { size_t o, part, x2, cx2, aa2, hh2, wqkv2, wo2, w12, w22, total; };
+FwdX3 plan_fwd_x3(const Shape& d) {
+    FwdX3 r; size_t off = 0;
+    auto f32 = [&off](size_t n) { size_t at = off; off += al(n) * 4; return at; };
+    auto b16 = [&off](size_t n) { size_t at = off; off += alb(n) * 2; return at; };
+    r.o = f32(d.R * d.W); r.part = f32(4 * d.R * d.W);
+    r.x2 = b16(d.R * 2 * d.W); r.cx2 = b16(d.R * 2 * d.W); r.aa2 = b16(d.R * 2 * d.W); r.hh2 = b16(d.R * 2 * d.mlp);
+    r.wqkv2 = b16(d.M3 * 2 * d.W); r.wo2 = b16(d.W * 2 * d.W); r.w12 = b16(d.mlp * 2 * d.W); r.w22 = b16(d.W * 2 * d.mlp);
+    r.total = off;
+    return r;
+}
+struct BwdX3 { size_t part, dy2, dhp2, do2, dqkv2, w2t, w1t, wot, wqkvt, total; };
+BwdX3 plan_bwd_x3(const Shape& d, size_t base) {
+    BwdX3 r; size_t off = base;
+    auto f32 = [&off](size_t n) { size_t at = off; off += al(n) * 4; return at; };
+    auto b16 = [&off](size_t n) { size_t at = off; off += alb(n) * 2; return at; };
+    r.part = f32(4 * d.R * d.W);
+    r.dy2 = b16(d.R * 2 * d.W); r.dhp2 = b16(d.R * 2 * d.mlp); r.do2 = b16(d.R * 2 * d.W); r.dqkv2 = b16(d.R * 2 * d.M3);
+    r.w2t = b16(d.mlp * 2 * d.W); r.w1t = b16(d.W * 2 * d.mlp); r.wot = b16(d.W * 2 * d.W); r.wqkvt = b16(d.W * 2 * d.M3);
+    r.total = off;
+    return r;
+}
+
 int colsum_item(const hirest_train_block_grads* g, const float* x, int64_t ldx, int R, int C, float* out) {
     if (!g->items || !g->n_items || *g->n_items >= g->max_items) return HIREST_E_BADARG;
     hirest_colsum_item& it = g->items[(*g->n_items)++];
@@ -83,16 +117,50 @@ int colsum_item(const hirest_train_block_grads* g, const float* x, int64_t ldx, 
 extern "C" size_t hirest_train_block_forward_scratch_bytes(const hirest_train_block* b) {
     if (!block_ok(b)) return 0;
     const Shape d(b);
+    if (b->precision == 1) return plan_fwd_x3(d).total;
     return al(d.R * d.W) * sizeof(float);                                        // o / y: the dense outputs in front of their dropout + add
 }
 
 extern "C" int hirest_train_block_forward(const hirest_train_block* b, void* scratch, size_t scratch_bytes, void* stream) {
     if (!block_ok(b) || !scratch || scratch_bytes < hirest_train_block_forward_scratch_bytes(b)) return HIREST_E_BADARG;
-    if (b->precision != 0) return HIREST_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Shape d(b);
     const int R = (int)d.R, W = (int)d.W, M3 = (int)d.M3, mlp = (int)d.mlp, dh = W / b->heads;
     const float scale = (float)pow((double)dh, -0.5);
+    if (b->precision == 1) {
+        if (W % 32 != 0 || mlp % 32 != 0 || W > 2048) return HIREST_E_SHAPE;
+        const FwdX3 r = plan_fwd_x3(d);
+        char* base = reinterpret_cast<char*>(scratch);
+        auto H = [base](size_t at) { return reinterpret_cast<hirest_bf16*>(base + at); };
+        float* o = reinterpret_cast<float*>(base + r.o);
+        void* part = base + r.part;
+        // the four weights in the operand format (they change every optimizer step): the caller's, or split here
+        const hirest_bf16 *wqkv2 = b->wqkv2, *wo2 = b->wo2, *w12 = b->w12, *w22 = b->w22;
+        if (!wqkv2 || !wo2 || !w12 || !w22) {
+            CHECK(hirest_split2_bf16(b->wqkv, W, H(r.wqkv2), 2 * W, M3, W, 0, s));
+            CHECK(hirest_split2_bf16(b->wo, W, H(r.wo2), 2 * W, W, W, 0, s));
+            CHECK(hirest_split2_bf16(b->w1, W, H(r.w12), 2 * W, mlp, W, 0, s));
+            CHECK(hirest_split2_bf16(b->w2, mlp, H(r.w22), 2 * mlp, W, mlp, 0, s));
+            wqkv2 = H(r.wqkv2); wo2 = H(r.wo2); w12 = H(r.w12); w22 = H(r.w22);
+        }
+        const hirest_bf16* x2 = b->x2;
+        if (!x2) { CHECK(hirest_split2_bf16(b->x, W, H(r.x2), 2 * W, R, W, 0, s)); x2 = H(r.x2); }
+        CHECK(gemm_x3(x2, wqkv2, b->bqkv, b->qkv, R, M3, W, HIREST_EPI_BIAS_F32, nullptr, s));
+        CHECK(hirest_attention_train_fwd_f32(b->qkv, b->P, b->cx, b->B, b->T, b->heads, dh, scale, -10000.0f, b->drop, b->seed_attn, s));
+        CHECK(hirest_split2_bf16(b->cx, W, H(r.cx2), 2 * W, R, W, 0, s));
+        CHECK(gemm_x3(H(r.cx2), wo2, b->bo, o, R, W, W, HIREST_EPI_BIAS_F32, nullptr, s));
+        CHECK(hirest_dropout_add_f32(o, b->x, b->a_pre, d.R * d.W, b->drop, b->seed_ao, s));
+        CHECK(hirest_layernorm_f32_split2(b->a_pre, W, nullptr, 0, b->ln1_g, b->ln1_b, b->ln_eps, b->aa, W, H(r.aa2), 2 * W, R, W, s));
+        CHECK(gemm_x3(H(r.aa2), w12, b->b1, b->hpre, R, mlp, W, HIREST_EPI_BIAS_F32, nullptr, s));
+        CHECK(hirest_act_f32(b->hpre, b->hh, d.R * d.mlp, 1, s));
+        CHECK(hirest_split2_bf16(b->hh, mlp, H(r.hh2), 2 * mlp, R, mlp, 0, s));
+        // the 3072-deep product: K slices on otherwise idle CUs (accumulate form onto zeros)
+        if (hipError_t e = hipMemsetAsync(o, 0, (size_t)d.R * d.W * sizeof(float), s)) return (int)e;
+        CHECK(gemm_x3(H(r.hh2), w22, b->b2, o, R, W, mlp, HIREST_EPI_BIAS_RESID_F32, part, s));
+        CHECK(hirest_dropout_add_f32(o, b->aa, b->x_pre, d.R * d.W, b->drop, b->seed_out, s));
+        CHECK(hirest_layernorm_f32_split2(b->x_pre, W, nullptr, 0, b->ln2_g, b->ln2_b, b->ln_eps, b->out, W, b->out2, 2 * W, R, W, s));
+        return 0;
+    }
     float* o = reinterpret_cast<float*>(scratch);
     CHECK(gemm(b->x, W, b->wqkv, W, b->bqkv, b->qkv, R, M3, W, b->ws, b->ws_bytes, s));
     CHECK(hirest_attention_train_fwd_f32(b->qkv, b->P, b->cx, b->B, b->T, b->heads, dh, scale, -10000.0f, b->drop, b->seed_attn, s));
@@ -111,18 +179,35 @@ extern "C" size_t hirest_train_block_backward_scratch_bytes(const hirest_train_b
     if (!block_ok(b)) return 0;
     const Shape d(b);
     // dxp, dyx2, dy, da, dap, dyx1, do, dcx: [R, W] each;  dh, dhp: [R, mlp];  dS: [B, H, T, T];  dqkv: [R, 3 W]
-    return (8 * al(d.R * d.W) + 2 * al(d.R * d.mlp) + al(d.PT) + al(d.R * d.M3)) * sizeof(float);
+    const size_t f32_part = (8 * al(d.R * d.W) + 2 * al(d.R * d.mlp) + al(d.PT) + al(d.R * d.M3)) * sizeof(float);
+    return b->precision == 1 ? plan_bwd_x3(d, f32_part).total : f32_part;
 }
 
 extern "C" int hirest_train_block_backward(const hirest_train_block* b, const hirest_train_block_grads* g, void* stream) {
     if (!block_ok(b) || !g || g->struct_size != sizeof(*g) || !g->dout || !g->dx || !g->scratch ||
         g->scratch_bytes < hirest_train_block_backward_scratch_bytes(b))
         return HIREST_E_BADARG;
-    if (b->precision != 0) return HIREST_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Shape d(b);
     const int R = (int)d.R, W = (int)d.W, M3 = (int)d.M3, mlp = (int)d.mlp, dh = W / b->heads;
     const float scale = (float)pow((double)dh, -0.5);
+    const bool x3 = b->precision == 1;
+    if (x3 && (W % 32 != 0 || mlp % 32 != 0)) return HIREST_E_SHAPE;
+    char* sbase = reinterpret_cast<char*>(g->scratch);
+    const BwdX3 q = plan_bwd_x3(d, (8 * al(d.R * d.W) + 2 * al(d.R * d.mlp) + al(d.PT) + al(d.R * d.M3)) * sizeof(float));
+    auto H = [sbase](size_t at) { return reinterpret_cast<hirest_bf16*>(sbase + at); };
+    void* part = sbase + q.part;
+    // dX = dY W on split operands: A = split(dY), B = split(W^T) (hirest_split2_transposed_bf16); `resid` is copied into dx first and the
+    // product accumulates onto it (resid itself may still be read by the side stream's dW product)
+    auto dx_x3 = [&](const float* dY, int O, hirest_bf16* dY2, const float* Wt, int I, const hirest_bf16* given, hirest_bf16* mine, const float* resid,
+                     float* dx) -> int {
+        CHECK(hirest_split2_bf16(dY, O, dY2, 2 * O, R, O, 0, s));
+        const hirest_bf16* WT2 = given;
+        if (!WT2) { CHECK(hirest_split2_transposed_bf16(Wt, I, mine, 2 * O, O, I, s)); WT2 = mine; }
+        if (!resid) return gemm_x3(dY2, WT2, nullptr, dx, R, I, O, HIREST_EPI_BIAS_F32, nullptr, s);
+        if (hipError_t e = hipMemcpyAsync(dx, resid, (size_t)R * I * sizeof(float), hipMemcpyDeviceToDevice, s)) return (int)e;
+        return gemm_x3(dY2, WT2, nullptr, dx, R, I, O, HIREST_EPI_BIAS_RESID_F32, part, s);
+    };
     float* p = reinterpret_cast<float*>(g->scratch);
     auto take = [&p](int64_t n) { float* q = p; p += al((size_t)n); return q; };
     float *dxp = take(d.R * d.W), *dyx2 = take(d.R * d.W), *dyb = take(d.R * d.W), *da = take(d.R * d.W), *dap = take(d.R * d.W),
@@ -138,11 +223,13 @@ extern "C" int hirest_train_block_backward(const hirest_train_block* b, const hi
     if (drop) { CHECK(hirest_dropout_add_f32(dxp, nullptr, dyb, d.R * d.W, b->drop, b->seed_out, s)); dy = dyb; }
     CHECK(grad_weight(dy, W, b->hh, mlp, g->g_w2, W, mlp, R, b, g, s));
     CHECK(colsum_item(g, dy, W, R, W, g->g_b2));
-    CHECK(gemm_layouts(dy, W, 0, b->w2, mlp, 1, nullptr, 0, dhid, R, mlp, W, b->ws, b->ws_bytes, s));          // dX = dY W: B(n = i, k = o) = W[o][i]
+    if (x3) CHECK(dx_x3(dy, W, H(q.dy2), b->w2, mlp, b->w2T2, H(q.w2t), nullptr, dhid));
+    else CHECK(gemm_layouts(dy, W, 0, b->w2, mlp, 1, nullptr, 0, dhid, R, mlp, W, b->ws, b->ws_bytes, s));     // dX = dY W: B(n = i, k = o) = W[o][i]
     CHECK(hirest_act_bwd_f32(b->hpre, dhid, dhp, d.R * d.mlp, 1, s));
     CHECK(grad_weight(dhp, mlp, b->aa, W, g->g_w1, mlp, W, R, b, g, s));
     CHECK(colsum_item(g, dhp, mlp, R, mlp, g->g_b1));
-    CHECK(gemm_layouts(dhp, mlp, 0, b->w1, W, 1, dxp, W, da, R, W, mlp, b->ws, b->ws_bytes, s));                // + the residual path
+    if (x3) CHECK(dx_x3(dhp, mlp, H(q.dhp2), b->w1, W, b->w1T2, H(q.w1t), dxp, da));
+    else CHECK(gemm_layouts(dhp, mlp, 0, b->w1, W, 1, dxp, W, da, R, W, mlp, b->ws, b->ws_bytes, s));           // + the residual path
     // attention.output.LayerNorm, dropout(attention.output.dense(cx)) + x
     CHECK(hirest_layernorm_bwd_f32(b->a_pre, da, b->ln1_g, b->ln_eps, dap, dyx1, R, W, s));
     CHECK(colsum_item(g, dyx1, W, R, W, g->g_ln1_g));
@@ -151,11 +238,13 @@ extern "C" int hirest_train_block_backward(const hirest_train_block* b, const hi
     if (drop) { CHECK(hirest_dropout_add_f32(dap, nullptr, dob, d.R * d.W, b->drop, b->seed_ao, s)); dO = dob; }
     CHECK(grad_weight(dO, W, b->cx, W, g->g_wo, W, W, R, b, g, s));
     CHECK(colsum_item(g, dO, W, R, W, g->g_bo));
-    CHECK(gemm_layouts(dO, W, 0, b->wo, W, 1, nullptr, 0, dcx, R, W, W, b->ws, b->ws_bytes, s));
+    if (x3) CHECK(dx_x3(dO, W, H(q.do2), b->wo, W, b->woT2, H(q.wot), nullptr, dcx));
+    else CHECK(gemm_layouts(dO, W, 0, b->wo, W, 1, nullptr, 0, dcx, R, W, W, b->ws, b->ws_bytes, s));
     // self-attention
     CHECK(hirest_attention_train_bwd_f32(b->qkv, b->P, dcx, dS, dqkv, b->B, b->T, b->heads, dh, scale, b->drop, b->seed_attn, s));
     CHECK(grad_weight(dqkv, M3, b->x, W, g->g_wqkv, M3, W, R, b, g, s));
     CHECK(colsum_item(g, dqkv, M3, R, M3, g->g_bqkv));
-    CHECK(gemm_layouts(dqkv, M3, 0, b->wqkv, W, 1, dap, W, g->dx, R, W, M3, b->ws, b->ws_bytes, s));            // + the residual path
+    if (x3) CHECK(dx_x3(dqkv, M3, H(q.dqkv2), b->wqkv, W, b->wqkvT2, H(q.wqkvt), dap, g->dx));
+    else CHECK(gemm_layouts(dqkv, M3, 0, b->wqkv, W, 1, dap, W, g->dx, R, W, M3, b->ws, b->ws_bytes, s));       // + the residual path
     return 0;
 }

@@ -49,6 +49,11 @@ SIDE_STREAM_DW = True      # weight-gradient GEMMs of a backward on a second str
 # One C call per encoder block and direction (csrc/train_block.hip: the same entry points in the same order, issued from C — the step was
 # paced by ~150 launches per step through Python at 15-20 us each).  False / HIREST_TRAIN_C_BLOCKS=0: the per-kernel calls below (A/B, tests).
 C_BLOCKS = os.environ.get("HIREST_TRAIN_C_BLOCKS", "1") != "0"
+# Products of the encoder blocks: "fp32" (exact fp32 MFMA: the reference's own arithmetic, run.py without --fp16) or "bf16x3" (forward and
+# dX products on bf16 hi + lo splits of both operands — ~16 mantissa bits per product at 3 bf16 MFMAs; dW, attention, LayerNorm, GELU and
+# the residual stream stay fp32; the reference's counterpart is --fp16's autocast, run.py:549-551).  C_BLOCKS only.  A model switched with
+# MomentModel.set_precision('bf16x3') trains at bf16x3 whatever this says.
+GEMM_PRECISION = os.environ.get("HIREST_TRAIN_GEMM", "fp32")
 _SIDE = {}
 
 
@@ -328,7 +333,39 @@ def _block_workspaces(dev, R, Hd, mlp, side_stream):
     return main, ops.f32_gemm_workspace(dev, max(dw, 1), 1, side_stream)
 
 
-def _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed):
+def _split_block_weights(P, wqkvs, dev):
+    """bf16x3: the four weights of every encoder block in the split operand format, as they are (forward: the GEMM's B operand) and transposed
+    (backward: dX = dY W), by ONE grouped launch per 16 matrices (hirest_split2_grouped_bf16) — they change with every optimizer step.
+    Returns, per block, {field of hirest_train_block: bf16 tensor}."""
+    per, items, total = [], [], 0
+    for i, wqkv in enumerate(wqkvs):
+        p = _V + f"encoder.layer.{i}."
+        blk = {}
+        for name, w in (("wqkv", wqkv), ("wo", P[p + "attention.output.dense.weight"]), ("w1", P[p + "intermediate.dense.weight"]),
+                        ("w2", P[p + "output.dense.weight"])):
+            O, I = w.shape
+            for field, tr, shape in ((name + "2", 0, (O, 2 * I)), (name + "T2", 1, (I, 2 * O))):
+                blk[field] = (w, tr, shape, total)
+                total += (shape[0] * shape[1] + 127) // 128 * 128
+        per.append(blk)
+    buf = torch.empty((total,), dtype=torch.bfloat16, device=dev)
+    out = []
+    for blk in per:
+        o = {}
+        for field, (w, tr, shape, off) in blk.items():
+            t = buf[off:off + shape[0] * shape[1]].view(shape)
+            o[field] = t
+            items.append((w, tr, t))
+        out.append(o)
+    arr = (_lib.SplitItem * len(items))()
+    for slot, (w, tr, t) in zip(arr, items):
+        slot.x, slot.out, slot.ldx, slot.ldo = w.data_ptr(), t.data_ptr(), w.stride(0), t.shape[1]
+        slot.rows, slot.cols, slot.transposed = w.shape[0], w.shape[1], tr
+    _chk(_lib.load().hirest_split2_grouped_bf16(arr, len(items), ops.stream_ptr()), "split2_grouped")
+    return out
+
+
+def _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed, x3=False, x2=None, wsplit=None):
     """One encoder block through hirest_train_block_forward (csrc/train_block.hip); keeps the descriptor and the activations for the backward."""
     lib = _lib.load()
     dev = x.device
@@ -345,7 +382,12 @@ def _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed):
     (ws, wsb), _ = _block_workspaces(dev, R, Hd, mlp, None)
     d = _lib.TrainBlock()
     d.struct_size = C.sizeof(_lib.TrainBlock)
-    d.B, d.T, d.heads, d.width, d.mlp, d.precision = B, T, heads, Hd, mlp, 0
+    d.B, d.T, d.heads, d.width, d.mlp, d.precision = B, T, heads, Hd, mlp, int(x3)
+    out2 = torch.empty((R, 2 * Hd), dtype=torch.bfloat16, device=dev) if x3 else None
+    d.x2, d.out2 = (x2.data_ptr() if x3 and x2 is not None else None), (out2.data_ptr() if x3 else None)
+    if x3 and wsplit is not None:
+        for field, t in wsplit.items():                            # wqkv2 wo2 w12 w22 + their transposes (the backward's)
+            setattr(d, field, t.data_ptr())
     d.ln_eps, d.drop = 1e-12, float(drop)
     d.seed_attn, d.seed_ao, d.seed_out = (seed + 10 + 4 * i) & 0xFFFFFFFF, (seed + 11 + 4 * i) & 0xFFFFFFFF, (seed + 12 + 4 * i) & 0xFFFFFFFF
     for field, t in (("wqkv", wqkv), ("bqkv", bqkv), ("wo", P[p + "attention.output.dense.weight"]), ("bo", P[p + "attention.output.dense.bias"]),
@@ -360,7 +402,7 @@ def _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed):
     need = lib.hirest_train_block_forward_scratch_bytes(C.byref(d))
     scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
     _chk(lib.hirest_train_block_forward(C.byref(d), scratch.data_ptr(), need, ops.stream_ptr()), "train_block_forward")
-    return dict(desc=d, flat=flat, x=x, wqkv=wqkv, bqkv=bqkv, out=act["out"].reshape(R, Hd), dims=(R, Hd, mlp))
+    return dict(desc=d, flat=flat, x=x, x2=x2, out2=out2, wsplit=wsplit, wqkv=wqkv, bqkv=bqkv, out=act["out"].reshape(R, Hd), dims=(R, Hd, mlp))
 
 
 def _block_backward(P, p, Ly, dout, G):
@@ -456,12 +498,23 @@ def _encoder_forward(model, P, inp, S):
     S.update(B=B, T=T, vis2=vis2, v0=v0, v=v, t=t, tn=tn, tin=tin, f=f, x0=x0, mm32=mm32, bm32=bm32, n_valid=n_valid,
              text=text.float().contiguous(), boundary=boundary)
     layers = []
-    for i in range(len(model.clip4cap_model.visual.encoder.layer)):
+    nl = len(model.clip4cap_model.visual.encoder.layer)
+    cats = []
+    for i in range(nl):
         p = _V + f"encoder.layer.{i}."
-        wqkv = torch.cat([P[p + "attention.self.query.weight"], P[p + "attention.self.key.weight"], P[p + "attention.self.value.weight"]], 0).contiguous()
-        bqkv = torch.cat([P[p + "attention.self.query.bias"], P[p + "attention.self.key.bias"], P[p + "attention.self.value.bias"]], 0).contiguous()
-        if C_BLOCKS and LAYOUT_GEMM and not STRIDED_GEMM:
-            Ly = _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed)
+        cats.append((torch.cat([P[p + "attention.self.query.weight"], P[p + "attention.self.key.weight"], P[p + "attention.self.value.weight"]], 0).contiguous(),
+                     torch.cat([P[p + "attention.self.query.bias"], P[p + "attention.self.key.bias"], P[p + "attention.self.value.bias"]], 0).contiguous()))
+    c_blocks = C_BLOCKS and LAYOUT_GEMM and not STRIDED_GEMM
+    if GEMM_PRECISION not in ("fp32", "bf16x3"):
+        raise ValueError(f"hirest_amd.train.GEMM_PRECISION = {GEMM_PRECISION!r}: 'fp32' or 'bf16x3'")
+    x3 = c_blocks and (GEMM_PRECISION == "bf16x3" or getattr(model, "precision", "fp32") == "bf16x3")   # MomentModel.set_precision covers training too
+    wsplit = _split_block_weights(P, [c[0] for c in cats], vis.device) if x3 else None
+    for i in range(nl):
+        p = _V + f"encoder.layer.{i}."
+        wqkv, bqkv = cats[i]
+        if c_blocks:
+            Ly = _block_forward(P, p, i, x, wqkv, bqkv, B, T, heads, drop, seed, x3, layers[-1].get("out2") if layers else None,
+                                wsplit[i] if wsplit is not None else None)
             layers.append(Ly)
             x = Ly["out"]
             continue

@@ -413,6 +413,20 @@ typedef struct hirest_vision_tower_x3 {
 } hirest_vision_tower_x3;
 
 int hirest_split2_bf16(const float* x, int64_t ldx, hirest_bf16* out, int64_t ldo, int64_t rows, int32_t D, int32_t act, void* stream);
+/* The split of x^T without a transposed copy: x fp32 [rows, cols] -> out bf16 [cols, 2 rows] (row c = column c of x in the operand format
+ * above) — the B operand of dX = dY W for a Linear's weight W [out_features, in_features] (module_visual.py's dense layers under
+ * run.py:238-295).  rows % 32 == 0. */
+int hirest_split2_transposed_bf16(const float* x, int64_t ldx, hirest_bf16* out, int64_t ldo, int32_t rows, int32_t cols, void* stream);
+/* Any number of matrices split in one call (launches of HIREST_SPLIT_GROUP_MAX items), each as by hirest_split2_bf16 (transposed = 0, act 0;
+ * cols % 32 == 0) or hirest_split2_transposed_bf16 (transposed = 1; rows that are no multiple of 32 are zero filled up to one, ldo >= 2 x that):
+ * a training step splits its encoder weights both ways once per step.  `items` is a HOST array, copied into the kernel arguments. */
+#define HIREST_SPLIT_GROUP_MAX 16
+typedef struct hirest_split_item {
+    const float* x; hirest_bf16* out;
+    int64_t ldx, ldo;
+    int32_t rows, cols, transposed, reserved;
+} hirest_split_item;
+int hirest_split2_grouped_bf16(const hirest_split_item* items, int32_t count, void* stream);
 int hirest_layernorm_split2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, hirest_bf16* out, int64_t ldo,
                             int32_t rows, int32_t D, void* stream);
 /* softmax(q k^T * scale) v for fp32 q / k / v rows (row strides ldq / ldkv, head h at column h * dh; out [B * Tq, H * dh]) with both products
@@ -856,6 +870,12 @@ typedef struct hirest_train_block {
     const float *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;       /* intermediate.dense [mlp, width], output.dense [width, mlp], output.LayerNorm */
     const float* x;                                       /* block input [B T, width]                                           */
     float *qkv, *P, *cx, *a_pre, *aa, *hpre, *hh, *x_pre, *out;   /* kept for the backward: [R,3W] [B,H,T,T] [R,W] [R,W] [R,W] [R,mlp] [R,mlp] [R,W]; out [R,W] */
+    const hirest_bf16* x2; hirest_bf16* out2;             /* precision 1 only, both optional: x / out in the split operand format [R, 2W] (a block's out2
+                                                             is the next block's x2; without x2 the block splits x itself)              */
+    const hirest_bf16 *wqkv2, *wo2, *w12, *w22;           /* precision 1, optional (all four or none): the weights already split (hirest_split2_bf16 /
+                                                             _grouped): [3W, 2W] [W, 2W] [mlp, 2W] [W, 2 mlp]; NULL: split by the forward call       */
+    const hirest_bf16 *wqkvT2, *woT2, *w1T2, *w2T2;       /* likewise their transposes for the backward's dX products (hirest_split2_transposed_bf16):
+                                                             [W, 6W] [W, 2W] [W, 2 mlp] [mlp, 2W]; NULL: split by the backward call                  */
     void* ws; size_t ws_bytes;                            /* split-form scratch of the fp32 GEMMs on `stream` (hirest_gemm_f32_workspace_bytes) */
 } hirest_train_block;
 typedef struct hirest_train_block_grads {

@@ -84,6 +84,47 @@ def test_layernorm_f32_split2(dev, rows, D, period):
         assert call(3072, o32.data_ptr()) == E_SHAPE and call(48, o32.data_ptr()) == E_SHAPE and call(32, None) == E_BADARG
 
 
+@pytest.mark.parametrize("rows,cols", [(768, 768), (768, 3072), (3072, 768), (2304, 768), (32, 5), (64, 130)])
+def test_split2_transposed_equals_split_of_the_transposed_copy(dev, rows, cols):
+    """hirest_split2_transposed_bf16: W [out, in] fp32 -> the split of W^T ([in, 2 out]) — the B operand of dX = dY W in the training step."""
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    x = synth.tensor(f"jx3.t.{rows}.{cols}", (rows, cols + 3), 1.3, 31).to(dev)[:, :cols]            # a row stride that is not the width
+    if x.stride(0) % 4 != 0:
+        x = torch.nn.functional.pad(x, (0, 4 - cols % 4))[:, :cols] if False else synth.tensor(f"jx3.t.{rows}.{cols}", (rows, cols + 4 - cols % 4 + 4), 1.3, 31).to(dev)[:, :cols]
+    out = torch.full((cols, 2 * rows), 7.0, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.hirest_split2_transposed_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), 2 * rows, rows, cols, ops.stream_ptr()), "split2_transposed")
+    want = ops.split2(x.t().contiguous())
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    assert lib.hirest_split2_transposed_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), 2 * rows, rows - 1, cols, ops.stream_ptr()) == -2
+
+
+def test_split2_grouped_equals_the_single_calls(dev):
+    """hirest_split2_grouped_bf16: 19 matrices (two launches), direct and transposed, ragged row counts for the transposed ones."""
+    from hirest_amd import _lib, ops
+    lib = _lib.load()
+    shapes = [(768, 768, 0), (768, 768, 1), (2304, 768, 0), (2304, 768, 1), (3072, 768, 0), (3072, 768, 1), (768, 3072, 0), (768, 3072, 1),
+              (1500, 768, 1), (1500, 3072, 1), (7, 64, 0), (7, 64, 1), (33, 96, 1), (1, 32, 0), (100, 2304, 0), (64, 5, 1), (31, 1, 1), (40, 160, 0),
+              (1500, 2304, 1)]
+    arr = (_lib.SplitItem * len(shapes))()
+    keep, want = [], []
+    for slot, (rows, cols, tr) in zip(arr, shapes):
+        x = synth.tensor(f"jx3.g.{rows}.{cols}.{tr}", (rows, (cols + 3) // 4 * 4), 1.1, 41).to(dev)[:, :cols]
+        rp = (rows + 31) // 32 * 32
+        out = torch.full((cols, 2 * rp) if tr else (rows, 2 * cols), 3.0, dtype=torch.bfloat16, device=dev)
+        slot.x, slot.out, slot.ldx, slot.ldo, slot.rows, slot.cols, slot.transposed = x.data_ptr(), out.data_ptr(), x.stride(0), out.shape[1], rows, cols, tr
+        keep.append((x, out))
+        if tr:
+            xt = torch.zeros((cols, rp), device=dev)
+            xt[:, :rows] = x.t()
+            want.append(ops.split2(xt))
+        else:
+            want.append(ops.split2(x.contiguous()))
+    _lib.check(lib.hirest_split2_grouped_bf16(arr, len(shapes), ops.stream_ptr()), "split2_grouped")
+    for (x, out), w, sh in zip(keep, want, shapes):
+        assert torch.equal(out.view(torch.int16), w.view(torch.int16)), sh
+
+
 # (M, N, K): the encoder's calls at B = 5 / B = 32 (rows = B * T) and ragged ones; K is the real depth (operands are [*, 2K])
 SHAPES = [(1500, 2304, 768), (1500, 768, 768), (1500, 3072, 768), (1500, 768, 3072), (1500, 768, 2048), (9600, 768, 768), (9600, 3072, 768),
           (300, 768, 3072), (1, 768, 768), (100, 2304, 768), (191, 96, 64), (193, 160, 96), (4100, 768, 512)]

@@ -43,8 +43,13 @@ def _setup(golden_dir, case, dev):
     return model, batch, seg_batch, cap_batch, np.load(os.path.join(golden_dir, f"train_{case}.npz"))
 
 
+# gemm: train.GEMM_PRECISION — 'bf16x3' = the encoder blocks' forward and dX products on split operands (csrc/train_block.hip, precision 1);
+# the same gates on every gradient tensor, the loss within 2e-4 instead of 1e-5 (its products carry ~16 bits)
+@pytest.mark.parametrize("gemm", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", ["a", "b"])
-def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
+def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case, gemm, monkeypatch):
+    from hirest_amd import train
+    monkeypatch.setattr(train, "GEMM_PRECISION", gemm)
     model, batch, seg_batch, cap_batch, g = _setup(golden_dir, case, dev)
     model.eval()                                   # dropout off: the arithmetic the goldens pin
     worst = 0.0
@@ -54,7 +59,7 @@ def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
         loss = model.train_step(b)["loss"]
         assert loss.requires_grad and loss.dim() == 0
         ref = float(g[prefix + "loss"])
-        assert abs(loss.item() - ref) <= 1e-5 * abs(ref), (prefix, loss.item(), ref)
+        assert abs(loss.item() - ref) <= (1e-5 if gemm == "fp32" else 2e-4) * abs(ref), (prefix, loss.item(), ref)
         loss.backward()
         names = [str(n) for n in g[prefix + "names"]]
         with_grad = {n for n, p in model.named_parameters() if p.grad is not None}
@@ -75,7 +80,7 @@ def test_train_step_loss_and_gradients_vs_reference(dev, golden_dir, case):
             if key in g.files:
                 assert np.abs(gr.numpy().reshape(g[key].shape) - g[key]).max() <= 1e-3 * np.abs(g[key]).max() + 1e-6, (prefix, n)
         print(f"case {case} {prefix or 'retrieval '}loss {loss.item():.7f} (reference {ref:.7f}), {len(names)} gradient tensors")
-    print(f"worst gradient-norm deviation {worst:.2e}")
+    print(f"[{gemm}] worst gradient-norm deviation {worst:.2e}")
     with pytest.raises(NotImplementedError):
         model.train_step({"tasks": ["something_else"]})
 

@@ -299,6 +299,28 @@ def measure(dev=None, cpu=True, log=lambda m: None):
         ent["cpu_baseline"] = {"value": tc * 1e3, "unit": "ms/step", "cores": threads, "kind": "port",
                                "sample": "oracle loss under torch autograd, forward + backward only (no optimizer)"}
     out["train_step"] = ent
+    # the same loop with the encoder blocks' forward and dX products on split operands (MomentModel.set_precision('bf16x3') covers training:
+    # csrc/train_block.hip precision 1; gradient goldens held by tests/test_gpu_train.py at the fp32 path's bars)
+    model.set_precision("bf16x3")
+    try:
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+        dx3, _ = _timeit(step, 10, sync)
+        ent3 = {"value": dx3 * 1e3, "unit": "ms/step", "higher_is_better": False, "videos_per_s": B / dx3, "task": "moment_retrieval",
+                "speedup_vs_fp32": dt / dx3,
+                "how": "encoder blocks: forward and dX products as three bf16 MFMAs per product (weights split once per step, one grouped launch); "
+                       "dW, attention, LayerNorm, GELU, losses exact fp32",
+                "roofline": {"bound": "mfma", "achieved": flops / dx3 / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flops / dx3 / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_step": flops,
+                             "note": "priced against the exact-fp32 MFMA peak like train_step (dW and attention still run there)"}}
+        try:
+            opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, fused=True)
+            dx3f, _ = _timeit(step, 10, sync)
+            ent3["ms_per_step_with_fused_adamw"] = dx3f * 1e3
+        except Exception:      # noqa: BLE001
+            ent3["ms_per_step_with_fused_adamw"] = None
+        out["train_step_bf16x3"] = ent3
+    finally:
+        model.set_precision("fp32")
     model.eval()
     del opt
 
