@@ -247,6 +247,11 @@ class _K:
         return y
 
 
+def _shaped(g, p):
+    """g in p's shape (most gradients already are: a reshape call costs the backward ~3 us of host time each, 57 per step)."""
+    return g if g.shape == p.shape else g.reshape(p.shape)
+
+
 def _f32(t):
     t = t.detach()
     return t if t.dtype is torch.float32 and t.is_contiguous() else t.float().contiguous()
@@ -726,7 +731,7 @@ class MomentLoss(torch.autograd.Function):
             _chk(lib.hirest_heads_bwd_f32(dl.data_ptr(), R, Hd, 2, ws.data_ptr(), we.data_ptr(), None, dx.data_ptr(), ops.stream_ptr()), "heads_bwd")
         _encoder_backward(model, P, S, dx, G)
         ctx.S = None
-        return (None, None, None) + tuple(G[n].reshape(P[n].shape) for n in names)
+        return (None, None, None) + tuple(_shaped(G[n], P[n]) for n in names)
 
 
 def _attn_fwd(q, ldq, k, v, ldkv, mask, B, Tq, Tk, heads, addc, drop, seed):
@@ -911,7 +916,7 @@ class CaptionLoss(torch.autograd.Function):
         G[_D + "embeddings.word_embeddings.weight"] = dWe[:V]
         _encoder_backward(model, P, S, denc, G)
         ctx.S = None
-        return (None, None, None) + tuple(G[n].reshape(P[n].shape) for n in names)
+        return (None, None, None) + tuple(_shaped(G[n], P[n]) for n in names)
 
 
 def time_grid(n_valid: torch.Tensor, T: int) -> torch.Tensor:
