@@ -47,16 +47,19 @@ int gemm_layouts(const float* A, int64_t lda, int akm, const float* Wt, int64_t 
 // "dY is complete on the main stream" markers for the side stream: a small ring of events (a wait captures the record that precedes it,
 // so reusing an event later does not disturb the waits already enqueued)
 hipEvent_t next_event() {
+    constexpr int MAXDEV = 64, RING = 64;
     static std::mutex mu;
-    static hipEvent_t ring[64];
-    static int n = 0, at = 0;
+    static hipEvent_t ring[MAXDEV][RING];
+    static int n[MAXDEV] = {}, at[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;      // events belong to the device they were created on
     std::lock_guard<std::mutex> lock(mu);
-    if (n < 64) {
-        if (hipEventCreateWithFlags(&ring[n], hipEventDisableTiming) != hipSuccess) return nullptr;
-        return ring[n++];
+    if (n[dev] < RING) {
+        if (hipEventCreateWithFlags(&ring[dev][n[dev]], hipEventDisableTiming) != hipSuccess) return nullptr;
+        return ring[dev][n[dev]++];
     }
-    at = (at + 1) & 63;
-    return ring[at];
+    at[dev] = (at[dev] + 1) % RING;
+    return ring[dev][at[dev]];
 }
 
 // dW = dY^T X: A(m = o, k = r) = dY[r][o], B(n = i, k = r) = X[r][i] — both k-major, read in place
