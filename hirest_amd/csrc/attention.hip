@@ -12,6 +12,7 @@
 // so P never leaves registers and O^T leaves each lane with 4 consecutive head-dim values (8-B stores).
 // Head dim 88 is zero-padded to 96 for the QK^T contraction; padded keys are masked to -inf.
 #include "common.h"
+#include <atomic>
 #include "profile.h"
 
 namespace {
@@ -722,14 +723,14 @@ __global__ __launch_bounds__((NW + (PROD ? 1 : 0)) * 64) void attention_kernel_v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int g_attn_dbg = 0;   // timing experiments only (hirest_attention_debug_mode)
-int g_attn_skew = 12; // de-phasing of the second wave of each SIMD, in units of ~64 cycles (hirest_attention_set_skew; results unchanged)
-int g_attn_stagger = 16;   // start offset between the CUs of an XCD, in units of ~64 cycles x (CU index mod 16) (hirest_attention_set_stagger)
-int g_attn_pace = 0;  // producer wave: ~64 x pace cycles between two K pieces (hirest_attention_set_pace)
-int g_attn_map = 2;   // hirest_attention_set_mapping: 0 = v3 gives every workgroup one frame (its heads in order), 1 = one head per workgroup over frames when the
+std::atomic<int> g_attn_dbg{0};   // timing experiments only (hirest_attention_debug_mode)
+std::atomic<int> g_attn_skew{12}; // de-phasing of the second wave of each SIMD, in units of ~64 cycles (hirest_attention_set_skew; results unchanged)
+std::atomic<int> g_attn_stagger{16};   // start offset between the CUs of an XCD, in units of ~64 cycles x (CU index mod 16) (hirest_attention_set_stagger)
+std::atomic<int> g_attn_pace{0};  // producer wave: ~64 x pace cycles between two K pieces (hirest_attention_set_pace)
+std::atomic<int> g_attn_map{2};   // hirest_attention_set_mapping: 0 = v3 gives every workgroup one frame (its heads in order), 1 = one head per workgroup over frames when the
                       // shape allows, 2 (default) = automatic: by head below 256 frames — a call of 64 frames is 64 per-frame workgroups on 256 CUs (0.131 ms)
                       // against 256 per-head ones (0.045 ms); from 256 frames on the per-frame walk is as fast or faster (1024: 0.83 vs 1.00 ms).  Same bits.
-int g_attn_variant = 7;   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame, 9 waves), 4 = v3 with 12 waves,
+std::atomic<int> g_attn_variant{7};   // 1 = v1, 2 = v2 (one workgroup per (frame, head)), 3 = v3 (persistent per frame, 9 waves), 4 = v3 with 12 waves,
                           // 5 = v3 with the lean softmax arithmetic, 6 = 5 + producer wave, 7 (default for N > 80) = v3 + producer wave (v3's bits)
 
 template <int DH, int DP, int NT, bool FAST, bool DBG, int NW = 9, bool LEAN = false, bool PROD = false>

@@ -11,6 +11,7 @@
 // P stays in registers: the C layout of S^T (lane = query; register r <-> key (r & 3) + 8 (r >> 2) + 4 half) is re-used as the B operand
 // of the second product by giving k-slot (half, i) of MFMA step s2 the key 16 s2 + 4 half + (i & 3) + 8 (i >> 2) on BOTH operands.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -239,7 +240,7 @@ void launch_x3(int nw, dim3 grid, hipStream_t s, Args... args) {
     else hipLaunchKernelGGL((attention_x3_kernel<DHP, 4>), grid, dim3(256), 0, s, args...);
 }
 long long* g_x3_trace = nullptr;   // device buffer for the phase stamps (hirest_attention_x3_debug_trace; timing tool only)
-int g_x3_waves = 0;      // 0 automatic; 3 / 4 / 8 / 9 force (hirest_attention_x3_select_waves)
+std::atomic<int> g_x3_waves{0};      // 0 automatic; 3 / 4 / 8 / 9 force (hirest_attention_x3_select_waves)
 
 }  // namespace
 

@@ -9,6 +9,7 @@
 // on later tokens and the rows kept here are bit for bit the rows a recomputation would produce (every kernel involved is
 // batch-invariant).  Beams are re-ordered every step, so each row's history is gathered from its PARENT row of the previous step.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -296,7 +297,7 @@ extern "C" size_t hirest_caption_step_workspace_bytes(const hirest_caption_decod
 
 #define CK(call) do { if (int e_ = (call)) return e_; } while (0)
 
-static int g_caption_mode = 0;     // hirest_caption_select: A/B and tests
+static std::atomic<int> g_caption_mode{0};     // hirest_caption_select: A/B and tests
 // 0 = LayerNorms / embedding inside the GEMMs and one-query attention kernels, 1 = separate LayerNorm / embedding / K-V gather kernels
 extern "C" int hirest_caption_select(int32_t mode) {
     if (mode < 0 || mode > 1) return HIREST_E_BADARG;

@@ -14,6 +14,7 @@
 // CONSECUTIVE output columns of one output row (D rows = n, D col = m): epilogue loads/stores
 // are 8-B (bf16) / 16-B (f32) vectors and bias is a 16-B load.
 #include <cstdio>
+#include <atomic>
 #include "gemm_shared.h"
 
 namespace {
@@ -1615,7 +1616,7 @@ int launch256(GemmP p, hipStream_t s) {
 }
 
 }  // namespace
-int g_gemm_dbg = 0;
+std::atomic<int> g_gemm_dbg{0};
 namespace {
 
 template <int EPI, int WM>
@@ -1659,7 +1660,7 @@ int launch_t128x3(const GemmP& p, hipStream_t s, bool allow_tall = false) {
     return t128x3_tall(p, allow_tall) ? launch_t128x3_impl<EPI, 3>(p, s) : launch_t128x3_impl<EPI, 2>(p, s);
 }
 static inline bool x3_small(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) < 256; }
-int g_force_kernel = 0;   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
+std::atomic<int> g_force_kernel{0};   // 0 auto, 1 t128, 2 t256 with a 4-slot ring, 3 t256 with a 5-slot ring (tests / A-B timing)
 
 // walk / knock-out switches of hirest_gemm_debug_mode that only gemm_pq256_dbg reads (bits 10-19)
 static inline bool pq_switches(const GemmP& p) { return p.sched || p.stagger || p.epi_dbg; }

@@ -7,6 +7,7 @@
 // (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, 1/16 of the bf16 rate) — at 10-90 GFLOP per video the
 // whole model is still a few hundred microseconds.
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -1194,7 +1195,7 @@ int launch_rows_stream(const GemmLN& q, int ng, int k, hipStream_t s) {
 // one / two blocks per CU.  Default 2: the layer products of a merged search (160 x 2304 / 3072 x 768) are a few microseconds of matrix
 // time behind a LayerNorm prologue, and a second block per CU covers one block's prologue with the other's MFMAs (B = 32, beam 5:
 // 1735 -> 1800 captions/s; mode 1: 1755)
-static int g_rows_ln_mode = 2;
+static std::atomic<int> g_rows_ln_mode{2};
 extern "C" int hirest_gemm_f32_rows_ln_mode(int32_t mode) {
     if (mode < 0 || mode > 2) return HIREST_E_BADARG;
     g_rows_ln_mode = mode;
@@ -1727,13 +1728,13 @@ inline int grid1d(int64_t total, int cap = 4096) { int64_t g = (total + 255) / 2
 }  // namespace
 
 extern "C" int hirest_gemm_f32_rows_preferred(int32_t M);
-static int g_f32_ring = 0;         // hirest_gemm_f32_ring_mode (A/B): 0 automatic, 1 off (the register-prefetch kernel), 2 always the ring
+static std::atomic<int> g_f32_ring{0};         // hirest_gemm_f32_ring_mode (A/B): 0 automatic, 1 off (the register-prefetch kernel), 2 always the ring
 extern "C" int hirest_gemm_f32_ring_mode(int32_t mode) {
     if (mode < 0 || mode > 2) return HIREST_E_BADARG;
     g_f32_ring = mode;
     return 0;
 }
-static int g_f32_kernel = 0;       // hirest_gemm_f32_select_kernel: A/B and tests
+static std::atomic<int> g_f32_kernel{0};       // hirest_gemm_f32_select_kernel: A/B and tests
 // 0 automatic (16-column kernel for M <= 256 when K % 32 == 0 [N < 8192 above 32 rows], else the split-K 32x32 kernel for M <= 256),
 // 1 always the 64x64 kernel, 2 automatic without the 16-column kernel
 extern "C" int hirest_gemm_f32_select_kernel(int32_t which) {

@@ -13,6 +13,7 @@
 // Workspace (B frames, M = B*T tokens): x f32 [M, D] residual stream, h f32 [M, D] attention output, big f32 [M, max(3D, Dm, kpad)]
 // qkv / pre-activation / patch rows, a2 bf16 [M, 2D] split operand of qkv / proj / fc1, b2 bf16 [M, 2Dm] split operand of fc2.
 #include "common.h"
+#include <atomic>
 #include "profile.h"
 
 namespace {
@@ -272,8 +273,8 @@ extern "C" int hirest_layernorm_split2(const float* x, int64_t ldx, const float*
     return hirest_launch_status();
 }
 
-static int g_x3_gelu_pass = 0;     // hirest_vision_x3_select_attention bit 1: GELU + split as a separate pass over an fp32 hidden activation (A/B)
-static int g_x3_attention = 0;     // 0: split-operand flash attention (attention_x3.hip); 1: the exact-fp32 attention of tower_f32 (A/B, tests)
+static std::atomic<int> g_x3_gelu_pass{0};     // hirest_vision_x3_select_attention bit 1: GELU + split as a separate pass over an fp32 hidden activation (A/B)
+static std::atomic<int> g_x3_attention{0};     // 0: split-operand flash attention (attention_x3.hip); 1: the exact-fp32 attention of tower_f32 (A/B, tests)
 extern "C" int hirest_vision_x3_select_attention(int32_t which) {
     if (which < 0 || which > 3) return HIREST_E_BADARG;
     g_x3_attention = which & 1;

@@ -7,6 +7,7 @@
 // backward, dropout, the fusion's elementwise backward and the loss.  These problems are small (B*T <= a few thousand rows):
 // one wave per row, no tiling heroics.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_ds_rows_kernel(const float* __restri
     for (int j = lane; j < Tk; j += 64) dr[j] = pr[j] * (dr[j] - delta);
 }
 
-int g_attn_train_tiled = 1;     // 0: the one-wave-per-row kernels (A/B, tests)
+std::atomic<int> g_attn_train_tiled{1};     // 0: the one-wave-per-row kernels (A/B, tests)
 
 // x[r] = table[ids[r]] + pos[r % T]   (DecoderEmbeddings, module_decoder.py:309-321) and its scatter-add backward
 __global__ void embedding_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table, const float* __restrict__ pos,

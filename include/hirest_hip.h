@@ -13,7 +13,7 @@
  *   - all pointers are DEVICE pointers unless the name says host;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing
  *     synchronises, nothing allocates device memory, there is no hidden global state
- *     (besides the test / timing switches hirest_*_select_kernel, hirest_*_debug_mode and the optional profiler);
+ *     (besides the test / timing switches hirest_*_select_kernel, hirest_*_debug_mode — process-wide atomics — and the optional profiler);
  *   - return value: 0 on success, a negative HIREST_E_* for argument errors, or a
  *     positive hipError_t from the launch;
  *   - bf16 tensors are raw uint16 bit patterns (round-to-nearest-even from fp32);
