@@ -135,6 +135,20 @@ class TrainBlock(C.Structure):
                                           "wqkv2", "wo2", "w12", "w22", "wqkvT2", "woT2", "w1T2", "w2T2", "ws")] + [("ws_bytes", C.c_size_t)]
 
 
+class TrainFusionBwd(C.Structure):
+    """hirest_train_fusion_bwd (include/hirest_hip.h)."""
+    _fields_ = [("struct_size", C.c_uint64)] + \
+               [(n, C.c_int32) for n in ("B", "T", "E", "W", "vis_dim", "text_dim", "asr_dim", "boundary", "max_pos", "reserved")] + \
+               [("drop", C.c_float), ("seed_emb", C.c_uint32)] + \
+               [(n, C.c_void_p) for n in ("w_emb", "emb_ln_g", "t2_w", "asr1_w", "asr0_g", "norm_g",
+                                          "x0", "f", "v", "tn", "tin", "a0", "asr2", "v0", "vis2", "t", "text", "mm32", "bm32", "n_valid", "dx",
+                                          "g_emb_ln_g", "g_emb_ln_b", "g_pos", "g_w_emb", "g_b_emb", "g_mask", "g_bound", "g_t2_w", "g_t2_b", "g_t0_w", "g_t0_b",
+                                          "g_asr1_w", "g_asr1_b", "g_asr0_g", "g_asr0_b", "g_norm_g", "g_norm_b", "g_vis_w", "g_vis_b", "g_text_w", "g_text_b")] + \
+               [("items", C.POINTER(ColsumItem)), ("n_items", C.POINTER(C.c_int32)), ("max_items", C.c_int32), ("reserved2", C.c_int32),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("side_stream", C.c_void_p), ("side_ws", C.c_void_p), ("side_ws_bytes", C.c_size_t),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
+
+
 class TrainBlockGrads(C.Structure):
     """hirest_train_block_grads (include/hirest_hip.h)."""
     _fields_ = [("struct_size", C.c_uint64)] + \
@@ -254,6 +268,8 @@ _SIGNATURES = {
                                         C.c_int32, C.c_void_p]),
     "hirest_transpose_pad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "hirest_weighted_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "hirest_train_fusion_backward_scratch_bytes": (C.c_size_t, [C.POINTER(TrainFusionBwd)]),
+    "hirest_train_fusion_backward": (C.c_int, [C.POINTER(TrainFusionBwd), C.c_void_p]),
     "hirest_train_block_forward_scratch_bytes": (C.c_size_t, [C.POINTER(TrainBlock)]),
     "hirest_train_block_forward": (C.c_int, [C.POINTER(TrainBlock), C.c_void_p, C.c_size_t, C.c_void_p]),
     "hirest_train_block_backward_scratch_bytes": (C.c_size_t, [C.POINTER(TrainBlock)]),

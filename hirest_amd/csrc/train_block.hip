@@ -63,15 +63,19 @@ hipEvent_t next_event() {
 }
 
 // dW = dY^T X: A(m = o, k = r) = dY[r][o], B(n = i, k = r) = X[r][i] — both k-major, read in place
-int grad_weight(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* out, int O, int I, int R, const hirest_train_block* b,
-                const hirest_train_block_grads* g, hipStream_t main) {
-    if (!g->side_stream) return gemm_layouts(dy, ldy, 1, x, ldx, 1, nullptr, 0, out, O, I, R, b->ws, b->ws_bytes, main);
-    hipStream_t side = reinterpret_cast<hipStream_t>(g->side_stream);
+struct Streams { void* ws; size_t ws_bytes; void* side_stream; void* side_ws; size_t side_ws_bytes; };
+int grad_weight(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* out, int O, int I, int R, const Streams& g, hipStream_t main) {
+    if (!g.side_stream) return gemm_layouts(dy, ldy, 1, x, ldx, 1, nullptr, 0, out, O, I, R, g.ws, g.ws_bytes, main);
+    hipStream_t side = reinterpret_cast<hipStream_t>(g.side_stream);
     hipEvent_t ev = next_event();
     if (!ev) return (int)hipErrorOutOfMemory;
     if (hipError_t e = hipEventRecord(ev, main)) return (int)e;
     if (hipError_t e = hipStreamWaitEvent(side, ev, 0)) return (int)e;
-    return gemm_layouts(dy, ldy, 1, x, ldx, 1, nullptr, 0, out, O, I, R, g->side_ws, g->side_ws_bytes, side);
+    return gemm_layouts(dy, ldy, 1, x, ldx, 1, nullptr, 0, out, O, I, R, g.side_ws, g.side_ws_bytes, side);
+}
+int grad_weight(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* out, int O, int I, int R, const hirest_train_block* b,
+                const hirest_train_block_grads* g, hipStream_t main) {
+    return grad_weight(dy, ldy, x, ldx, out, O, I, R, Streams{b->ws, b->ws_bytes, g->side_stream, g->side_ws, g->side_ws_bytes}, main);
 }
 
 // ---- precision 1: forward and dX products on split operands (three bf16 MFMAs per product, gemm_t128x3) ----
@@ -108,11 +112,16 @@ BwdX3 plan_bwd_x3(const Shape& d, size_t base) {
     return r;
 }
 
-int colsum_item(const hirest_train_block_grads* g, const float* x, int64_t ldx, int R, int C, float* out) {
-    if (!g->items || !g->n_items || *g->n_items >= g->max_items) return HIREST_E_BADARG;
-    hirest_colsum_item& it = g->items[(*g->n_items)++];
-    it.x = x; it.row_weight = nullptr; it.row_select = nullptr; it.out = out; it.ldx = ldx; it.R = R; it.C = C; it.select_value = 0; it.reserved = 0;
+struct Items { hirest_colsum_item* items; int32_t* n; int32_t max; };
+int colsum_item(const Items& g, const float* x, int64_t ldx, int R, int C, float* out, const float* weight = nullptr, const int32_t* select = nullptr,
+                int value = 0) {
+    if (!g.items || !g.n || *g.n >= g.max) return HIREST_E_BADARG;
+    hirest_colsum_item& it = g.items[(*g.n)++];
+    it.x = x; it.row_weight = weight; it.row_select = select; it.out = out; it.ldx = ldx; it.R = R; it.C = C; it.select_value = value; it.reserved = 0;
     return 0;
+}
+int colsum_item(const hirest_train_block_grads* g, const float* x, int64_t ldx, int R, int C, float* out) {
+    return colsum_item(Items{g->items, g->n_items, g->max_items}, x, ldx, R, C, out);
 }
 
 }  // namespace
@@ -251,3 +260,81 @@ extern "C" int hirest_train_block_backward(const hirest_train_block* b, const hi
     else CHECK(gemm_layouts(dqkv, M3, 0, b->wqkv, W, 1, dap, W, g->dx, R, W, M3, b->ws, b->ws_bytes, s));       // + the residual path
     return 0;
 }
+
+// ---- the backward below the encoder blocks: embeddings + fusion (train.py:_encoder_backward after its block loop, call for call) ----
+namespace {
+struct FusionPlan { size_t dxe, dx0, dyx, df, dv, dtn, tmp, dpre, time, da0, dxa, dyxa, dv0, dyxv, dt, total; };
+FusionPlan plan_fusion(const hirest_train_fusion_bwd* f) {
+    const size_t R = (size_t)f->B * f->T, W = f->W, E = f->E, A = f->asr_dim;
+    FusionPlan r; size_t off = 0;
+    auto take = [&off](size_t n) { size_t at = off; off += al(n) * sizeof(float); return at; };
+    r.dxe = take(R * W); r.dx0 = take(R * W); r.dyx = take(R * W); r.df = take(R * E); r.dv = take(R * E); r.dtn = take((size_t)f->B * E);
+    r.tmp = take(R * E); r.dpre = take(R * E); r.time = take(R); r.da0 = take(R * A); r.dxa = take(R * A); r.dyxa = take(R * A);
+    r.dv0 = take(R * E); r.dyxv = take(R * E); r.dt = take((size_t)f->B * E);
+    r.total = off;
+    return r;
+}
+inline bool fusion_ok(const hirest_train_fusion_bwd* f) {
+    return f && f->struct_size == sizeof(*f) && f->B > 0 && f->T > 0 && f->E > 0 && f->W > 0 && f->vis_dim > 0 && f->text_dim > 0 && f->asr_dim >= 0 &&
+           f->T <= f->max_pos && f->E % 16 == 0 && f->W % 16 == 0 && f->vis_dim % 4 == 0 && f->text_dim % 4 == 0 && f->asr_dim % 4 == 0 &&
+           (int64_t)f->T * f->W <= 0x7fffffff;
+}
+}  // namespace
+
+extern "C" size_t hirest_train_fusion_backward_scratch_bytes(const hirest_train_fusion_bwd* f) { return fusion_ok(f) ? plan_fusion(f).total : 0; }
+
+extern "C" int hirest_train_fusion_backward(const hirest_train_fusion_bwd* f, void* stream) {
+    if (!fusion_ok(f) || !f->dx || !f->scratch || f->scratch_bytes < plan_fusion(f).total || !f->g_pos) return HIREST_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int B = f->B, T = f->T, E = f->E, W = f->W, A = f->asr_dim, R = B * T;
+    const FusionPlan q = plan_fusion(f);
+    char* base = reinterpret_cast<char*>(f->scratch);
+    auto F = [base](size_t at) { return reinterpret_cast<float*>(base + at); };
+    const Items it{f->items, f->n_items, f->max_items};
+    const Streams st{f->ws, f->ws_bytes, f->side_stream, f->side_ws, f->side_ws_bytes};
+    // embeddings: dropout, LayerNorm, position rows, word_embeddings (a Linear)
+    const float* dxe = f->dx;
+    if (f->drop != 0.0f) { CHECK(hirest_dropout_add_f32(f->dx, nullptr, F(q.dxe), (int64_t)R * W, f->drop, f->seed_emb, s)); dxe = F(q.dxe); }
+    float* dx0 = F(q.dx0);
+    CHECK(hirest_layernorm_bwd_f32(f->x0, dxe, f->emb_ln_g, 1e-12f, dx0, F(q.dyx), R, W, s));
+    CHECK(colsum_item(it, F(q.dyx), W, R, W, f->g_emb_ln_g));
+    CHECK(colsum_item(it, dxe, W, R, W, f->g_emb_ln_b));
+    if (hipError_t e = hipMemsetAsync(f->g_pos, 0, (size_t)f->max_pos * W * sizeof(float), s)) return (int)e;
+    CHECK(colsum_item(it, dx0, (int64_t)T * W, B, T * W, f->g_pos));              // rows t of every video add up: dx0 viewed as [B, T W]
+    CHECK(grad_weight(dx0, W, f->f, E, f->g_w_emb, W, E, R, st, s));
+    CHECK(colsum_item(it, dx0, W, R, W, f->g_b_emb));
+    float* df = F(q.df);
+    CHECK(gemm_layouts(dx0, W, 0, f->w_emb, E, 1, nullptr, 0, df, R, E, W, f->ws, f->ws_bytes, s));
+    // fusion: f = (v * tn + asr + temporal) + mask_embed[moment_mask] (+ boundary_embed[boundary_mask])
+    for (int k = 0; k < 2; ++k) CHECK(colsum_item(it, df, E, R, E, f->g_mask + (size_t)k * E, nullptr, f->mm32, k));
+    if (f->boundary)
+        for (int k = 0; k < 2; ++k) CHECK(colsum_item(it, df, E, R, E, f->g_bound + (size_t)k * E, nullptr, f->bm32, k));
+    CHECK(hirest_joint_base_bwd_f32(df, f->v, f->tn, F(q.dv), F(q.dtn), B, T, E, s));
+    // temporal embedding: Linear(1, E) -> tanh -> Linear(E, E) over the normalised time grid
+    CHECK(grad_weight(df, E, f->tin, E, f->g_t2_w, E, E, R, st, s));
+    CHECK(colsum_item(it, df, E, R, E, f->g_t2_b));
+    CHECK(gemm_layouts(df, E, 0, f->t2_w, E, 1, nullptr, 0, F(q.tmp), R, E, E, f->ws, f->ws_bytes, s));
+    CHECK(hirest_act_bwd_f32(f->tin, F(q.tmp), F(q.dpre), (int64_t)R * E, 3, s));
+    CHECK(hirest_joint_time_grid_f32(f->n_valid, B, T, F(q.time), s));
+    CHECK(colsum_item(it, F(q.dpre), E, R, E, f->g_t0_w, F(q.time)));
+    CHECK(colsum_item(it, F(q.dpre), E, R, E, f->g_t0_b));
+    if (A > 0) {                                                                  // asr_enc_layer: LayerNorm(asr_dim) -> Linear(asr_dim, E)
+        CHECK(grad_weight(df, E, f->a0, A, f->g_asr1_w, E, A, R, st, s));
+        CHECK(colsum_item(it, df, E, R, E, f->g_asr1_b));
+        CHECK(gemm_layouts(df, E, 0, f->asr1_w, A, 1, nullptr, 0, F(q.da0), R, A, E, f->ws, f->ws_bytes, s));
+        CHECK(hirest_layernorm_bwd_f32(f->asr2, F(q.da0), f->asr0_g, 1e-5f, F(q.dxa), F(q.dyxa), R, A, s));
+        CHECK(colsum_item(it, F(q.dyxa), A, R, A, f->g_asr0_g));
+        CHECK(colsum_item(it, F(q.da0), A, R, A, f->g_asr0_b));
+    }
+    // normalize_video (LayerNorm) <- clip_g_map;  tn = t / |t| <- clip_g_map_text
+    CHECK(hirest_layernorm_bwd_f32(f->v0, F(q.dv), f->norm_g, 1e-12f, F(q.dv0), F(q.dyxv), R, E, s));
+    CHECK(colsum_item(it, F(q.dyxv), E, R, E, f->g_norm_g));
+    CHECK(colsum_item(it, F(q.dv), E, R, E, f->g_norm_b));
+    CHECK(grad_weight(F(q.dv0), E, f->vis2, f->vis_dim, f->g_vis_w, E, f->vis_dim, R, st, s));
+    CHECK(colsum_item(it, F(q.dv0), E, R, E, f->g_vis_b));
+    CHECK(hirest_l2norm_bwd_f32(f->t, F(q.dtn), F(q.dt), B, E, s));
+    CHECK(grad_weight(F(q.dt), E, f->text, f->text_dim, f->g_text_w, E, f->text_dim, B, st, s));
+    CHECK(colsum_item(it, F(q.dt), E, B, E, f->g_text_b));
+    return 0;
+}
+

@@ -543,6 +543,74 @@ def _encoder_forward(model, P, inp, S):
     return x
 
 
+def _fusion_backward(model, P, S, dx, G):
+    """The backward below the encoder blocks (embeddings + fusion) through hirest_train_fusion_backward (csrc/train_block.hip): the calls of
+    _encoder_backward's tail, issued from C.  Parameter gradients go into G."""
+    lib = _lib.load()
+    B, T = S["B"], S["T"]
+    R, E, Hd = B * T, 512, 768
+    dev = dx.device
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    pos = P[_V + "embeddings.position_embeddings.weight"]
+    asr = model.use_asr
+    A = S["asr2"].shape[1] if asr else 0
+    d = _lib.TrainFusionBwd()
+    d.struct_size = C.sizeof(_lib.TrainFusionBwd)
+    d.B, d.T, d.E, d.W, d.vis_dim, d.text_dim, d.asr_dim = B, T, E, Hd, S["vis2"].shape[1], S["text"].shape[1], A
+    d.boundary, d.max_pos = int(bool(S["boundary"])), pos.shape[0]
+    d.drop, d.seed_emb = float(S["drop"]), (S["seed"] + 1) & 0xFFFFFFFF
+    for field, t in (("w_emb", P[_V + "embeddings.word_embeddings.weight"]), ("emb_ln_g", P[_V + "embeddings.LayerNorm.weight"]),
+                     ("t2_w", P["temporal_embed.2.weight"]), ("norm_g", P["clip4cap_model.normalize_video.visual_norm2d.weight"]),
+                     ("x0", S["x0"]), ("f", S["f"]), ("v", S["v"]), ("tn", S["tn"]), ("tin", S["tin"]), ("v0", S["v0"]), ("vis2", S["vis2"]),
+                     ("t", S["t"]), ("text", S["text"]), ("mm32", S["mm32"]), ("n_valid", S["n_valid"])):
+        setattr(d, field, t.data_ptr())
+    if asr:
+        d.asr1_w, d.asr0_g, d.a0, d.asr2 = (P["asr_enc_layer.1.weight"].data_ptr(), P["asr_enc_layer.0.weight"].data_ptr(), S["a0"].data_ptr(),
+                                            S["asr2"].data_ptr())
+    if S["boundary"]:
+        d.bm32 = S["bm32"].data_ptr()
+    dx = dx.contiguous()
+    d.dx = dx.data_ptr()
+    out = {_V + "embeddings.LayerNorm.weight": ("g_emb_ln_g", f32(Hd)), _V + "embeddings.LayerNorm.bias": ("g_emb_ln_b", f32(Hd)),
+           _V + "embeddings.position_embeddings.weight": ("g_pos", f32(*pos.shape)),
+           _V + "embeddings.word_embeddings.weight": ("g_w_emb", f32(Hd, E)), _V + "embeddings.word_embeddings.bias": ("g_b_emb", f32(Hd)),
+           "mask_embed.weight": ("g_mask", f32(2, E)),
+           "temporal_embed.2.weight": ("g_t2_w", f32(E, E)), "temporal_embed.2.bias": ("g_t2_b", f32(E)),
+           "temporal_embed.0.weight": ("g_t0_w", f32(E, 1)), "temporal_embed.0.bias": ("g_t0_b", f32(E)),
+           "clip4cap_model.normalize_video.visual_norm2d.weight": ("g_norm_g", f32(E)),
+           "clip4cap_model.normalize_video.visual_norm2d.bias": ("g_norm_b", f32(E)),
+           "clip_g_map.weight": ("g_vis_w", f32(E, S["vis2"].shape[1])), "clip_g_map.bias": ("g_vis_b", f32(E)),
+           "clip_g_map_text.weight": ("g_text_w", f32(E, S["text"].shape[1])), "clip_g_map_text.bias": ("g_text_b", f32(E))}
+    if S["boundary"]:
+        out["boundary_embed.weight"] = ("g_bound", f32(2, E))
+    if asr:
+        out.update({"asr_enc_layer.1.weight": ("g_asr1_w", f32(E, A)), "asr_enc_layer.1.bias": ("g_asr1_b", f32(E)),
+                    "asr_enc_layer.0.weight": ("g_asr0_g", f32(A)), "asr_enc_layer.0.bias": ("g_asr0_b", f32(A))})
+    for name, (field, t) in out.items():
+        setattr(d, field, t.data_ptr())
+        G[name] = t
+    st = _K._side
+    side = st["stream"].cuda_stream if st is not None else None
+    shapes_main = [(R, E, Hd), (R, E, E)] + ([(R, A, E)] if asr else [])                                 # dX products: (M, N, K)
+    shapes_side = [(Hd, E, R), (E, E, R), (E, S["vis2"].shape[1], R), (E, S["text"].shape[1], B)] + ([(E, A, R)] if asr else [])
+    d.ws, d.ws_bytes = ops.f32_gemm_workspace(dev, max(max(lib.hirest_gemm_f32_layouts_workspace_bytes(*m) for m in shapes_main), 1))
+    if side is not None:
+        d.side_stream = side
+        d.side_ws, d.side_ws_bytes = ops.f32_gemm_workspace(dev, max(max(lib.hirest_gemm_f32_layouts_workspace_bytes(*m) for m in shapes_side), 1), 1, side)
+    d.items, d.n_items, d.max_items = _K._c_items, C.pointer(_K._c_count), 64
+    need = lib.hirest_train_fusion_backward_scratch_bytes(C.byref(d))
+    if need == 0:
+        raise RuntimeError("hirest_train_fusion_backward: unsupported shape")
+    scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+    d.scratch, d.scratch_bytes = scratch.data_ptr(), need
+    _chk(lib.hirest_train_fusion_backward(C.byref(d), ops.stream_ptr()), "train_fusion_backward")
+    _K._c_keep.append((scratch, dx, S))
+    if st is not None:
+        st["c_used"] = True
+        st["keep"].append((scratch, dx, S))
+
+
+
 def _encoder_backward(model, P, S, dx, G):
     """Backward of _encoder_forward: dx = d loss / d feats [B*T, 768]; parameter gradients go into G."""
     lib = _lib.load()
@@ -583,6 +651,8 @@ def _encoder_backward(model, P, S, dx, G):
             G[p + f"attention.self.{nm}.weight"] = dwqkv[k * Hd:(k + 1) * Hd]
             G[p + f"attention.self.{nm}.bias"] = dbqkv[k * Hd:(k + 1) * Hd]
         dx = _K.grad_input(dqkv, Ly["wqkv"], resid=dap)                                                # + residual path
+    if C_BLOCKS and LAYOUT_GEMM and not STRIDED_GEMM and _K._pending is not None:
+        return _fusion_backward(model, P, S, dx, G)
     # ---- embeddings
     dxe = _K.dropout_add(dx, None, drop, seed + 1)
     dx0, G[_V + "embeddings.LayerNorm.weight"], G[_V + "embeddings.LayerNorm.bias"] = \

@@ -888,6 +888,28 @@ typedef struct hirest_train_block_grads {
     void* side_stream; void* side_ws; size_t side_ws_bytes;
     void* scratch; size_t scratch_bytes;
 } hirest_train_block_grads;
+/* The part of the training step's backward below the encoder blocks — VisualModel embeddings (module_visual.py:56-81) and the fusion of
+ * modeling.py:155-195: LayerNorm / dropout backward, position rows, word_embeddings, mask / boundary embeddings, v * tn, the temporal MLP,
+ * the ASR projection, normalize_video, clip_g_map, clip_g_map_text — issued by one C call (hirest_train_block's conventions: dX products on
+ * `stream`, dW products on `side_stream`, column sums appended to `items`, `scratch` alive until both have executed; bit-identical to the
+ * per-kernel calls).  g_pos [max_pos, W] is zero-filled here.  asr_dim = 0: no ASR branch; boundary = 0: no boundary embedding. */
+typedef struct hirest_train_fusion_bwd {
+    uint64_t struct_size;
+    int32_t B, T, E, W, vis_dim, text_dim, asr_dim, boundary, max_pos, reserved;
+    float drop; uint32_t seed_emb;
+    const float *w_emb, *emb_ln_g, *t2_w, *asr1_w, *asr0_g, *norm_g;             /* [W,E] [W] [E,E] [E,asr_dim] [asr_dim] [E]                  */
+    const float *x0, *f, *v, *tn, *tin, *a0, *asr2, *v0, *vis2, *t, *text;       /* kept by the forward                                         */
+    const int32_t *mm32, *bm32, *n_valid;
+    const float* dx;                                                             /* d loss / d (embedding output) [R, W]                        */
+    float *g_emb_ln_g, *g_emb_ln_b, *g_pos, *g_w_emb, *g_b_emb, *g_mask, *g_bound, *g_t2_w, *g_t2_b, *g_t0_w, *g_t0_b,
+          *g_asr1_w, *g_asr1_b, *g_asr0_g, *g_asr0_b, *g_norm_g, *g_norm_b, *g_vis_w, *g_vis_b, *g_text_w, *g_text_b;
+    hirest_colsum_item* items; int32_t* n_items; int32_t max_items, reserved2;
+    void* ws; size_t ws_bytes;
+    void* side_stream; void* side_ws; size_t side_ws_bytes;
+    void* scratch; size_t scratch_bytes;
+} hirest_train_fusion_bwd;
+size_t hirest_train_fusion_backward_scratch_bytes(const hirest_train_fusion_bwd* f);
+int hirest_train_fusion_backward(const hirest_train_fusion_bwd* f, void* stream);
 size_t hirest_train_block_forward_scratch_bytes(const hirest_train_block* b);
 int hirest_train_block_forward(const hirest_train_block* b, void* scratch, size_t scratch_bytes, void* stream);
 size_t hirest_train_block_backward_scratch_bytes(const hirest_train_block* b);
