@@ -502,6 +502,25 @@ extern "C" int hirest_caption_beam_step(const hirest_caption_decoder* d, int32_t
                      n_steps, done, ids, parent_rows, row_add, done_host, tail_workspace, tail_workspace_bytes, stream);
 }
 
+// collect_hypothesis_and_scores(..., n_best = 1) (clip4caption/train.py:590-599, beam.py:31-123) on the device: per sample the best beam (highest
+// score, lowest beam number among equals — torch.sort's order on a sorted top-k) walked back through the recorded parents.  out[b] = n | the n words.
+__global__ void beam_backtrack_kernel(const float* __restrict__ scores, const int32_t* __restrict__ tokens, const int32_t* __restrict__ backptr,
+                                      const int32_t* __restrict__ n_steps, int beam, int max_steps, int B, int32_t* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int k = 0;
+    float best = scores[(int64_t)b * beam];
+    for (int i = 1; i < beam; ++i) { const float v = scores[(int64_t)b * beam + i]; if (v > best) { best = v; k = i; } }
+    const int n = n_steps[b] < max_steps ? n_steps[b] : max_steps;
+    int32_t* o = out + (int64_t)b * (max_steps + 1);
+    o[0] = n;
+    for (int j = n - 1; j >= 0; --j) {
+        const int64_t at = ((int64_t)b * max_steps + j) * beam + k;
+        o[1 + j] = tokens[at];
+        k = backptr[at];
+    }
+}
+
 extern "C" int hirest_beam_advance(const float* val, const int32_t* idx, int32_t B, int32_t beam, int32_t vocab, int32_t step,
                                    int32_t max_steps, int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr, int32_t* n_steps,
                                    int32_t* done, int32_t* next_ids, int32_t* next_parents, float* next_add, void* stream) {
@@ -509,5 +528,13 @@ extern "C" int hirest_beam_advance(const float* val, const int32_t* idx, int32_t
     if (B <= 0 || beam <= 0 || beam > 64 || vocab <= 0 || step < 0 || step >= max_steps) return HIREST_E_BADARG;
     hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), val, idx, beam, vocab, step,
                        max_steps, eos_id, scores, tokens, backptr, n_steps, done, next_ids, next_parents, next_add);
+    return hirest_launch_status();
+}
+
+extern "C" int hirest_beam_backtrack(const float* scores, const int32_t* tokens, const int32_t* backptr, const int32_t* n_steps, int32_t B,
+                                     int32_t beam, int32_t max_steps, int32_t* out, void* stream) {
+    if (!scores || !tokens || !backptr || !n_steps || !out || B <= 0 || beam <= 0 || max_steps <= 0) return HIREST_E_BADARG;
+    hipLaunchKernelGGL(beam_backtrack_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), scores, tokens, backptr,
+                       n_steps, beam, max_steps, B, out);
     return hirest_launch_status();
 }

@@ -634,6 +634,10 @@ int hirest_caption_beam_step(const hirest_caption_decoder* d, int32_t B, int32_t
 int hirest_beam_advance(const float* val, const int32_t* idx, int32_t B, int32_t beam, int32_t vocab, int32_t step, int32_t max_steps,
                         int32_t eos_id, float* scores, int32_t* tokens, int32_t* backptr, int32_t* n_steps, int32_t* done,
                         int32_t* next_ids, int32_t* next_parents, float* next_add, void* stream);
+/* The read-out of a finished search (clip4caption/train.py:590-599 with n_best = 1): per sample the best beam — highest score, lowest beam
+ * number among equal scores — walked back through backptr.  out int32 [B, max_steps + 1]: out[b][0] = n_steps[b], then that many words. */
+int hirest_beam_backtrack(const float* scores, const int32_t* tokens, const int32_t* backptr, const int32_t* n_steps, int32_t B,
+                          int32_t beam, int32_t max_steps, int32_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Joint model, training side: backward of MomentModel.train_moment_retrieval (modeling.py:155-270) in exact fp32.

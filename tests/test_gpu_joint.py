@@ -257,6 +257,11 @@ def test_step_captioning_vs_reference(dev, golden_dir, case, precision):
     res = model.test_step(batch, num_beams=pred["beams"], return_ids=True)
     assert res["prediction"] == pred["prediction"]
     assert [" ".join(str(i) for i in h) for h in res["token_ids"]] == pred["prediction"]
+    # the read-out of the finished search on the device (default, hirest_beam_backtrack) and on the host (BeamState) pick the same words
+    assert model.caption_device_readout
+    model.caption_device_readout = False
+    assert model.test_step(batch, num_beams=pred["beams"], return_ids=True) == res
+    model.caption_device_readout = True
     # default = decoding with the self-attention K / V of earlier positions kept per beam; recomputing the whole prefix every
     # step, as the reference does (train.py:547-566), gives the same tokens
     assert model.caption_kv_cache
