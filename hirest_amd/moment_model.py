@@ -1006,14 +1006,18 @@ class MomentModel(nn.Module):
         return self._caption_texts([bm.best_hypothesis() for bm in beams], return_ids)
 
     def _caption_texts(self, hyps, return_ids):
-        texts = []
-        for h in hyps:
-            toks = [self.tokenizer_vocab[i] if self.tokenizer_vocab is not None else str(i) for i in h]
-            if "[SEP]" in toks:
-                toks = toks[:toks.index("[SEP]")]
-            if "[PAD]" in toks:
-                toks = toks[:toks.index("[PAD]")]
-            texts.append(" ".join(toks).replace(" ##", "").strip("##").strip())
+        vocab = self.tokenizer_vocab
+        if vocab is None:                                    # ids printed as decimal strings: no '[SEP]' / '[PAD]' / '##' to handle
+            texts = [" ".join(map(str, h)) for h in hyps]
+        else:
+            texts = []
+            for h in hyps:
+                toks = [vocab[i] for i in h]
+                if "[SEP]" in toks:
+                    toks = toks[:toks.index("[SEP]")]
+                if "[PAD]" in toks:
+                    toks = toks[:toks.index("[PAD]")]
+                texts.append(" ".join(toks).replace(" ##", "").strip("##").strip())
         res = {"prediction": texts}
         if return_ids:
             res["token_ids"] = hyps

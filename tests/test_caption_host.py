@@ -1,4 +1,4 @@
-"""MomentModel._trim_index_table (the vectorised form test_step_captioning uses) against the per-sample list walk _trim_index, which restates
+"""Host-side pieces of step captioning.  MomentModel._trim_index_table (the vectorised form test_step_captioning uses) against the per-sample list walk _trim_index, which restates
 trim_feats (modeling.py:529-554): more selected frames than slots -> the first max_frames; fewer -> frame j repeated
 (j + 1) F // N - j F // N times; none -> zero rows (-1)."""
 import random
@@ -31,3 +31,14 @@ def test_trim_index_closed_form_examples():
     assert MomentModel._trim_index_table(mask, 20).tolist()[0] == [2] * 6 + [5] * 7 + [6] * 7
     mask[0, :] = 1
     assert MomentModel._trim_index_table(mask, 4).tolist()[0] == [0, 1, 2, 3]
+
+
+def test_caption_texts_with_and_without_a_vocabulary():
+    """_caption_texts: ids as decimal strings when no BERT vocabulary is attached; with one, the reference's read-out (train.py:600-611:
+    cut at [SEP] / [PAD], join word pieces)."""
+    m = MomentModel.__new__(MomentModel)                      # the method only reads tokenizer_vocab
+    m.tokenizer_vocab = None
+    assert m._caption_texts([[7, 102, 5], []], True) == {"prediction": ["7 102 5", ""], "token_ids": [[7, 102, 5], []]}
+    m.tokenizer_vocab = ["[PAD]", "[CLS]", "[SEP]", "cut", "##ting", "board", "##s"]
+    res = m._caption_texts([[3, 4, 5, 6, 2, 3], [5, 0, 3], [2]], False)
+    assert res == {"prediction": ["cutting boards", "board", ""]}
