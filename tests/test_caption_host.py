@@ -34,7 +34,7 @@ def test_trim_index_closed_form_examples():
 
 
 def test_caption_texts_with_and_without_a_vocabulary():
-    """_caption_texts: ids as decimal strings when no BERT vocabulary is attached; with one, the reference's read-out (train.py:600-611:
+    """_caption_texts: ids as decimal strings when no BERT vocabulary is attached; with one, the reference's read-out (modeling.py:614-626:
     cut at [SEP] / [PAD], join word pieces)."""
     m = MomentModel.__new__(MomentModel)                      # the method only reads tokenizer_vocab
     m.tokenizer_vocab = None
