@@ -334,6 +334,45 @@ def test_encoder_blocks_issued_from_c_equal_the_per_kernel_calls(dev, golden_dir
         train.C_BLOCKS, train.SIDE_STREAM_DW = True, True
 
 
+def test_c_issued_step_without_an_asr_branch(dev, golden_dir):
+    """A model built with asr_dim <= 0 has no asr_enc_layer (modeling.py:38-43): the C-issued backward (asr_dim = 0 in hirest_train_fusion_bwd)
+    equals the per-kernel path bit for bit there too, both tasks, train mode."""
+    import hirest_amd
+    from hirest_amd import train
+    from hirest_amd.synth import joint_inputs, train_targets
+    model = hirest_amd.MomentModel(n_frames=-1, asr_dim=-1, args=None, clip_model=None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert not any(k.startswith("asr_enc_layer") for k in shapes)
+    model.load_state_dict(synth.joint_state_dict(shapes, 37), strict=False)
+    model = model.to(dev).train()
+    B, T = 3, 77
+    vis, asr, text, vis_mask, moment_mask, bounds = joint_inputs("train.noasr", B, T, 59)
+    st, et, seg, prev = train_targets("train.noasr", B, T, 59, bounds)
+    batches = [{"tasks": ["moment_retrieval"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "text_feat": text,
+                "moment_retrieval_start_target": st, "moment_retrieval_end_target": et},
+               {"tasks": ["moment_segmentation"], "vis_feats": vis, "vis_mask": vis_mask, "moment_mask": moment_mask, "text_feat": text,
+                "prev_boundary_mask": prev, "moment_segmentation_target": seg}]
+
+    def grads(b, c_blocks):
+        train.C_BLOCKS = c_blocks
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(5)
+        loss = model.train_step(b)["loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    try:
+        for b in batches:
+            lw, want = grads(b, False)
+            lg, got = grads(b, True)
+            assert torch.equal(lw, lg) and torch.isfinite(lw) and got.keys() == want.keys()
+            for n in want:
+                assert torch.equal(got[n], want[n]), (b["tasks"][0], n)
+    finally:
+        train.C_BLOCKS = True
+
+
 def test_backward_refuses_parameters_updated_in_place_after_the_forward(dev, golden_dir):
     """The forward keeps fp32 parameters by reference and the backward multiplies by them again: forward A, forward B, backward A,
     optimizer.step(), backward B would back-propagate B through the updated weights.  The version counters recorded in the forward
