@@ -54,6 +54,7 @@ C_BLOCKS = os.environ.get("HIREST_TRAIN_C_BLOCKS", "1") != "0"
 # the residual stream stay fp32; the reference's counterpart is --fp16's autocast, run.py:549-551).  C_BLOCKS only.  A model switched with
 # MomentModel.set_precision('bf16x3') trains at bf16x3 whatever this says.
 GEMM_PRECISION = os.environ.get("HIREST_TRAIN_GEMM", "fp32")
+GROUPED_WEIGHT_SPLIT = True   # bf16x3: the blocks' weights split both ways by one grouped launch per step; False: by each block call itself (tests)
 _SIDE = {}
 
 
@@ -513,7 +514,7 @@ def _encoder_forward(model, P, inp, S):
     if GEMM_PRECISION not in ("fp32", "bf16x3"):
         raise ValueError(f"hirest_amd.train.GEMM_PRECISION = {GEMM_PRECISION!r}: 'fp32' or 'bf16x3'")
     x3 = c_blocks and (GEMM_PRECISION == "bf16x3" or getattr(model, "precision", "fp32") == "bf16x3")   # MomentModel.set_precision covers training too
-    wsplit = _split_block_weights(P, [c[0] for c in cats], vis.device) if x3 else None
+    wsplit = _split_block_weights(P, [c[0] for c in cats], vis.device) if x3 and GROUPED_WEIGHT_SPLIT else None
     for i in range(nl):
         p = _V + f"encoder.layer.{i}."
         wqkv, bqkv = cats[i]

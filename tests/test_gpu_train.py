@@ -373,6 +373,34 @@ def test_c_issued_step_without_an_asr_branch(dev, golden_dir):
         train.C_BLOCKS = True
 
 
+def test_bf16x3_blocks_split_their_weights_themselves_to_the_same_bits(dev, golden_dir):
+    """precision 1 of hirest_train_block: with the weights pre-split by one grouped launch (default) or split by each block call
+    (hirest_split2_bf16 / hirest_split2_transposed_bf16 inside the call) the operands are the same bits, so loss and gradients are too."""
+    from hirest_amd import train
+    model, batch, seg_batch, _, _ = _setup(golden_dir, "a", dev)
+    model.train()
+
+    def grads(b, grouped):
+        train.GROUPED_WEIGHT_SPLIT = grouped
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(9)
+        loss = model.train_step(b)["loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    train.GEMM_PRECISION = "bf16x3"
+    try:
+        for b in (batch, seg_batch):
+            lw, want = grads(b, True)
+            lg, got = grads(b, False)
+            assert torch.equal(lw, lg) and got.keys() == want.keys()
+            for n in want:
+                assert torch.equal(got[n], want[n]), (b["tasks"][0], n)
+    finally:
+        train.GEMM_PRECISION, train.GROUPED_WEIGHT_SPLIT = "fp32", True
+
+
 def test_backward_refuses_parameters_updated_in_place_after_the_forward(dev, golden_dir):
     """The forward keeps fp32 parameters by reference and the backward multiplies by them again: forward A, forward B, backward A,
     optimizer.step(), backward B would back-propagate B through the updated weights.  The version counters recorded in the forward
