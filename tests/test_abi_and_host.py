@@ -79,6 +79,37 @@ def test_argument_errors_without_gpu(lib):
     assert ctypes.sizeof(ColsumItem) == 56 and COLSUM_GROUP_MAX == 40       # hirest_colsum_item / HIREST_COLSUM_GROUP_MAX
     assert lib.hirest_weighted_colsum_grouped_f32(None, 3, None) == -1
     assert lib.hirest_weighted_colsum_grouped_f32((ColsumItem * 2)(), 2, None) == -1     # NULL matrices: refused before any launch
+    # round 6: the joint model's bf16x3 pieces, the C-issued training step, the captioning read-out
+    assert lib.hirest_layernorm_f32_split2(None, 768, None, 0, None, None, 1e-12, None, 768, None, 1536, 5, 768, None) == -1
+    assert lib.hirest_split2_transposed_bf16(None, 768, None, 1536, 768, 768, None) == -1
+    assert ctypes.sizeof(_lib.SplitItem) == 48
+    assert lib.hirest_split2_grouped_bf16(None, 2, None) == -1 and lib.hirest_split2_grouped_bf16((_lib.SplitItem * 2)(), 2, None) == -1
+    assert lib.hirest_beam_backtrack(None, None, None, None, 5, 5, 48, None, None) == -1
+    tb = _lib.TrainBlock()
+    assert lib.hirest_train_block_forward_scratch_bytes(ctypes.byref(tb)) == 0                 # struct_size 0: another layout
+    tb.struct_size = ctypes.sizeof(_lib.TrainBlock)
+    tb.B, tb.T, tb.heads, tb.width, tb.mlp = 5, 300, 12, 768, 3072
+    al64 = lambda n: (n + 63) // 64 * 64
+    R = 1500
+    assert lib.hirest_train_block_forward_scratch_bytes(ctypes.byref(tb)) == 4 * al64(R * 768)
+    assert lib.hirest_train_block_backward_scratch_bytes(ctypes.byref(tb)) == \
+        4 * (8 * al64(R * 768) + 2 * al64(R * 3072) + al64(5 * 12 * 300 * 300) + al64(R * 2304))
+    tb.precision = 1
+    assert lib.hirest_train_block_forward_scratch_bytes(ctypes.byref(tb)) > 4 * al64(R * 768)
+    tb.precision = 2
+    assert lib.hirest_train_block_forward_scratch_bytes(ctypes.byref(tb)) == 0                 # unknown precision
+    tb.precision = 0
+    assert lib.hirest_train_block_forward(ctypes.byref(tb), None, 0, None) == -1               # no scratch: refused before any launch
+    tg = _lib.TrainBlockGrads()
+    assert lib.hirest_train_block_backward(ctypes.byref(tb), ctypes.byref(tg), None) == -1     # struct_size 0
+    tf = _lib.TrainFusionBwd()
+    assert lib.hirest_train_fusion_backward_scratch_bytes(ctypes.byref(tf)) == 0 and lib.hirest_train_fusion_backward(ctypes.byref(tf), None) == -1
+    tf.struct_size = ctypes.sizeof(_lib.TrainFusionBwd)
+    tf.B, tf.T, tf.E, tf.W, tf.vis_dim, tf.text_dim, tf.asr_dim, tf.max_pos = 5, 300, 512, 768, 1024, 1024, 384, 2048
+    assert lib.hirest_train_fusion_backward_scratch_bytes(ctypes.byref(tf)) > 0
+    assert lib.hirest_train_fusion_backward(ctypes.byref(tf), None) == -1                      # no dx / scratch
+    tf.T = 4096
+    assert lib.hirest_train_fusion_backward_scratch_bytes(ctypes.byref(tf)) == 0               # longer than the position table
 
 
 def test_workspace_size_formula(lib):
